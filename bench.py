@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the path-trace hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one tick of the reference's render loop (main.js:838-857): one
+sample for every pixel of the frame (camera ray -> full path, tracer.fs:436-518)
+accumulated into the running-mean radiance buffer.  N=1 workload = BASELINE
+configs[1]: synthetic 'bunny' scene (69 316 triangles), 1920x1080, depth 8.
+For N>1 (launched by torch.distributed.run, one rank per GPU) the frame grows
+with N (weak scaling: 1920*a x 1080*b, a*b = N), is cut into 32x32 tiles dealt
+round-robin to the ranks (no data-path collective), and ONE RCCL sum-reduce of
+the RGBA32F radiance buffer to rank 0 closes the timed region.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def frame_for(n_gpus, w, h):
+    fac = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}.get(n_gpus)
+    if fac is None:
+        fac = (n_gpus, 1)
+    return w * fac[0], h * fac[1]
+
+
+def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=15.0):
+    """The oracle (kind 'port': plain-C restatement, OpenMP over rows) timed on
+    this host's cores on a bounded, uniformly tile-sampled part of the SAME
+    frame: shard 0 of S round-robin 32x32-tile shards, S chosen from a probe."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as O
+    cores = os.cpu_count() or 1
+    acc = np.zeros((H, W, 4), np.float32)
+    n_tiles = ((W + 31) // 32) * ((H + 31) // 32)
+
+    def run(n_shards):
+        c = O.OCounters()
+        acc[:] = 0
+        t0 = time.perf_counter()
+        O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], lens, cam["env_theta"], bounces, 0, 1, 1, acc,
+                 counters=c, shard=0, n_shards=n_shards, tile=32)
+        return time.perf_counter() - t0, c.as_dict()["samples"]
+
+    probe_shards = max(1, n_tiles // 32)
+    t, s = run(probe_shards)
+    rate = s / max(t, 1e-9)
+    want = rate * budget_s
+    n_shards = max(1, int(round(W * H / max(want, 1.0))))
+    t, s = run(n_shards)
+    return {"value": round(s / t / 1e6, 5), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/liboracle.so (C restatement, OpenMP x{cores}), 1 tick over every {n_shards}-th 32x32 tile "
+                      f"of the same {W}x{H} depth-{bounces} frame: {s} samples in {t:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--mesh-n", type=int, default=76, help="cube-sphere resolution: 12*n^2 triangles (289 -> 1M)")
+    ap.add_argument("--aperture", type=float, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n_gpus = world
+
+    import numpy as np
+    import torch
+    import fspt_amd
+    from fspt_amd import scene as S
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libfspt has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if n_gpus > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    t0 = time.perf_counter()
+    arrays = S.bunny_scene(n=args.mesh_n)
+    build_s = time.perf_counter() - t0
+    W, H = frame_for(n_gpus, args.width, args.height)
+    cam = dict(S.BUNNY_CAMERA)
+    if args.aperture is not None:
+        cam["aperture"] = args.aperture
+    lens = S.lens_features(cam["focal_depth"], cam["aperture"])
+
+    pt = fspt_amd.PathTracer(arrays, W, H, device=local_rank, num_bounces=args.bounces)
+    pt.set_camera(**cam)
+    pt.set_shard(rank, n_gpus, 32)
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    pt.bind_accumulator(accum.data_ptr(), keep=accum)
+    pt.seed(1)
+
+    def barrier():
+        pt.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup (untimed) ----
+    if args.warmup > 0:
+        pt.render(args.warmup)
+    barrier()
+    # ---- timed: exactly K steps ----
+    t_start = time.perf_counter()
+    pt.render(args.steps)
+    pt.sync()
+    if dist is not None:
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms, launches = pt.last_kernel_ms()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_samples = float(W) * H * args.steps
+    value = total_samples / elapsed / 1e6
+
+    # ---- algorithmic bytes (counting variant of the same kernel, outside the timed region) ----
+    if rank == 0:
+        pt.enable_counters(True)
+        L = fspt_amd._lib
+        L.check(L.lib().fspt_counters_reset(pt._t))
+        pt.render(1)
+        cnt = pt.counters()
+        pt.enable_counters(False)
+        bps = fspt_amd.bytes_per_sample(cnt)
+        samples_per_launch = cnt["samples"]
+        avg_launch_s = kernel_ms / 1e3 / max(1, launches)
+        achieved = bps * samples_per_launch / avg_launch_s / 1e9
+        per_sample = {k: round(v / max(1, cnt["samples"]), 4) for k, v in cnt.items() if k != "samples"}
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "fspt::k_trace<true,false>", "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                    "bytes_per_sample": round(bps, 1), "per_sample": per_sample}
+        out = {
+            "metric": "Msamples/s at 1920x1080 depth 8 (bunny, 70k tri)",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"bunny-synthetic {arrays.n_tris} tri, {W}x{H}, depth {args.bounces}, "
+                                   f"1 spp/step, aperture {cam['aperture']}",
+                       "scene_bytes": arrays.nbytes(), "bvh_nodes": arrays.n_nodes, "bvh_depth": arrays.depth,
+                       "env_bins": int(arrays.bins.size // 4), "sharding": f"32x32 tiles round-robin over {n_gpus}",
+                       "scene_build_s": round(build_s, 2)},
+            "roofline": roofline,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(arrays, W, H, cam, lens, args.bounces)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    pt.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,9 @@
+"""fspt_amd — MI355X-native path-trace hot path of apbodnar/FSPT.
+
+Product code only: the HIP kernels + C ABI (csrc/, libfspt.so), the ctypes
+binding (_lib), the host mirror of the reference's frame driver (tracer) and
+the scene assembly helpers (scene).  Nothing here imports oracle/.
+"""
+from ._lib import FsptError, lib  # noqa: F401
+from .scene import SceneArrays, build_scene, bunny_scene, BUNNY_CAMERA  # noqa: F401
+from .tracer import PathTracer, Scene, bytes_per_sample  # noqa: F401

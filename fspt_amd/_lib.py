@@ -1,0 +1,132 @@
+"""ctypes binding of libfspt.so (include/fspt.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).
+There is no fallback: if the shared object is missing this module raises, and
+every device entry point raises ``FsptError`` when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfspt.so")
+
+
+class FsptError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libfspt error {code}: {msg}")
+        self.code = code
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("bvh", C.POINTER(C.c_float)), ("n_nodes", C.c_uint32),
+        ("tri", C.POINTER(C.c_float)), ("n_tris", C.c_uint32),
+        ("mat", C.POINTER(C.c_float)),
+        ("norm", C.POINTER(C.c_float)),
+        ("uv", C.POINTER(C.c_float)),
+        ("atlas", C.POINTER(C.c_uint8)), ("atlas_res", C.c_uint32), ("atlas_layers", C.c_uint32),
+        ("env", C.POINTER(C.c_uint8)), ("env_w", C.c_uint32), ("env_h", C.c_uint32),
+        ("bins", C.POINTER(C.c_uint32)), ("n_bins", C.c_uint32),
+        ("leaf_size", C.c_uint32),
+    ]
+
+
+class CameraParams(C.Structure):
+    _fields_ = [
+        ("P", C.c_float * 3), ("I", C.c_float * 3), ("fov_scale", C.c_float),
+        ("lens", C.c_float * 2), ("env_theta", C.c_float), ("num_bounces", C.c_uint32),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "steps", "leaves", "shades", "env_lookups")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class PropDesc(C.Structure):
+    _fields_ = [
+        ("rotate", C.POINTER(C.c_double)), ("n_rotate", C.c_uint32),
+        ("scale", C.c_double), ("translate", C.c_double * 3),
+        ("normals_mode", C.c_uint32),
+        ("diffuse_layer", C.c_double), ("emissive_layer", C.c_double),
+        ("normal_layer", C.c_double), ("mr_layer", C.c_double),
+        ("emittance", C.c_double * 3),
+        ("ior", C.c_double), ("dielectric", C.c_double),
+    ]
+
+
+# every symbol include/fspt.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+_F = C.POINTER(C.c_float)
+_U32 = C.POINTER(C.c_uint32)
+SIGNATURES = {
+    "fspt_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(_VP)]),
+    "fspt_scene_destroy": (C.c_int, [_VP]),
+    "fspt_scene_depth": (C.c_int, [_VP, _U32]),
+    "fspt_target_create": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
+    "fspt_target_destroy": (C.c_int, [_VP]),
+    "fspt_target_set_shard": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "fspt_target_bind_accumulator": (C.c_int, [_VP, _VP]),
+    "fspt_target_accumulator": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "fspt_camera": (C.c_int, [_VP, _F, _F, C.c_float, _F, C.c_float]),
+    "fspt_set_rays": (C.c_int, [_VP, _F, _F]),
+    "fspt_read_rays": (C.c_int, [_VP, _F, _F]),
+    "fspt_trace": (C.c_int, [_VP, C.c_uint32, C.c_float, C.c_float, C.c_uint32]),
+    "fspt_render": (C.c_int, [_VP, C.POINTER(CameraParams), C.c_uint32, C.c_uint32, C.c_uint64]),
+    "fspt_rand_base_next": (C.c_float, [C.POINTER(C.c_uint64)]),
+    "fspt_clear": (C.c_int, [_VP]),
+    "fspt_sync": (C.c_int, [_VP]),
+    "fspt_read_radiance": (C.c_int, [_VP, _F]),
+    "fspt_intersect": (C.c_int, [_VP, _F, C.c_uint32, _F, C.POINTER(C.c_int32), _U32, _U32]),
+    "fspt_enable_counters": (C.c_int, [_VP, C.c_int]),
+    "fspt_get_counters": (C.c_int, [_VP, C.POINTER(Counters)]),
+    "fspt_counters_reset": (C.c_int, [_VP]),
+    "fspt_math_eval": (C.c_int, [C.c_int, C.c_int, _F, _F, C.c_uint32, _F]),
+    "fspt_last_kernel_ms": (C.c_int, [_VP, _F, _U32]),
+    "fspt_builder_create": (C.c_int, [C.POINTER(_VP)]),
+    "fspt_builder_destroy": (C.c_int, [_VP]),
+    "fspt_builder_add_obj": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(PropDesc)]),
+    "fspt_builder_build": (C.c_int, [_VP, C.c_uint32]),
+    "fspt_builder_counts": (C.c_int, [_VP, _U32, _U32, _U32]),
+    "fspt_builder_get": (C.c_int, [_VP, _F, _F, _F, _F, _F]),
+    "fspt_env_bins": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, _U32, C.c_uint32, _U32]),
+    "fspt_last_error": (C.c_char_p, []),
+    "fspt_abi_version": (C.c_int, []),
+    "fspt_device_count": (C.c_int, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libfspt.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FsptError(-100, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise FsptError(rc, lib().fspt_last_error().decode("utf-8", "replace"))
+
+
+def fptr(a):
+    return a.ctypes.data_as(_F)
+
+
+def u32ptr(a):
+    return a.ctypes.data_as(_U32)
+
+
+def u8ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))

@@ -1,0 +1,525 @@
+// fspt_api.cpp — host side of the libfspt C ABI (include/fspt.h).
+//
+// Mirrors the WebGL2 resource/draw-call layer of the reference's main.js:
+// scene upload (initBVH 408-437, initAtlas 548-560), render targets
+// (initBuffers 598-617), drawCamera (741-756), drawTracer (758-807), clear
+// (826-836) and the tick loop (838-857).  No CPU fallback: every device entry
+// point fails with FSPT_E_NO_DEVICE when there is no HIP device.
+#include "../../include/fspt.h"
+#include "fspt_device.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void fspt_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      fspt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
+      return FSPT_E_HIP;                                                                          \
+    }                                                                                             \
+  } while (0)
+
+struct fspt_scene {
+  int device = 0;
+  int num_cus = 256;
+  fspt::DScene d{};
+  void *nodes = nullptr, *tris = nullptr, *shade = nullptr, *atlas = nullptr, *env = nullptr, *bins = nullptr;
+  uint32_t depth = 0, n_nodes = 0, n_tris = 0, n_interior = 0;
+};
+
+struct fspt_target {
+  fspt_scene *scene = nullptr;
+  uint32_t W = 0, H = 0;
+  float4 *accum_own = nullptr;
+  float4 *accum = nullptr;
+  float4 *ray_pos = nullptr, *ray_dir = nullptr;
+  bool rays_valid = false;
+  uint32_t *work_counters = nullptr; // ring of zeroed work counters, one per launch
+  uint32_t n_work_counters = 0;
+  unsigned long long *counters = nullptr; // 6 x u64 on device
+  bool count = false;
+  uint32_t shard = 0, n_shards = 1, tile = 32;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  uint32_t last_launches = 0;
+};
+
+static int check_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    fspt_set_error("no HIP device available (%s); libfspt has no CPU fallback",
+                   e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return FSPT_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    fspt_set_error("device %d out of range (have %d)", device, n);
+    return FSPT_E_INVALID;
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    fspt_set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    return FSPT_E_NO_DEVICE;
+  }
+  return FSPT_OK;
+}
+
+extern "C" {
+
+const char *fspt_last_error(void) { return g_err; }
+int fspt_abi_version(void) { return FSPT_ABI_VERSION; }
+
+int fspt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+float fspt_rand_base_next(uint64_t *state) {
+  uint64_t x = *state;
+  x ^= x >> 12;
+  x ^= x << 25;
+  x ^= x >> 27;
+  *state = x;
+  uint64_t r = x * 2685821657736338717ULL;
+  return ((float)(r >> 40) * (1.0f / 16777216.0f)) * 10000.0f;
+}
+
+// ---------------------------------------------------------------------------
+// scene
+// ---------------------------------------------------------------------------
+int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out) {
+  if (!desc || !out) { fspt_set_error("fspt_scene_create: NULL argument"); return FSPT_E_INVALID; }
+  *out = nullptr;
+  if (!desc->bvh || !desc->tri || !desc->mat || !desc->norm || !desc->uv || desc->n_nodes == 0 || desc->n_tris == 0) {
+    fspt_set_error("fspt_scene_create: bvh/tri/mat/norm/uv must be non-empty");
+    return FSPT_E_INVALID;
+  }
+  if (!desc->atlas || desc->atlas_res == 0 || desc->atlas_layers == 0) {
+    fspt_set_error("fspt_scene_create: atlas must have at least one layer");
+    return FSPT_E_INVALID;
+  }
+  if (!desc->bins || desc->n_bins == 0) {
+    fspt_set_error("fspt_scene_create: radianceBins must hold at least one bin (main.js:292)");
+    return FSPT_E_INVALID;
+  }
+  if (desc->env && (desc->env_w == 0 || desc->env_h == 0)) {
+    fspt_set_error("fspt_scene_create: env given with zero size");
+    return FSPT_E_INVALID;
+  }
+  if (desc->leaf_size == 0 || desc->leaf_size > 64) {
+    fspt_set_error("fspt_scene_create: leaf_size %u out of range [1,64]", desc->leaf_size);
+    return FSPT_E_INVALID;
+  }
+  const uint32_t N = desc->n_nodes, T = desc->n_tris;
+  auto word = [&](uint32_t node, int w) -> int32_t {
+    int32_t v;
+    std::memcpy(&v, desc->bvh + (size_t)node * 9 + w, 4);
+    return v;
+  };
+  // ---- validate + renumber interior nodes (pre-order is kept) ----------------
+  std::vector<int32_t> ref(N);
+  uint32_t n_interior = 0;
+  for (uint32_t i = 0; i < N; ++i) {
+    int32_t l = word(i, 0), r = word(i, 1), ts = word(i, 2);
+    if (ts > -1) {
+      if ((uint32_t)ts > T) { fspt_set_error("node %u: triStart %d > n_tris %u", i, ts, T); return FSPT_E_INVALID; }
+      ref[i] = ~ts;
+    } else {
+      // serializeTree is pre-order (bvh.js:33-50): children come after their parent.
+      if (l <= (int32_t)i || r <= (int32_t)i || (uint32_t)l >= N || (uint32_t)r >= N) {
+        fspt_set_error("node %u: child indices (%d,%d) violate pre-order / range [%u,%u)", i, l, r, i + 1, N);
+        return FSPT_E_INVALID;
+      }
+      ref[i] = (int32_t)n_interior++;
+    }
+  }
+  std::vector<float> nodes((size_t)(n_interior ? n_interior : 1) * 16, 0.0f);
+  // depth of every node (root 0); a child's depth = parent's + 1
+  std::vector<uint32_t> depth(N, 0);
+  uint32_t max_depth = 0;
+  for (uint32_t i = 0; i < N; ++i) {
+    int32_t ts = word(i, 2);
+    if (ts > -1) continue;
+    int32_t l = word(i, 0), r = word(i, 1);
+    depth[l] = depth[i] + 1;
+    depth[r] = depth[i] + 1;
+    if (depth[i] + 1 > max_depth) max_depth = depth[i] + 1;
+    float *n = &nodes[(size_t)ref[i] * 16];
+    const float *lb = desc->bvh + (size_t)l * 9 + 3, *rb = desc->bvh + (size_t)r * 9 + 3;
+    n[0] = lb[0]; n[1] = lb[1]; n[2] = lb[2]; n[3] = lb[3]; n[4] = lb[4]; n[5] = lb[5];
+    n[6] = rb[0]; n[7] = rb[1]; n[8] = rb[2]; n[9] = rb[3]; n[10] = rb[4]; n[11] = rb[5];
+    int32_t lr[4] = {ref[l], ref[r], 0, 0};
+    std::memcpy(n + 12, lr, 16);
+  }
+  if (max_depth + 1 > 64) {
+    // the reference's stack is int[64] (tracer.fs:368)
+    fspt_set_error("BVH depth %u exceeds the traversal stack (64)", max_depth);
+    return FSPT_E_INVALID;
+  }
+  // ---- pre-edged triangles, padded by leaf_size "-1" triangles (main.js:150-152) ----
+  const uint32_t TP = T + desc->leaf_size;
+  std::vector<float> tris((size_t)TP * 12, 0.0f);
+  for (uint32_t i = 0; i < TP; ++i) {
+    float v[9];
+    if (i < T) std::memcpy(v, desc->tri + (size_t)i * 9, 36);
+    else for (int k = 0; k < 9; ++k) v[k] = -1.0f;
+    float *o = &tris[(size_t)i * 12];
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    o[3] = v[3] - v[0]; o[4] = v[4] - v[1]; o[5] = v[5] - v[2]; // e1 = v2 - v1 (tracer.fs:301)
+    o[6] = v[6] - v[0]; o[7] = v[7] - v[1]; o[8] = v[8] - v[2]; // e2 = v3 - v1 (tracer.fs:302)
+  }
+  // ---- shading records ---------------------------------------------------------
+  std::vector<float> shade((size_t)T * 40, 0.0f);
+  for (uint32_t i = 0; i < T; ++i) {
+    float *o = &shade[(size_t)i * 40];
+    std::memcpy(o, desc->norm + (size_t)i * 27, 27 * 4);
+    std::memcpy(o + 27, desc->uv + (size_t)i * 6, 6 * 4);
+    const float *m = desc->mat + (size_t)i * 12;
+    o[33] = m[0]; o[34] = m[1]; o[35] = m[2]; o[36] = m[3]; // diffuse, emissive("specular"), normal, mr layers
+    o[37] = m[9]; o[38] = m[10];                             // ior, dielectric
+  }
+
+  int rc = check_device(device);
+  if (rc) return rc;
+  fspt_scene *s = new fspt_scene();
+  s->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
+  auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    if (bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    return e;
+  };
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = upload(&s->nodes, nodes.data(), nodes.size() * 4);
+  if (e == hipSuccess) e = upload(&s->tris, tris.data(), tris.size() * 4);
+  if (e == hipSuccess) e = upload(&s->shade, shade.data(), shade.size() * 4);
+  if (e == hipSuccess)
+    e = upload(&s->atlas, desc->atlas, (size_t)desc->atlas_res * desc->atlas_res * desc->atlas_layers * 4);
+  if (e == hipSuccess && desc->env) e = upload(&s->env, desc->env, (size_t)desc->env_w * desc->env_h * 4);
+  if (e == hipSuccess) e = upload(&s->bins, desc->bins, (size_t)desc->n_bins * 16);
+  if (e != hipSuccess) {
+    fspt_set_error("scene upload failed: %s", hipGetErrorString(e));
+    fspt_scene_destroy(s);
+    return FSPT_E_HIP;
+  }
+  s->d.nodes = (const float4 *)s->nodes;
+  s->d.tris = (const float4 *)s->tris;
+  s->d.shade = (const float4 *)s->shade;
+  s->d.atlas = (const uint32_t *)s->atlas;
+  s->d.env = (const uint32_t *)s->env;
+  s->d.bins = (const uint4 *)s->bins;
+  s->d.atlas_res = desc->atlas_res;
+  s->d.atlas_layers = desc->atlas_layers;
+  s->d.env_w = desc->env ? desc->env_w : 0;
+  s->d.env_h = desc->env ? desc->env_h : 0;
+  s->d.n_bins = desc->n_bins;
+  s->d.leaf_size = desc->leaf_size;
+  s->d.root_ref = ref[0];
+  s->d.stack_n = max_depth + 1;
+  s->depth = max_depth;
+  s->n_nodes = N;
+  s->n_tris = T;
+  s->n_interior = n_interior;
+  *out = s;
+  return FSPT_OK;
+}
+
+int fspt_scene_destroy(fspt_scene *s) {
+  if (!s) return FSPT_OK;
+  hipSetDevice(s->device);
+  hipFree(s->nodes); hipFree(s->tris); hipFree(s->shade); hipFree(s->atlas); hipFree(s->env); hipFree(s->bins);
+  delete s;
+  return FSPT_OK;
+}
+
+int fspt_scene_depth(const fspt_scene *s, uint32_t *depth) {
+  if (!s || !depth) { fspt_set_error("fspt_scene_depth: NULL argument"); return FSPT_E_INVALID; }
+  *depth = s->depth;
+  return FSPT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// target
+// ---------------------------------------------------------------------------
+static const uint32_t WORK_RING = 4096;
+
+int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **out) {
+  if (!scene || !out || W == 0 || H == 0) { fspt_set_error("fspt_target_create: bad argument"); return FSPT_E_INVALID; }
+  if ((uint64_t)W * H > (1ull << 30)) { fspt_set_error("fspt_target_create: %ux%u too large", W, H); return FSPT_E_INVALID; }
+  int rc = check_device(scene->device);
+  if (rc) return rc;
+  fspt_target *t = new fspt_target();
+  t->scene = scene;
+  t->W = W; t->H = H;
+  size_t px = (size_t)W * H;
+  hipError_t e = hipMalloc((void **)&t->accum_own, px * 16);
+  if (e == hipSuccess) e = hipMalloc((void **)&t->ray_pos, px * 16);
+  if (e == hipSuccess) e = hipMalloc((void **)&t->ray_dir, px * 16);
+  if (e == hipSuccess) e = hipMalloc((void **)&t->work_counters, WORK_RING * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&t->counters, 6 * 8);
+  if (e == hipSuccess) e = hipStreamCreate(&t->stream);
+  if (e == hipSuccess) e = hipEventCreate(&t->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&t->ev1);
+  if (e == hipSuccess) e = hipMemsetAsync(t->accum_own, 0, px * 16, t->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(t->counters, 0, 48, t->stream);
+  if (e != hipSuccess) {
+    fspt_set_error("fspt_target_create: %s", hipGetErrorString(e));
+    fspt_target_destroy(t);
+    return FSPT_E_HIP;
+  }
+  t->accum = t->accum_own;
+  *out = t;
+  return FSPT_OK;
+}
+
+int fspt_target_destroy(fspt_target *t) {
+  if (!t) return FSPT_OK;
+  hipSetDevice(t->scene->device);
+  if (t->stream) hipStreamSynchronize(t->stream);
+  hipFree(t->accum_own); hipFree(t->ray_pos); hipFree(t->ray_dir); hipFree(t->work_counters); hipFree(t->counters);
+  if (t->ev0) hipEventDestroy(t->ev0);
+  if (t->ev1) hipEventDestroy(t->ev1);
+  if (t->stream) hipStreamDestroy(t->stream);
+  delete t;
+  return FSPT_OK;
+}
+
+int fspt_target_set_shard(fspt_target *t, uint32_t shard, uint32_t n_shards, uint32_t tile) {
+  if (!t) { fspt_set_error("fspt_target_set_shard: NULL target"); return FSPT_E_INVALID; }
+  if (n_shards == 0 || shard >= n_shards) { fspt_set_error("shard %u of %u invalid", shard, n_shards); return FSPT_E_INVALID; }
+  if (tile == 0 || tile % 8 != 0 || tile > 256) { fspt_set_error("tile %u must be a multiple of 8 in [8,256]", tile); return FSPT_E_INVALID; }
+  t->shard = shard; t->n_shards = n_shards; t->tile = tile;
+  return FSPT_OK;
+}
+
+int fspt_target_bind_accumulator(fspt_target *t, void *device_ptr) {
+  if (!t) { fspt_set_error("fspt_target_bind_accumulator: NULL target"); return FSPT_E_INVALID; }
+  t->accum = device_ptr ? (float4 *)device_ptr : t->accum_own;
+  return FSPT_OK;
+}
+
+int fspt_target_accumulator(fspt_target *t, void **device_ptr) {
+  if (!t || !device_ptr) { fspt_set_error("fspt_target_accumulator: NULL argument"); return FSPT_E_INVALID; }
+  *device_ptr = t->accum;
+  return FSPT_OK;
+}
+
+int fspt_camera(fspt_target *t, const float P[3], const float I[3], float fov_scale, const float lens[2],
+                float rand_base) {
+  if (!t || !P || !I || !lens) { fspt_set_error("fspt_camera: NULL argument"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  fspt::CameraP c;
+  std::memcpy(c.P, P, 12); std::memcpy(c.I, I, 12);
+  c.fov_scale = fov_scale; c.lens[0] = lens[0]; c.lens[1] = lens[1];
+  HIP_TRY(fspt::launch_camera(t->W, t->H, c, rand_base, t->ray_pos, t->ray_dir, t->stream));
+  t->rays_valid = true;
+  return FSPT_OK;
+}
+
+int fspt_set_rays(fspt_target *t, const float *pos, const float *dir) {
+  if (!t || !pos || !dir) { fspt_set_error("fspt_set_rays: NULL argument"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  size_t bytes = (size_t)t->W * t->H * 16;
+  HIP_TRY(hipMemcpyAsync(t->ray_pos, pos, bytes, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipMemcpyAsync(t->ray_dir, dir, bytes, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  t->rays_valid = true;
+  return FSPT_OK;
+}
+
+int fspt_read_rays(fspt_target *t, float *pos, float *dir) {
+  if (!t || !pos || !dir) { fspt_set_error("fspt_read_rays: NULL argument"); return FSPT_E_INVALID; }
+  if (!t->rays_valid) { fspt_set_error("fspt_read_rays: no rays generated yet"); return FSPT_E_STATE; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  size_t bytes = (size_t)t->W * t->H * 16;
+  HIP_TRY(hipMemcpyAsync(pos, t->ray_pos, bytes, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipMemcpyAsync(dir, t->ray_dir, bytes, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return FSPT_OK;
+}
+
+static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
+  p.scene = t->scene->d;
+  p.W = t->W; p.H = t->H;
+  p.ray_pos = t->ray_pos; p.ray_dir = t->ray_dir;
+  p.accum = t->accum;
+  p.counters = t->count ? t->counters : nullptr;
+  p.shard = t->shard; p.n_shards = t->n_shards; p.tile = t->tile;
+  p.tiles_x = (t->W + t->tile - 1) / t->tile;
+  p.tiles_y = (t->H + t->tile - 1) / t->tile;
+  uint32_t n_tiles = p.tiles_x * p.tiles_y;
+  p.n_owned_tiles = (n_tiles > t->shard) ? (n_tiles - t->shard + t->n_shards - 1) / t->n_shards : 0;
+}
+
+int fspt_trace(fspt_target *t, uint32_t tick, float rand_base, float env_theta, uint32_t num_bounces) {
+  if (!t) { fspt_set_error("fspt_trace: NULL target"); return FSPT_E_INVALID; }
+  if (!t->rays_valid) { fspt_set_error("fspt_trace: call fspt_camera or fspt_set_rays first"); return FSPT_E_STATE; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  fspt::TraceP p{};
+  fill_trace_params(t, p);
+  p.tick = tick; p.rand_base = rand_base; p.rand_base_cam = 0.0f; p.env_theta = env_theta; p.num_bounces = num_bounces;
+  HIP_TRY(hipMemsetAsync(t->work_counters, 0, 4, t->stream));
+  p.work_counter = t->work_counters;
+  HIP_TRY(hipEventRecord(t->ev0, t->stream));
+  HIP_TRY(fspt::launch_trace(p, false, t->count, t->scene->num_cus, t->stream));
+  HIP_TRY(hipEventRecord(t->ev1, t->stream));
+  t->timed = true; t->last_launches = 1;
+  return FSPT_OK;
+}
+
+int fspt_render(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks, uint64_t seed) {
+  if (!t || !cam) { fspt_set_error("fspt_render: NULL argument"); return FSPT_E_INVALID; }
+  if (n_ticks == 0) return FSPT_OK;
+  HIP_TRY(hipSetDevice(t->scene->device));
+  fspt::TraceP p{};
+  fill_trace_params(t, p);
+  std::memcpy(p.cam.P, cam->P, 12); std::memcpy(p.cam.I, cam->I, 12);
+  p.cam.fov_scale = cam->fov_scale; p.cam.lens[0] = cam->lens[0]; p.cam.lens[1] = cam->lens[1];
+  p.env_theta = cam->env_theta; p.num_bounces = cam->num_bounces;
+  uint64_t st = seed;
+  bool first = true;
+  uint32_t done = 0;
+  while (done < n_ticks) {
+    uint32_t batch = n_ticks - done < WORK_RING ? n_ticks - done : WORK_RING;
+    HIP_TRY(hipMemsetAsync(t->work_counters, 0, (size_t)batch * 4, t->stream));
+    if (first) { HIP_TRY(hipEventRecord(t->ev0, t->stream)); first = false; }
+    for (uint32_t k = 0; k < batch; ++k) {
+      p.rand_base_cam = fspt_rand_base_next(&st);
+      p.rand_base = fspt_rand_base_next(&st);
+      p.tick = first_tick + done + k;
+      p.work_counter = t->work_counters + k;
+      HIP_TRY(fspt::launch_trace(p, true, t->count, t->scene->num_cus, t->stream));
+    }
+    done += batch;
+  }
+  HIP_TRY(hipEventRecord(t->ev1, t->stream));
+  t->timed = true; t->last_launches = n_ticks;
+  return FSPT_OK;
+}
+
+int fspt_clear(fspt_target *t) {
+  if (!t) { fspt_set_error("fspt_clear: NULL target"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  HIP_TRY(hipMemsetAsync(t->accum, 0, (size_t)t->W * t->H * 16, t->stream));
+  return FSPT_OK;
+}
+
+int fspt_sync(fspt_target *t) {
+  if (!t) { fspt_set_error("fspt_sync: NULL target"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return FSPT_OK;
+}
+
+int fspt_read_radiance(fspt_target *t, float *out) {
+  if (!t || !out) { fspt_set_error("fspt_read_radiance: NULL argument"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  HIP_TRY(hipMemcpyAsync(out, t->accum, (size_t)t->W * t->H * 16, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return FSPT_OK;
+}
+
+int fspt_last_kernel_ms(fspt_target *t, float *ms, uint32_t *launches) {
+  if (!t || !ms) { fspt_set_error("fspt_last_kernel_ms: NULL argument"); return FSPT_E_INVALID; }
+  if (!t->timed) { fspt_set_error("fspt_last_kernel_ms: nothing traced yet"); return FSPT_E_STATE; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  HIP_TRY(hipEventSynchronize(t->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, t->ev0, t->ev1));
+  if (launches) *launches = t->last_launches;
+  return FSPT_OK;
+}
+
+int fspt_enable_counters(fspt_target *t, int enable) {
+  if (!t) { fspt_set_error("fspt_enable_counters: NULL target"); return FSPT_E_INVALID; }
+  t->count = enable != 0;
+  return FSPT_OK;
+}
+
+int fspt_counters_reset(fspt_target *t) {
+  if (!t) { fspt_set_error("fspt_counters_reset: NULL target"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  HIP_TRY(hipMemsetAsync(t->counters, 0, 48, t->stream));
+  return FSPT_OK;
+}
+
+int fspt_get_counters(fspt_target *t, fspt_counters *out) {
+  if (!t || !out) { fspt_set_error("fspt_get_counters: NULL argument"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  unsigned long long v[6];
+  HIP_TRY(hipMemcpyAsync(v, t->counters, 48, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  out->samples = v[0]; out->rays = v[1]; out->steps = v[2]; out->leaves = v[3]; out->shades = v[4];
+  out->env_lookups = v[5];
+  return FSPT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stand-alone intersect + math probes
+// ---------------------------------------------------------------------------
+int fspt_intersect(fspt_scene *s, const float *rays, uint32_t n, float *t_out, int32_t *index_out, uint32_t *steps_out,
+                   uint32_t *leaves_out) {
+  if (!s || (n && (!rays || !t_out || !index_out))) { fspt_set_error("fspt_intersect: NULL argument"); return FSPT_E_INVALID; }
+  if (n == 0) return FSPT_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  float *d_rays = nullptr, *d_t = nullptr;
+  int *d_i = nullptr;
+  uint32_t *d_s = nullptr, *d_l = nullptr;
+  int rc = FSPT_OK;
+  hipError_t e = hipMalloc((void **)&d_rays, (size_t)n * 24);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_t, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_i, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_s, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_l, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    fspt::IntersectP p{};
+    p.scene = s->d; p.rays = d_rays; p.n = n; p.t_out = d_t; p.index_out = d_i; p.steps_out = d_s; p.leaves_out = d_l;
+    e = fspt::launch_intersect(p, nullptr);
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(t_out, d_t, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(index_out, d_i, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && steps_out) e = hipMemcpy(steps_out, d_s, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && leaves_out) e = hipMemcpy(leaves_out, d_l, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { fspt_set_error("fspt_intersect: %s", hipGetErrorString(e)); rc = FSPT_E_HIP; }
+  hipFree(d_rays); hipFree(d_t); hipFree(d_i); hipFree(d_s); hipFree(d_l);
+  return rc;
+}
+
+int fspt_math_eval(int device, int op, const float *a, const float *b, uint32_t n, float *out) {
+  if (!a || !out) { fspt_set_error("fspt_math_eval: NULL argument"); return FSPT_E_INVALID; }
+  int rc = check_device(device);
+  if (rc) return rc;
+  if (n == 0) return FSPT_OK;
+  float *da = nullptr, *db = nullptr, *dout = nullptr;
+  hipError_t e = hipMalloc((void **)&da, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&dout, (size_t)n * 4);
+  if (e == hipSuccess && b) e = hipMalloc((void **)&db, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && b) e = hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = fspt::launch_math(op, da, db, n, dout, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost);
+  hipFree(da); hipFree(db); hipFree(dout);
+  if (e != hipSuccess) { fspt_set_error("fspt_math_eval: %s", hipGetErrorString(e)); return FSPT_E_HIP; }
+  return FSPT_OK;
+}
+
+} // extern "C"

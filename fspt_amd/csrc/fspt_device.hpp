@@ -1,0 +1,91 @@
+// fspt_device.hpp — device data layouts + launch parameter blocks shared by
+// fspt_kernels.hip (device code) and fspt_api.cpp (host side of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fspt {
+
+// Traversal references.  ref >= 0: interior node index (native numbering,
+// root = 0); ref < 0: leaf, first triangle = ~ref; REF_SENTINEL: empty stack.
+constexpr int REF_SENTINEL = (int)0x80000000;
+
+constexpr float MAX_T = 100000.0f;       // tracer.fs:10
+constexpr float EPSILON = 0.000001f;     // tracer.fs:11
+constexpr float M_PI_F = 3.14159265f;    // tracer.fs:12
+constexpr float M_TAU_F = M_PI_F * 2.0f; // tracer.fs:13
+constexpr float INV_PI_F = 1.0f / M_PI_F;
+constexpr int MAX_PATH_ITERS = 64;       // cap on tracer.fs:488's unbounded i--
+
+constexpr int NODE_F4 = 4;   // 64-byte two-child node = 4 x float4
+constexpr int TRI_F4 = 3;    // 48-byte pre-edged triangle = 3 x float4
+constexpr int SHADE_F4 = 10; // 160-byte shading record = 10 x float4
+
+// Node (64 B):   f4[0] = lmin.xyz lmax.x   f4[1] = lmax.yz rmin.xy
+//                f4[2] = rmin.z rmax.xyz   f4[3] = (int) left_ref right_ref 0 0
+//   (tracer.fs:374-378 fetches the header of `current` and then, dependently,
+//    the boxes of both children: 3 round trips; here one.)
+// Tri (48 B):    f4[0] = v1.xyz e1.x  f4[1] = e1.yz e2.xy  f4[2] = e2.z 0 0 0
+//   e1 = v2 - v1, e2 = v3 - v1 in binary32 = tracer.fs:301-302 precomputed.
+// Shade (160 B): floats 0..26 normTex record (n,t,bt per vertex, main.js:383-385)
+//                27..32 uv (main.js:386), 33..36 layers diffuse/emissive/normal/mr
+//                (main.js:377-379), 37 ior, 38 dielectric, 39 pad.
+struct DScene {
+  const float4 *nodes;
+  const float4 *tris;
+  const float4 *shade;
+  const uint32_t *atlas; // RGBA8 texels, layer-major
+  const uint32_t *env;   // RGBE texels (NULL = black default environment)
+  const uint4 *bins;
+  uint32_t atlas_res, atlas_layers;
+  uint32_t env_w, env_h;
+  uint32_t n_bins;
+  uint32_t leaf_size;
+  int root_ref;
+  uint32_t stack_n; // LDS stack entries per lane (tree depth + 1)
+};
+
+struct CameraP {
+  float P[3];
+  float I[3];
+  float fov_scale;
+  float lens[2];
+};
+
+struct TraceP {
+  DScene scene;
+  uint32_t W, H;
+  uint32_t tick;
+  float rand_base;     // drawTracer's randBase
+  float rand_base_cam; // drawCamera's randBase (fused ray generation only)
+  float env_theta;
+  uint32_t num_bounces;
+  CameraP cam;
+  const float4 *ray_pos; // ray buffers (two-call form)
+  const float4 *ray_dir;
+  float4 *accum;
+  uint32_t *work_counter;       // zeroed before the launch
+  unsigned long long *counters; // 6 x u64 (COUNT variants) or NULL
+  // sharding
+  uint32_t shard, n_shards, tile;
+  uint32_t tiles_x, tiles_y, n_owned_tiles;
+};
+
+struct IntersectP {
+  DScene scene;
+  const float *rays; // 6 floats per ray
+  uint32_t n;
+  float *t_out;
+  int *index_out;
+  uint32_t *steps_out;
+  uint32_t *leaves_out;
+};
+
+// launchers (fspt_kernels.hip)
+hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream);
+hipError_t launch_camera(uint32_t W, uint32_t H, const CameraP &cam, float rand_base, float4 *pos, float4 *dir,
+                         hipStream_t stream);
+hipError_t launch_intersect(const IntersectP &p, hipStream_t stream);
+hipError_t launch_math(int op, const float *a, const float *b, uint32_t n, float *out, hipStream_t stream);
+
+} // namespace fspt

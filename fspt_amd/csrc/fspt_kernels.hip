@@ -1,0 +1,767 @@
+// fspt_kernels.hip — gfx950 kernels of libfspt.
+//
+// The reference's hot path is one fragment-shader invocation per pixel
+// (shader/tracer.fs:436-518).  Here it is a persistent-threads wavefront
+// kernel: every 64-lane wave pulls pixels from a global work counter, and a
+// lane whose path has terminated is refilled with a fresh pixel in place
+// ("path regeneration"), so the wave stays full until the frame is done.  The
+// wave alternates two phases that every live lane takes part in:
+//   S  consume traversal results (tracer.fs:501-512), finish/regenerate
+//      (camera.fs:37-46, tracer.fs:515-517) or shade (tracer.fs:447-499);
+//   T  trace the lane's one or two pending rays (shadow, then extension)
+//      through the BVH (tracer.fs:366-404) in a while-while loop whose
+//      deferred-child stack lives in LDS.
+// Arithmetic is "fspt-math" (fspt_math.hpp); traversal order, pruning rule and
+// the 4-triangle leaf over-read are the reference's, so results are identical
+// to the CPU restatement bit for bit.
+#include "fspt_device.hpp"
+#include "fspt_math.hpp"
+
+namespace fspt {
+using namespace fm;
+
+#define WAVE 64
+#define BLOCK_THREADS 256
+#define WAVES_PER_BLOCK (BLOCK_THREADS / WAVE)
+#define WORK_CHUNK 256u
+
+// ---------------------------------------------------------------------------
+// rayBoxIntersect (tracer.fs:317-326); 1/dir hoisted (same value every call)
+// ---------------------------------------------------------------------------
+FM_DEV float ray_box(V3 bmin, V3 bmax, V3 o, V3 inv) {
+  float t1x = (bmin.x - o.x) * inv.x, t2x = (bmax.x - o.x) * inv.x;
+  float t1y = (bmin.y - o.y) * inv.y, t2y = (bmax.y - o.y) * inv.y;
+  float t1z = (bmin.z - o.z) * inv.z, t2z = (bmax.z - o.z) * inv.z;
+  float tMax = min_(min_(max_(t1x, t2x), max_(t1y, t2y)), max_(t1z, t2z));
+  float tMin = max_(max_(min_(t1x, t2x), min_(t1y, t2y)), min_(t1z, t2z));
+  return (tMax >= tMin && tMax > 0.0f) ? tMin : MAX_T;
+}
+
+// rayTriangleIntersect (tracer.fs:300-315) on a pre-edged triangle; the early
+// returns become one predicate with the same NaN behaviour.
+FM_DEV float ray_tri(V3 o, V3 d, V3 v1, V3 e1, V3 e2) {
+  V3 p = cross(d, e2);
+  float det = dot(e1, p);
+  float invDet = 1.0f / det;
+  V3 t = o - v1;
+  float u = dot(t, p) * invDet;
+  V3 q = cross(t, e1);
+  float v = dot(d, q) * invDet;
+  float dist = dot(e2, q) * invDet;
+  bool miss = (abs_(det) < EPSILON) || (u < 0.0f) || (u > 1.0f) || (v < 0.0f) || (u + v > 1.0f) || !(dist > EPSILON);
+  return miss ? MAX_T : dist;
+}
+
+struct Counters {
+  uint32_t samples, rays, steps, leaves, shades, envs;
+};
+
+// ---------------------------------------------------------------------------
+// intersectScene (tracer.fs:366-404) for up to two rays sharing an origin:
+// ray A (optional: the NEE shadow ray, tracer.fs:501) then ray B (primary or
+// extension ray, tracer.fs:440,507).  `stack` points at this lane's column of
+// the wave's LDS stack (entry k at stack[k*64]).
+// ---------------------------------------------------------------------------
+template <bool COUNT>
+FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 dB, int &hitA, float &tB, int &hitB,
+                       Counters &cnt) {
+  int slot = hasA ? 0 : 1;
+  V3 d = hasA ? dA : dB;
+  V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  float t = MAX_T;
+  int hit = -1;
+  int cur = S.root_ref;
+  int sp = 0;
+  hitA = -1;
+  if (COUNT) cnt.rays++;
+  const float4 *__restrict__ nodes = S.nodes;
+  const float4 *__restrict__ tris = S.tris;
+  const uint32_t leaf_size = S.leaf_size;
+  while (true) {
+    // ---- interior nodes ----------------------------------------------------
+    while (cur >= 0) {
+      if (COUNT) cnt.steps++;
+      const float4 *n = nodes + (size_t)cur * NODE_F4;
+      float4 n0 = n[0], n1 = n[1], n2 = n[2];
+      int4 n3 = *reinterpret_cast<const int4 *>(n + 3);
+      float tl = ray_box(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv);
+      float tr = ray_box(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv);
+      bool hl = tl < t, hr = tr < t;
+      bool swap = tl > tr; // tracer.fs:384: right first only when strictly nearer
+      int nearRef = swap ? n3.y : n3.x;
+      int farRef = swap ? n3.x : n3.y;
+      if (hl && hr) {
+        stack[sp * WAVE] = farRef;
+        sp++;
+        cur = nearRef;
+      } else if (hl) {
+        cur = n3.x;
+      } else if (hr) {
+        cur = n3.y;
+      } else if (sp > 0) {
+        sp--;
+        cur = stack[sp * WAVE];
+      } else {
+        cur = REF_SENTINEL;
+      }
+    }
+    if (cur == REF_SENTINEL) {
+      if (slot == 0) { // shadow ray done: only its hit/miss is consumed (tracer.fs:502)
+        hitA = hit;
+        slot = 1;
+        d = dB;
+        inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        t = MAX_T;
+        hit = -1;
+        cur = S.root_ref;
+        if (COUNT) cnt.rays++;
+        continue;
+      }
+      break;
+    }
+    // ---- leaf: processLeaf (tracer.fs:355-364), always leaf_size triangles ----
+    {
+      if (COUNT) { cnt.steps++; cnt.leaves++; }
+      int ts = ~cur;
+      const float4 *tp = tris + (size_t)ts * TRI_F4;
+      if (leaf_size == 4) {
+        float4 a[4], b[4], c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = tp[i * 3]; b[i] = tp[i * 3 + 1]; c[i] = tp[i * 3 + 2]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float res = ray_tri(o, d, v3(a[i].x, a[i].y, a[i].z), v3(a[i].w, b[i].x, b[i].y), v3(b[i].z, b[i].w, c[i].x));
+          if (res < t) { t = res; hit = ts + i; }
+        }
+      } else {
+        for (uint32_t i = 0; i < leaf_size; ++i) {
+          float4 a = tp[i * 3], b = tp[i * 3 + 1], c = tp[i * 3 + 2];
+          float res = ray_tri(o, d, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x));
+          if (res < t) { t = res; hit = ts + (int)i; }
+        }
+      }
+      if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
+      else cur = REF_SENTINEL;
+    }
+  }
+  tB = t;
+  hitB = hit;
+}
+
+// ---------------------------------------------------------------------------
+// Texture fetches (sampler state: main.js:170-180, 548-559)
+// ---------------------------------------------------------------------------
+// (float)b / 255.0f, exactly (verified for all 256 bytes: one Newton step on
+// the rounded reciprocal is correctly rounded for these operands)
+FM_DEV float unorm8(uint32_t b) {
+  const float rc = 1.0f / 255.0f;
+  float x = (float)b;
+  float q = x * rc;
+  float r = fma_(-q, 255.0f, x);
+  return fma_(r, rc, q);
+}
+FM_DEV int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+FM_DEV int wrap_clamp(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+FM_DEV float safe_floor_coord(float u) {
+  float f = floor_(u);
+  if (!(f > -1.0e9f && f < 1.0e9f)) f = 0.0f;
+  return f;
+}
+struct Tap4 { uint32_t t00, t10, t01, t11; float a, b; };
+FM_DEV Tap4 bilinear_taps(const uint32_t *texels, int w, int h, float s, float t, bool repeat_t) {
+  Tap4 r;
+  float u = fma_(s, (float)w, -0.5f), v = fma_(t, (float)h, -0.5f);
+  float fu = safe_floor_coord(u), fv = safe_floor_coord(v);
+  float a = u - fu, b = v - fv;
+  if (!(a >= 0.0f && a <= 1.0f)) a = 0.0f;
+  if (!(b >= 0.0f && b <= 1.0f)) b = 0.0f;
+  int i0 = (int)fu, j0 = (int)fv;
+  int i1 = wrap_repeat(i0 + 1, w);
+  i0 = wrap_repeat(i0, w);
+  int j1, j0w;
+  if (repeat_t) { j1 = wrap_repeat(j0 + 1, h); j0w = wrap_repeat(j0, h); }
+  else { j1 = wrap_clamp(j0 + 1, h); j0w = wrap_clamp(j0, h); }
+  r.t00 = texels[(size_t)j0w * w + i0];
+  r.t10 = texels[(size_t)j0w * w + i1];
+  r.t01 = texels[(size_t)j1 * w + i0];
+  r.t11 = texels[(size_t)j1 * w + i1];
+  r.a = a; r.b = b;
+  return r;
+}
+FM_DEV float tap_channel(const Tap4 &tp, int ch) {
+  float t00 = unorm8((tp.t00 >> (8 * ch)) & 255u), t10 = unorm8((tp.t10 >> (8 * ch)) & 255u);
+  float t01 = unorm8((tp.t01 >> (8 * ch)) & 255u), t11 = unorm8((tp.t11 >> (8 * ch)) & 255u);
+  return lerp_(lerp_(t00, t10, tp.a), lerp_(t01, t11, tp.a), tp.b);
+}
+// texture(texArray, vec3(uv, layer)) (tracer.fs:453-456)
+FM_DEV Tap4 atlas_taps(const DScene &S, float u, float v, float layer) {
+  int l = (int)floor_(layer + 0.5f);
+  if (l < 0) l = 0;
+  if (l > (int)S.atlas_layers - 1) l = (int)S.atlas_layers - 1;
+  const uint32_t *base = S.atlas + (size_t)l * S.atlas_res * S.atlas_res;
+  return bilinear_taps(base, (int)S.atlas_res, (int)S.atlas_res, u, v, true);
+}
+// envSample + envColor (tracer.fs:410-419)
+template <bool COUNT>
+FM_DEV V3 env_sample(const DScene &S, V3 dir, float envTheta, Counters &cnt) {
+  if (COUNT) cnt.envs++;
+  if (!S.env) return v3(0.0f, 0.0f, 0.0f);
+  float cx = envTheta + atan2_(dir.z, dir.x) / M_TAU_F;
+  float cy = fma_(asin_(-dir.y), INV_PI_F, 0.5f);
+  Tap4 tp = bilinear_taps(S.env, (int)S.env_w, (int)S.env_h, cx, cy, false);
+  float r = tap_channel(tp, 0), g = tap_channel(tp, 1), b = tap_channel(tp, 2), e = tap_channel(tp, 3);
+  float sc = exp2_(fma_(e, 255.0f, -128.0f));
+  return v3(r * sc, g * sc, b * sc);
+}
+// sampleEnv (tracer.fs:421-434)
+FM_DEV void sample_env(const DScene &S, float envTheta, float &seed, V3 &dir, float &pdf) {
+  float nb = (float)S.n_bins;
+  int idx = (int)(nb * rnd(seed));
+  if (idx > (int)S.n_bins - 1) idx = (int)S.n_bins - 1;
+  if (idx < 0) idx = 0;
+  uint4 bn = S.bins[idx];
+  float bx = (float)bn.x, by = (float)bn.y, bz = (float)bn.z, bw = (float)bn.w;
+  float dx = (float)S.env_w, dy = (float)S.env_h;
+  if (!S.env) { dx = 1.0f; dy = 2048.0f; }
+  float r1 = rnd(seed);
+  float r2 = rnd(seed);
+  float ux = -envTheta + fma_(bz - bx, r1, bx) / dx;
+  float uy = 0.0f + fma_(bw - by, r2, by) / dy;
+  float theta = ux * M_TAU_F;
+  float phi = uy * M_PI_F;
+  float sinPhi, cosPhi, sinTheta, cosTheta;
+  sincos_(phi, sinPhi, cosPhi);
+  sincos_(theta, sinTheta, cosTheta);
+  dir = v3(cosTheta * sinPhi, cosPhi, sinTheta * sinPhi);
+  float nominal = (dx * dy) / nb;
+  pdf = nominal / (((((bz - bx) * (bw - by)) * M_TAU_F) * M_PI_F) * sinPhi);
+}
+
+// ---------------------------------------------------------------------------
+// BRDF helpers (tracer.fs:194-298)
+// ---------------------------------------------------------------------------
+FM_DEV float gtr2(float ndh, float a) {
+  float a2 = a * a;
+  float t = fma_((a2 - 1.0f) * ndh, ndh, 1.0f);
+  return a2 / ((M_PI_F * t) * t);
+}
+FM_DEV float smithG(float ndv, float alphaG) {
+  float a = alphaG * alphaG, b = ndv * ndv;
+  return 1.0f / (ndv + sqrt_(fma_(-a, b, a + b)));
+}
+FM_DEV float gtr2_pdf(V3 incident, V3 normal, float rough, V3 bsdfDir) {
+  float alpha = max_(0.001f, rough);
+  V3 h = normalize(bsdfDir + incident);
+  float cosTheta = abs_(dot(h, normal));
+  float pdf = gtr2(cosTheta, alpha) * cosTheta;
+  return pdf / (4.0f * abs_(dot(bsdfDir, h)));
+}
+FM_DEV float schlick(V3 incident, V3 normal, float nx, float ny) {
+  float r0 = (nx - ny) / (nx + ny);
+  r0 *= r0;
+  float cosTheta = dot(normal, incident);
+  if (nx > ny) {
+    float n = nx / ny;
+    float sinTheta2 = (n * n) * fma_(-cosTheta, cosTheta, 1.0f);
+    if (sinTheta2 > 1.0f) return 1.0f;
+    cosTheta = sqrt_(1.0f - sinTheta2);
+  }
+  float x = 1.0f - cosTheta;
+  float q = ((((1.0f - r0) * x) * x) * x) * x;
+  return fma_(q, x, r0);
+}
+FM_DEV void local_frame(V3 n, V3 &tangent, V3 &bitangent) {
+  V3 up = (abs_(n.z) < 0.999f) ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+  tangent = normalize(cross(up, n));
+  bitangent = cross(n, tangent);
+}
+FM_DEV V3 frame_combine(V3 t, V3 b, V3 n, V3 h) {
+  return v3(fma_(n.x, h.z, fma_(b.x, h.y, t.x * h.x)), fma_(n.y, h.z, fma_(b.y, h.y, t.y * h.x)),
+            fma_(n.z, h.z, fma_(b.z, h.y, t.z * h.x)));
+}
+FM_DEV V3 sample_microfacet(V3 normal, float rough, float &seed) {
+  float r1 = rnd(seed), r2 = rnd(seed);
+  V3 t, b;
+  local_frame(normal, t, b);
+  float a = max_(0.001f, rough);
+  float phi = r1 * M_TAU_F;
+  float cosTheta = sqrt_((1.0f - r2) / fma_(fma_(a, a, -1.0f), r2, 1.0f));
+  float sinTheta = clamp_(sqrt_(fma_(-cosTheta, cosTheta, 1.0f)), 0.0f, 1.0f);
+  float sinPhi, cosPhi;
+  sincos_(phi, sinPhi, cosPhi);
+  V3 h = v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+  return frame_combine(t, b, normal, h);
+}
+FM_DEV V3 sample_lambert(V3 normal, float &seed) {
+  float r1 = rnd(seed), r2 = rnd(seed);
+  V3 t, b;
+  local_frame(normal, t, b);
+  float r = sqrt_(r1);
+  float phi = M_TAU_F * r2;
+  float sp, cp;
+  sincos_(phi, sp, cp);
+  V3 d;
+  d.x = r * cp;
+  d.y = r * sp;
+  d.z = sqrt_(max_(0.0f, fma_(-d.y, d.y, fma_(-d.x, d.x, 1.0f))));
+  return frame_combine(t, b, normal, d);
+}
+FM_DEV V3 eval_specular(V3 incident, V3 normal, V3 diffuse, float metallic, float rough, V3 bsdfDir) {
+  float ndl = dot(normal, bsdfDir);
+  float ndv = dot(normal, incident);
+  V3 H = normalize(bsdfDir + incident);
+  float ndh = dot(normal, H);
+  float a = max_(0.001f, rough);
+  float Ds = gtr2(ndh, a);
+  float om = 1.0f - metallic;
+  V3 Fs = v3(fma_(diffuse.x, metallic, om), fma_(diffuse.y, metallic, om), fma_(diffuse.z, metallic, om));
+  float roughg = fma_(rough, 0.5f, 0.5f);
+  roughg = roughg * roughg;
+  float Gs = smithG(ndl, roughg) * smithG(ndv, roughg);
+  return v3((Gs * Fs.x) * Ds, (Gs * Fs.y) * Ds, (Gs * Fs.z) * Ds);
+}
+
+// ---------------------------------------------------------------------------
+// camera.fs main (37-46) for pixel (x, y)
+// ---------------------------------------------------------------------------
+FM_DEV void camera_ray(uint32_t x, uint32_t y, uint32_t W, uint32_t H, const CameraP &cam, float randBase, V3 &o,
+                       V3 &d) {
+  float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+  float resx = (float)W, resy = (float)H;
+  float uvx = fma_(fx / resx, 2.0f, -1.0f), uvy = fma_(fy / resy, 2.0f, -1.0f);
+  float seed = fma_(fx, resy, randBase) + fy;
+  V3 Iv = v3(cam.I[0], cam.I[1], cam.I[2]), Pv = v3(cam.P[0], cam.P[1], cam.P[2]);
+  V3 basisX = normalize(cross(Iv, v3(0.0f, 1.0f, 0.0f)));
+  V3 basisY = normalize(cross(basisX, Iv));
+  float fov = cam.fov_scale;
+  float icx = uvx * (resx / resy), icy = uvy * 1.0f;
+  V3 screen;
+  screen.x = (fma_(icy * basisY.x, fov, (icx * basisX.x) * fov) + Iv.x) + Pv.x;
+  screen.y = (fma_(icy * basisY.y, fov, (icx * basisX.y) * fov) + Iv.y) + Pv.y;
+  screen.z = (fma_(icy * basisY.z, fov, (icx * basisX.z) * fov) + Iv.z) + Pv.z;
+  float theta = (rnd(seed) * M_PI_F) * 2.0f;
+  float r = sqrt_(rnd(seed)) * 1.414f;
+  float st, ct;
+  sincos_(theta, st, ct);
+  V3 aa;
+  aa.x = (r * ((basisX.x * ct) / resx + (basisY.x * st) / resy)) * fov;
+  aa.y = (r * ((basisX.y * ct) / resx + (basisY.y * st) / resy)) * fov;
+  aa.z = (r * ((basisX.z * ct) / resx + (basisY.z * st) / resy)) * fov;
+  float theta2 = (rnd(seed) * M_PI_F) * 2.0f;
+  float s2, c2;
+  sincos_(theta2, s2, c2);
+  float sq = sqrt_(rnd(seed));
+  float lx = cam.lens[0], ly = cam.lens[1];
+  V3 dof;
+  dof.x = (fma_(s2, basisY.x, c2 * basisX.x) * ly) * sq;
+  dof.y = (fma_(s2, basisY.y, c2 * basisX.y) * ly) * sq;
+  dof.z = (fma_(s2, basisY.z, c2 * basisX.z) * ly) * sq;
+  o = Pv + dof;
+  V3 tgt = v3(fma_(dof.x, lx, screen.x + aa.x), fma_(dof.y, lx, screen.y + aa.y), fma_(dof.z, lx, screen.z + aa.z));
+  d = normalize(tgt - o);
+}
+
+// ---------------------------------------------------------------------------
+// Per-lane path state
+// ---------------------------------------------------------------------------
+struct Path {
+  V3 ro, rd;      // pending extension / primary ray
+  V3 thr, color;  // accumulatedReflectance, color (tracer.fs:441,445)
+  V3 envDir;      // pending NEE shadow ray direction
+  V3 pend;        // accumulatedReflectance * envThroughput (tracer.fs:503)
+  float wx, wy;   // misWeights (tracer.fs:499)
+  int bounce;     // tracer.fs:446 `i`
+  int iters;
+  int pix;        // y*W + x, -1: lane idle
+  bool hasShadow;
+  bool primary;   // pending ray is the camera ray
+};
+
+// tracer.fs:447-499: shade the hit (t, tri) of ray (ro, rd); sets up the next
+// shadow + extension rays in `ps`.
+template <bool COUNT>
+FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randBase, float envTheta, Counters &cnt) {
+  if (COUNT) cnt.shades++;
+  const float4 *tp = S.tris + (size_t)ti * TRI_F4;
+  float4 ta = tp[0], tb = tp[1], tc4 = tp[2];
+  V3 v1 = v3(ta.x, ta.y, ta.z), e1 = v3(ta.w, tb.x, tb.y), e2 = v3(tb.z, tb.w, tc4.x);
+  const float4 *sp = S.shade + (size_t)ti * SHADE_F4;
+  float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6], s7 = sp[7], s8 = sp[8],
+         s9 = sp[9];
+  V3 n1 = v3(s0.x, s0.y, s0.z), t1 = v3(s0.w, s1.x, s1.y), b1 = v3(s1.z, s1.w, s2.x);
+  V3 n2 = v3(s2.y, s2.z, s2.w), t2 = v3(s3.x, s3.y, s3.z), b2 = v3(s3.w, s4.x, s4.y);
+  V3 n3 = v3(s4.z, s4.w, s5.x), t3 = v3(s5.y, s5.z, s5.w), b3 = v3(s6.x, s6.y, s6.z);
+  float uv0x = s6.w, uv0y = s7.x, uv1x = s7.y, uv1y = s7.z, uv2x = s7.w, uv2y = s8.x;
+  float layDiffuse = s8.y, laySpec = s8.z, layNormal = s8.w, layRough = s9.x;
+  float ior = s9.y, dielectric = s9.z;
+
+  V3 rd = ps.rd;
+  V3 origin = vfma(rd, tHit, ps.ro);
+  // barycentricWeights (tracer.fs:339-353); v0 = e1, v1 = e2
+  V3 w;
+  {
+    V3 vv2 = origin - v1;
+    float d00 = dot(e1, e1), d01 = dot(e1, e2), d11 = dot(e2, e2);
+    float d20 = dot(vv2, e1), d21 = dot(vv2, e2);
+    float invDenom = 1.0f / fma_(d00, d11, -(d01 * d01));
+    float bv = fma_(d11, d20, -(d01 * d21)) * invDenom;
+    float bw = fma_(d00, d21, -(d01 * d20)) * invDenom;
+    w = v3((1.0f - bv) - bw, bv, bw);
+  }
+  float tcx = fma_(w.z, uv2x, fma_(w.y, uv1x, w.x * uv0x));
+  float tcy = fma_(w.z, uv2y, fma_(w.y, uv1y, w.x * uv0y));
+  V3 texDiffuse, texEmissive, texNormal;
+  float metallic, rough;
+  {
+    Tap4 q = atlas_taps(S, tcx, tcy, layDiffuse);
+    texDiffuse = v3(tap_channel(q, 0), tap_channel(q, 1), tap_channel(q, 2));
+    q = atlas_taps(S, tcx, tcy, laySpec);
+    texEmissive = v3(tap_channel(q, 0), tap_channel(q, 1), tap_channel(q, 2));
+    q = atlas_taps(S, tcx, tcy, layRough);
+    metallic = tap_channel(q, 0);
+    rough = tap_channel(q, 1);
+    q = atlas_taps(S, tcx, tcy, layNormal);
+    texNormal = v3((tap_channel(q, 0) - 0.5f) * 2.0f, (tap_channel(q, 1) - 0.5f) * 2.0f,
+                   (tap_channel(q, 2) - 0.0f) * 1.0f);
+  }
+  rough = rough * rough;
+  float seed = fma_(origin.z, 4761.52835f, ((origin.x * randBase) * origin.y) * 1.396529836f);
+  V3 baryNormal = bary3(w, n1, n2, n3);
+  V3 baryTangent = bary3(w, t1, t2, t3);
+  V3 baryBitangent = bary3(w, b1, b2, b3);
+  V3 macroNormal = normalize(
+      v3(fma_(texNormal.z, baryNormal.x, fma_(texNormal.y, baryBitangent.x, texNormal.x * baryTangent.x)),
+         fma_(texNormal.z, baryNormal.y, fma_(texNormal.y, baryBitangent.y, texNormal.x * baryTangent.y)),
+         fma_(texNormal.z, baryNormal.z, fma_(texNormal.y, baryBitangent.z, texNormal.x * baryTangent.z))));
+  bool inside = dot(-rd, baryNormal) < 0.0f;
+  float nsx = inside ? ior : 1.0f, nsy = inside ? 1.0f : ior;
+  if (inside) macroNormal = -macroNormal;
+  V3 off = (macroNormal * EPSILON) * 2.0f;
+  V3 ro = origin + off;
+
+  V3 thr = ps.thr;
+  ps.color = v3(fma_((thr.x * texEmissive.x) * texDiffuse.x, 30.0f, ps.color.x),
+                fma_((thr.y * texEmissive.y) * texDiffuse.y, 30.0f, ps.color.y),
+                fma_((thr.z * texEmissive.z) * texDiffuse.z, 30.0f, ps.color.z));
+  V3 incident = -rd;
+  V3 envThroughput, bsdfThroughput;
+  float bsdfPdf;
+  V3 microNormal = sample_microfacet(macroNormal, rough, seed);
+  V3 envDir;
+  float envPdf;
+  sample_env(S, envTheta, seed, envDir, envPdf);
+  float cosEnv = dot(macroNormal, envDir);
+  float F = schlick(incident, microNormal, nsx, nsy);
+  bool specular = fma_(1.0f, metallic, F * (1.0f - metallic)) > rnd(seed);
+  bool refracted = false;
+  if (specular) {
+    V3 I = -incident;
+    float k = 2.0f * dot(microNormal, I);
+    rd = v3(fma_(-k, microNormal.x, I.x), fma_(-k, microNormal.y, I.y), fma_(-k, microNormal.z, I.z));
+    bsdfPdf = gtr2_pdf(incident, macroNormal, rough, rd);
+    V3 es = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, rd);
+    float cl = clamp_(dot(macroNormal, rd), 0.0f, 1.0f);
+    bsdfThroughput = v3((es.x * cl) / bsdfPdf, (es.y * cl) / bsdfPdf, (es.z * cl) / bsdfPdf);
+    V3 ee = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, envDir);
+    float ce = clamp_(cosEnv, 0.0f, 1.0f);
+    envThroughput = v3((ee.x * ce) / envPdf, (ee.y * ce) / envPdf, (ee.z * ce) / envPdf);
+  } else if (dielectric >= 0.0f) {
+    bsdfPdf = 1.0f;
+    bsdfThroughput = v3(1.0f, 1.0f, 1.0f);
+    envThroughput = v3(0.0f, 0.0f, 0.0f);
+    ro = origin - off;
+    V3 I = -incident;
+    float eta = nsx / nsy;
+    float dNI = dot(microNormal, I);
+    float kk = 1.0f - (eta * eta) * (1.0f - dNI * dNI);
+    if (kk < 0.0f) rd = v3(0.0f, 0.0f, 0.0f);
+    else {
+      float sc = fma_(eta, dNI, sqrt_(kk));
+      rd = v3(fma_(eta, I.x, -(sc * microNormal.x)), fma_(eta, I.y, -(sc * microNormal.y)),
+              fma_(eta, I.z, -(sc * microNormal.z)));
+    }
+    refracted = true; // tracer.fs:488 `i--`
+  } else {
+    rd = sample_lambert(macroNormal, seed);
+    bsdfPdf = abs_(dot(rd, macroNormal)) * INV_PI_F;
+    float cl = clamp_(dot(macroNormal, rd), 0.0f, 1.0f);
+    bsdfThroughput = v3(((texDiffuse.x * INV_PI_F) * cl) / bsdfPdf, ((texDiffuse.y * INV_PI_F) * cl) / bsdfPdf,
+                        ((texDiffuse.z * INV_PI_F) * cl) / bsdfPdf);
+    float ce = clamp_(cosEnv, 0.0f, 1.0f);
+    envThroughput = v3(((texDiffuse.x * INV_PI_F) * ce) / envPdf, ((texDiffuse.y * INV_PI_F) * ce) / envPdf,
+                       ((texDiffuse.z * INV_PI_F) * ce) / envPdf);
+  }
+  if (inside) { // tracer.fs:497
+    bsdfThroughput = v3(max_(1.0f - (((1.0f - texDiffuse.x) * tHit) * dielectric), 0.0f),
+                        max_(1.0f - (((1.0f - texDiffuse.y) * tHit) * dielectric), 0.0f),
+                        max_(1.0f - (((1.0f - texDiffuse.z) * tHit) * dielectric), 0.0f));
+  }
+  // misWeights (tracer.fs:194-203)
+  if (envPdf > EPSILON && bsdfPdf > EPSILON) {
+    float a2 = envPdf * envPdf, b2 = bsdfPdf * bsdfPdf, sum = a2 + b2;
+    ps.wx = a2 / sum;
+    ps.wy = b2 / sum;
+  } else {
+    ps.wx = 1.0f;
+    ps.wy = 0.0f;
+  }
+  ps.hasShadow = (dielectric < 0.0f && cosEnv > 0.0f); // tracer.fs:500
+  ps.envDir = envDir;
+  ps.pend = thr * envThroughput;
+  ps.ro = ro;
+  ps.rd = rd;
+  // tracer.fs:508: accumulatedReflectance *= bsdfThroughput happens after both traces; the
+  // shadow contribution above already captured the pre-update value in `pend`.
+  ps.thr = thr * bsdfThroughput;
+  if (!refracted) ps.bounce++;
+  ps.iters++;
+  ps.primary = false;
+}
+
+// Work index -> pixel.  The frame is cut into tile x tile pixel tiles dealt
+// round-robin to shards; inside a tile pixels are enumerated in 8x8 blocks so
+// that the 64 lanes of a wave start on a compact screen patch.
+FM_DEV bool work_to_pixel(const TraceP &p, uint32_t idx, uint32_t &x, uint32_t &y) {
+  uint32_t tile = p.tile;
+  uint32_t per_tile = tile * tile;
+  uint32_t k = idx / per_tile, local = idx - k * per_tile;
+  uint32_t g = p.shard + k * p.n_shards;
+  if (g >= p.tiles_x * p.tiles_y) return false;
+  uint32_t tx = g % p.tiles_x, ty = g / p.tiles_x;
+  uint32_t sub = local >> 6, l = local & 63u;
+  uint32_t subs_x = tile >> 3;
+  uint32_t sx = sub % subs_x, sy = sub / subs_x;
+  x = tx * tile + sx * 8 + (l & 7u);
+  y = ty * tile + sy * 8 + (l >> 3);
+  return x < p.W && y < p.H;
+}
+
+// ---------------------------------------------------------------------------
+// The path-trace kernel: tracer.fs main() (436-518) over the whole frame.
+// ---------------------------------------------------------------------------
+template <bool GEN_RAYS, bool COUNT>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
+  extern __shared__ int lds_stack[];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const DScene &S = p.scene;
+  int *stack = lds_stack + (size_t)wave * S.stack_n * WAVE + lane;
+
+  Counters cnt = {0, 0, 0, 0, 0, 0};
+  Path ps;
+  ps.pix = -1;
+  ps.hasShadow = false;
+  ps.primary = true;
+  ps.bounce = 0;
+  ps.iters = 0;
+  ps.wx = ps.wy = 0.0f;
+  ps.ro = ps.rd = ps.thr = ps.color = ps.envDir = ps.pend = v3(0.0f, 0.0f, 0.0f);
+
+  // traversal results of the previous T phase
+  int hitA = -1, hitB = -1;
+  float tB = MAX_T;
+
+  const uint32_t total_work = p.n_owned_tiles * p.tile * p.tile;
+  uint32_t pool_next = 0, pool_end = 0; // wave-uniform
+  bool exhausted = false;               // wave-uniform
+
+  while (true) {
+    // ================= S phase =================
+    bool need_pixel = (ps.pix < 0);
+    if (ps.pix >= 0) {
+      // NEE result (tracer.fs:500-505)
+      if (ps.hasShadow && hitA == -1) {
+        V3 es = env_sample<COUNT>(S, ps.envDir, p.env_theta, cnt);
+        ps.color = v3(fma_(ps.pend.x * es.x, ps.wx, ps.color.x), fma_(ps.pend.y * es.y, ps.wx, ps.color.y),
+                      fma_(ps.pend.z * es.z, ps.wx, ps.color.z));
+      }
+      ps.hasShadow = false;
+      bool finished = false;
+      if (hitB == -1) {
+        // tracer.fs:442-443 (primary: weight 1, reflectance 1) / 509-512
+        V3 es = env_sample<COUNT>(S, ps.rd, p.env_theta, cnt);
+        float wgt = ps.primary ? 1.0f : ps.wy;
+        V3 thr = ps.primary ? v3(1.0f, 1.0f, 1.0f) : ps.thr;
+        ps.color = v3(fma_(thr.x * es.x, wgt, ps.color.x), fma_(thr.y * es.y, wgt, ps.color.y),
+                      fma_(thr.z * es.z, wgt, ps.color.z));
+        finished = true;
+      } else if (ps.bounce >= (int)p.num_bounces || ps.iters >= MAX_PATH_ITERS) {
+        finished = true; // tracer.fs:446 loop bound reached with a live hit
+      } else {
+        shade_hit<COUNT>(S, ps, tB, hitB, p.rand_base, p.env_theta, cnt);
+      }
+      if (finished) {
+        // tracer.fs:515-517
+        float4 prev = p.accum[ps.pix];
+        float ft = (float)p.tick;
+        float den = ft + 1.0f;
+        float cr = clamp_(ps.color.x, 0.0f, 1024.0f), cg = clamp_(ps.color.y, 0.0f, 1024.0f),
+              cb = clamp_(ps.color.z, 0.0f, 1024.0f);
+        float4 o4;
+        o4.x = fma_(prev.x, ft, cr) / den;
+        o4.y = fma_(prev.y, ft, cg) / den;
+        o4.z = fma_(prev.z, ft, cb) / den;
+        o4.w = 1.0f;
+        p.accum[ps.pix] = o4;
+        ps.pix = -1;
+        need_pixel = true;
+      }
+    }
+    // ---- refill idle lanes from the wave's pixel pool ---------------------
+    while (true) {
+      unsigned long long need = __ballot(need_pixel);
+      if (need == 0ull) break;
+      uint32_t avail = pool_end - pool_next;
+      if (avail == 0u) {
+        if (exhausted) break;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(p.work_counter, WORK_CHUNK);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= total_work) { exhausted = true; break; }
+        pool_next = base;
+        pool_end = min(base + WORK_CHUNK, total_work);
+        continue;
+      }
+      uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+      uint32_t want = (uint32_t)__popcll(need);
+      uint32_t take = want < avail ? want : avail;
+      if (need_pixel && rank < take) {
+        uint32_t x, y;
+        if (work_to_pixel(p, pool_next + rank, x, y)) {
+          ps.pix = (int)(y * p.W + x);
+          if (COUNT) cnt.samples++;
+          if (GEN_RAYS) {
+            camera_ray(x, y, p.W, p.H, p.cam, p.rand_base_cam, ps.ro, ps.rd);
+          } else {
+            float4 po = p.ray_pos[ps.pix], di = p.ray_dir[ps.pix];
+            ps.ro = v3(po.x, po.y, po.z);
+            ps.rd = v3(di.x, di.y, di.z);
+          }
+          ps.thr = v3(1.0f, 1.0f, 1.0f);
+          ps.color = v3(0.0f, 0.0f, 0.0f);
+          ps.bounce = 0;
+          ps.iters = 0;
+          ps.primary = true;
+          ps.hasShadow = false;
+          need_pixel = false;
+        }
+      }
+      pool_next += take;
+    }
+    if (__ballot(ps.pix >= 0) == 0ull) break; // wave drained and no work left
+
+    // ================= T phase =================
+    if (ps.pix >= 0) {
+      trace_rays<COUNT>(S, stack, ps.ro, ps.hasShadow, ps.envDir, ps.rd, hitA, tB, hitB, cnt);
+    }
+  }
+
+  if (COUNT) {
+    unsigned long long v[6] = {cnt.samples, cnt.rays, cnt.steps, cnt.leaves, cnt.shades, cnt.envs};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      unsigned long long x = v[i];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+      if (lane == 0) atomicAdd(p.counters + i, x);
+    }
+  }
+}
+
+// camera.fs as a stand-alone pass (drawCamera, main.js:741-756)
+__global__ __launch_bounds__(BLOCK_THREADS) void k_camera(uint32_t W, uint32_t H, CameraP cam, float randBase,
+                                                         float4 *pos, float4 *dir) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W * H) return;
+  uint32_t x = i % W, y = i / W;
+  V3 o, d;
+  camera_ray(x, y, W, H, cam, randBase, o, d);
+  pos[i] = make_float4(o.x, o.y, o.z, 1.0f);
+  dir[i] = make_float4(d.x, d.y, d.z, 1.0f);
+}
+
+// intersectScene as a stand-alone pass
+__global__ __launch_bounds__(BLOCK_THREADS) void k_intersect(const IntersectP p) {
+  extern __shared__ int lds_stack[];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  int *stack = lds_stack + (size_t)wave * p.scene.stack_n * WAVE + lane;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  V3 o = v3(p.rays[i * 6], p.rays[i * 6 + 1], p.rays[i * 6 + 2]);
+  V3 d = v3(p.rays[i * 6 + 3], p.rays[i * 6 + 4], p.rays[i * 6 + 5]);
+  Counters cnt = {0, 0, 0, 0, 0, 0};
+  int hitA, hitB;
+  float tB;
+  trace_rays<true>(p.scene, stack, o, false, d, d, hitA, tB, hitB, cnt);
+  p.t_out[i] = tB;
+  p.index_out[i] = hitB;
+  if (p.steps_out) p.steps_out[i] = cnt.steps;
+  if (p.leaves_out) p.leaves_out[i] = cnt.leaves;
+}
+
+__global__ void k_math(int op, const float *a, const float *b, uint32_t n, float *out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f;
+  switch (op) {
+    case 0: r = sin_(x); break;
+    case 1: r = cos_(x); break;
+    case 2: r = atan2_(x, y); break;
+    case 3: r = asin_(x); break;
+    case 4: r = exp2_(x); break;
+    case 5: r = x / y; break;
+    case 6: r = sqrt_(x); break;
+    case 7: { float sd = x; r = rnd(sd); break; }
+    case 8: r = fract_(x); break;
+    default: r = 0.0f;
+  }
+  out[i] = r;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static size_t stack_bytes(const DScene &S) { return (size_t)WAVES_PER_BLOCK * S.stack_n * WAVE * sizeof(int); }
+
+hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream) {
+  size_t lds = stack_bytes(p.scene);
+  // persistent grid: enough resident blocks to fill every CU; the work counter balances the rest
+  int blocks_per_cu = 4;
+  uint32_t total_work = p.n_owned_tiles * p.tile * p.tile;
+  uint32_t max_useful = (total_work + BLOCK_THREADS - 1) / BLOCK_THREADS;
+  uint32_t grid = (uint32_t)(num_cus * blocks_per_cu);
+  if (grid > max_useful) grid = max_useful;
+  if (grid == 0) return hipSuccess;
+  dim3 g(grid), b(BLOCK_THREADS);
+  if (gen_rays) {
+    if (count) hipLaunchKernelGGL((k_trace<true, true>), g, b, lds, stream, p);
+    else hipLaunchKernelGGL((k_trace<true, false>), g, b, lds, stream, p);
+  } else {
+    if (count) hipLaunchKernelGGL((k_trace<false, true>), g, b, lds, stream, p);
+    else hipLaunchKernelGGL((k_trace<false, false>), g, b, lds, stream, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_camera(uint32_t W, uint32_t H, const CameraP &cam, float rand_base, float4 *pos, float4 *dir,
+                         hipStream_t stream) {
+  uint32_t n = W * H;
+  hipLaunchKernelGGL(k_camera, dim3((n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS), 0, stream, W, H, cam,
+                     rand_base, pos, dir);
+  return hipGetLastError();
+}
+
+hipError_t launch_intersect(const IntersectP &p, hipStream_t stream) {
+  if (p.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_intersect, dim3((p.n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS),
+                     stack_bytes(p.scene), stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_math(int op, const float *a, const float *b, uint32_t n, float *out, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_math, dim3((n + 255) / 256), dim3(256), 0, stream, op, a, b, n, out);
+  return hipGetLastError();
+}
+
+} // namespace fspt

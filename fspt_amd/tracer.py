@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's frame driver (main.js:741-857) on top of
+libfspt: same method names, same argument meaning, same call order.
+
+    pt = PathTracer(scene_arrays, width, height)
+    pt.eye, pt.dir, pt.fovScale, pt.lensFeatures, pt.envTheta   # main.js:67-74
+    pt.drawCamera(randBase); pt.drawTracer(i, randBase)          # one sample
+    pt.tick()                                                    # main.js:838-857
+    pt.clear()                                                   # main.js:826-836
+    pt.readRadiance() -> float32 [H, W, 4], row 0 = bottom       # what draw.fs:87 reads
+
+All compute happens in the HIP kernels; a missing library or device raises
+FsptError (there is no CPU path here).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Scene:
+    """Device-resident scene (initBVH's texture uploads, main.js:408-437,548-560)."""
+
+    def __init__(self, arrays, device=0):
+        self.arrays = arrays
+        self.device = device
+        self._h = C.c_void_p()
+        desc = arrays.desc()
+        L.check(L.lib().fspt_scene_create(C.byref(desc), device, C.byref(self._h)))
+
+    @property
+    def depth(self):
+        d = C.c_uint32()
+        L.check(L.lib().fspt_scene_depth(self._h, C.byref(d)))
+        return d.value
+
+    def intersect(self, rays):
+        """intersectScene (tracer.fs:366-404) for rays float32 [n, 6] -> t, index, steps, leaves."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        t = np.zeros(n, np.float32); idx = np.zeros(n, np.int32)
+        steps = np.zeros(n, np.uint32); leaves = np.zeros(n, np.uint32)
+        L.check(L.lib().fspt_intersect(self._h, L.fptr(rays), n, L.fptr(t),
+                                       idx.ctypes.data_as(C.POINTER(C.c_int32)), L.u32ptr(steps), L.u32ptr(leaves)))
+        return t, idx, steps, leaves
+
+    def close(self):
+        if self._h:
+            L.lib().fspt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PathTracer:
+    NUM_BOUNCES = 4  # tracer.fs:9
+
+    def __init__(self, scene, width, height, device=0, num_bounces=None):
+        self.scene = scene if isinstance(scene, Scene) else Scene(scene, device)
+        self.resolution = (int(width), int(height))
+        self._t = C.c_void_p()
+        L.check(L.lib().fspt_target_create(self.scene._h, self.resolution[0], self.resolution[1], C.byref(self._t)))
+        # main.js:67-74 defaults
+        self.fovScale = 0.5
+        self.envTheta = 0.0
+        self.dir = [0.0, 0.0, -1.0]
+        self.eye = [0.0, 0.0, 2.0]
+        self.lensFeatures = [1.0 - 1.0 / 2.0, 0.02]
+        self.num_bounces = self.NUM_BOUNCES if num_bounces is None else int(num_bounces)
+        self.pingpong = 0
+        self._rng = C.c_uint64(1)
+        self._keep = None
+
+    # ---- configuration -----------------------------------------------------
+    def set_camera(self, P, I, fov_scale=0.5, env_theta=0.0, focal_depth=2.0, aperture=0.02, **_):
+        self.eye = [float(x) for x in P]
+        self.dir = [float(x) for x in I]
+        self.fovScale = float(fov_scale)
+        self.envTheta = float(env_theta)
+        self.lensFeatures = [1.0 - 1.0 / float(focal_depth), float(aperture)]
+
+    def seed(self, s):
+        """Seed of the host PRNG that replaces Math.random()*10000 (main.js:748,777)."""
+        if int(s) == 0:
+            raise ValueError("xorshift seed must be non-zero")
+        self._rng = C.c_uint64(int(s))
+
+    def next_rand_base(self):
+        return float(L.lib().fspt_rand_base_next(C.byref(self._rng)))
+
+    def set_shard(self, shard, n_shards, tile=32):
+        L.check(L.lib().fspt_target_set_shard(self._t, shard, n_shards, tile))
+
+    def bind_accumulator(self, device_ptr, keep=None):
+        """Accumulate into caller-owned device memory (e.g. a torch tensor) so a
+        collective can run on it in place; `keep` is held to keep it alive."""
+        self._keep = keep
+        L.check(L.lib().fspt_target_bind_accumulator(self._t, C.c_void_p(device_ptr)))
+
+    def enable_counters(self, on=True):
+        L.check(L.lib().fspt_enable_counters(self._t, 1 if on else 0))
+
+    # ---- the reference's draw calls ------------------------------------------
+    def drawCamera(self, randBase):
+        P = (C.c_float * 3)(*self.eye); I = (C.c_float * 3)(*self.dir); lens = (C.c_float * 2)(*self.lensFeatures)
+        L.check(L.lib().fspt_camera(self._t, P, I, self.fovScale, lens, float(randBase)))
+
+    def drawTracer(self, i, randBase):
+        L.check(L.lib().fspt_trace(self._t, int(i), float(randBase), self.envTheta, self.num_bounces))
+
+    def tick(self):
+        """One iteration of main.js:838-857 (camera draw, trace draw, pingpong++)."""
+        self.drawCamera(self.next_rand_base())
+        self.drawTracer(self.pingpong, self.next_rand_base())
+        self.pingpong += 1
+
+    def render(self, n_ticks):
+        """n_ticks fused ticks (ray generation inside the path kernel), same
+        randBase stream and results as n_ticks x tick()."""
+        cp = L.CameraParams()
+        cp.P = (C.c_float * 3)(*self.eye); cp.I = (C.c_float * 3)(*self.dir)
+        cp.fov_scale = self.fovScale; cp.lens = (C.c_float * 2)(*self.lensFeatures)
+        cp.env_theta = self.envTheta; cp.num_bounces = self.num_bounces
+        L.check(L.lib().fspt_render(self._t, C.byref(cp), self.pingpong, int(n_ticks), self._rng.value))
+        for _ in range(2 * int(n_ticks)):  # advance the host stream like the kernel did
+            self.next_rand_base()
+        self.pingpong += int(n_ticks)
+
+    def clear(self):
+        L.check(L.lib().fspt_clear(self._t))
+        self.pingpong = 0
+        L.check(L.lib().fspt_counters_reset(self._t))
+
+    def sync(self):
+        L.check(L.lib().fspt_sync(self._t))
+
+    # ---- read-back -------------------------------------------------------------
+    def setRays(self, pos, dir):
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1)
+        dir = np.ascontiguousarray(dir, dtype=np.float32).reshape(-1)
+        n = self.resolution[0] * self.resolution[1] * 4
+        if pos.size != n or dir.size != n:
+            raise ValueError("ray buffers must be W*H*4 floats")
+        L.check(L.lib().fspt_set_rays(self._t, L.fptr(pos), L.fptr(dir)))
+
+    def readRays(self):
+        W, H = self.resolution
+        pos = np.zeros((H, W, 4), np.float32); d = np.zeros((H, W, 4), np.float32)
+        L.check(L.lib().fspt_read_rays(self._t, L.fptr(pos), L.fptr(d)))
+        return pos, d
+
+    def readRadiance(self):
+        W, H = self.resolution
+        out = np.zeros((H, W, 4), np.float32)
+        L.check(L.lib().fspt_read_radiance(self._t, L.fptr(out)))
+        return out
+
+    def counters(self):
+        c = L.Counters()
+        L.check(L.lib().fspt_get_counters(self._t, C.byref(c)))
+        return c.as_dict()
+
+    def last_kernel_ms(self):
+        ms = C.c_float(); n = C.c_uint32()
+        L.check(L.lib().fspt_last_kernel_ms(self._t, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self._t:
+            L.lib().fspt_target_destroy(self._t)
+            self._t = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bytes_per_sample(counters):
+    """Algorithmic bytes per sample on the REFERENCE layout:
+    60 B per traversal step (12 B header + 2x24 B child boxes, tracer.fs:374-378),
+    144 B per leaf visit (4 x 36 B, tracer.fs:355-364), 280 B per shading event
+    (tracer.fs:447-460), 16 B per environment lookup (tracer.fs:410-419), 64 B of
+    ray + accumulator traffic per sample (tracer.fs:439,516-517)."""
+    s = max(1, counters["samples"])
+    return (60.0 * counters["steps"] + 144.0 * counters["leaves"] + 280.0 * counters["shades"]
+            + 16.0 * counters["env_lookups"]) / s + 64.0

@@ -1,0 +1,253 @@
+/*
+ * fspt.h — C ABI of libfspt, the MI355X-native replacement for the WebGL2
+ * draw-call boundary of apbodnar/FSPT's path-trace hot path.
+ *
+ * The reference has no plugin/FFI interface: its hot path (shader/tracer.fs)
+ * sits behind the WebGL2 calls issued by main.js. Every entry point below
+ * names the reference call site it replaces (file:line in /root/reference).
+ * INTEGRATION.md shows the N-API stub a maintainer of the reference would add
+ * to main.js to call these instead of gl.*.
+ *
+ * Conventions
+ *   - plain C, no C++/torch/HIP types in any signature;
+ *   - every function returns 0 on success, <0 (FSPT_E_*) on error;
+ *     fspt_last_error() returns a thread-local message (reference just
+ *     console.log()s / throws: main.js:91-94, 564-569);
+ *   - the library COPIES every host array it is given (caller may free after
+ *     the call returns);
+ *   - all calls for one target come from one host thread (the reference is a
+ *     single JS thread: main.js:838-857); work is enqueued on a HIP stream,
+ *     only fspt_read_*, fspt_sync and fspt_counters block;
+ *   - there is NO CPU fallback: without a HIP device every device entry point
+ *     fails with FSPT_E_NO_DEVICE.
+ */
+#ifndef FSPT_H
+#define FSPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSPT_ABI_VERSION 1
+
+enum {
+  FSPT_OK = 0,
+  FSPT_E_INVALID = -1,   /* bad argument / inconsistent sizes            */
+  FSPT_E_NO_DEVICE = -2, /* no HIP device or HIP runtime error at init   */
+  FSPT_E_HIP = -3,       /* HIP runtime error (message has the details)  */
+  FSPT_E_NOMEM = -4,
+  FSPT_E_PARSE = -5,     /* scene pipeline: malformed OBJ / image        */
+  FSPT_E_STATE = -6      /* call order (e.g. trace before camera)        */
+};
+
+typedef struct fspt_scene fspt_scene;
+typedef struct fspt_target fspt_target;
+typedef struct fspt_builder fspt_builder;
+
+/* ------------------------------------------------------------------------
+ * Scene upload.  Replaces the texture uploads of initBVH (main.js:408-437),
+ * initAtlas (main.js:548-560) and createEnvironmentMapImg (main.js:170-180).
+ * Arrays are exactly what the reference hands to gl.texImage2D, WITHOUT the
+ * padBuffer() padding (main.js:143-154) — pass the un-padded element counts.
+ * ---------------------------------------------------------------------- */
+typedef struct fspt_scene_desc {
+  /* bvhTex (main.js:369-370,272-282): 9 x 32-bit words per node, pre-order,
+   * [left:i32 right:i32 triStart:i32 | min.xyz | max.xyz]; the first three
+   * words are raw int bits stored in float slots (maskBVHBuffer).            */
+  const float *bvh;
+  uint32_t n_nodes;
+  /* triTex (main.js:374): 9 floats per triangle v1 v2 v3, leaf order.        */
+  const float *tri;
+  uint32_t n_tris;
+  /* matTex (main.js:377-382): 12 floats per triangle
+   * [diffuseLayer emissiveLayer normalLayer | mrLayer 0 0 | emittance.rgb |
+   *  ior dielectric 0].                                                      */
+  const float *mat;
+  /* normTex (main.js:383-385): 27 floats per triangle, per vertex n,t,bt.    */
+  const float *norm;
+  /* uvTex (main.js:386): 6 floats per triangle.                              */
+  const float *uv;
+  /* texArray (main.js:548-559): RGBA8, atlas_res^2 * atlas_layers texels,
+   * layer-major, row 0 first (GL order).                                     */
+  const uint8_t *atlas;
+  uint32_t atlas_res;
+  uint32_t atlas_layers;
+  /* envTex (main.js:170-180): RGBE in RGBA8, env_w * env_h texels, row 0
+   * first.  NULL => black environment (main.js:303-307).                     */
+  const uint8_t *env;
+  uint32_t env_w;
+  uint32_t env_h;
+  /* radianceBins uniform (tracer.fs:21, env_sampler.js:73): n_bins x
+   * (x0,y0,x1,y1).  n_bins must be >= 1 (main.js:292: [0,0,1,2048]).         */
+  const uint32_t *bins;
+  uint32_t n_bins;
+  /* '#define LEAF_SIZE' spliced into the shader (main.js:45,895).            */
+  uint32_t leaf_size;
+} fspt_scene_desc;
+
+/* device = HIP device ordinal.  Builds the MI355X-native layouts (64-byte
+ * two-child nodes, 48-byte pre-edged triangles, 160-byte shading records). */
+int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out);
+int fspt_scene_destroy(fspt_scene *scene);
+/* Maximum depth of the uploaded tree (root = 0); sizes the LDS stacks. */
+int fspt_scene_depth(const fspt_scene *scene, uint32_t *depth);
+
+/* ------------------------------------------------------------------------
+ * Render target.  Replaces initBuffers (main.js:598-617): two RGBA32F screen
+ * textures (a single accumulator here: each pixel reads/writes only itself,
+ * tracer.fs:516-517) and the two RGBA32F camera textures.
+ *
+ * Sharding: the frame is cut into tile x tile pixel tiles dealt
+ * round-robin (tile index % n_shards == shard) to the shards; a target only
+ * traces its own tiles and leaves every other pixel of its full-size
+ * accumulator at zero, so that a sum-reduce over shards yields the frame.
+ * n_shards = 1, shard = 0 traces everything.
+ * ---------------------------------------------------------------------- */
+int fspt_target_create(fspt_scene *scene, uint32_t width, uint32_t height,
+                       fspt_target **out);
+int fspt_target_destroy(fspt_target *target);
+int fspt_target_set_shard(fspt_target *target, uint32_t shard, uint32_t n_shards,
+                          uint32_t tile);
+/* Use caller-owned device memory (e.g. a torch tensor's data_ptr, W*H*4
+ * floats) as the accumulator so that a collective can run on it in place.
+ * NULL restores the internally allocated buffer. */
+int fspt_target_bind_accumulator(fspt_target *target, void *device_ptr);
+/* Device pointer of the accumulator currently in use (W*H*4 floats). */
+int fspt_target_accumulator(fspt_target *target, void **device_ptr);
+
+/* drawCamera (main.js:741-756) -> camera.fs:37-46.  Writes the pos/dir ray
+ * buffers.  lens = lensFeatures = [1 - 1/focalDepth, apertureSize].          */
+int fspt_camera(fspt_target *target, const float P[3], const float I[3],
+                float fov_scale, const float lens[2], float rand_base);
+/* Inject ray buffers instead (W*H*4 floats each, RGBA32F rows bottom-up) —
+ * used to feed the GLSL oracle's camera output to the tracer. */
+int fspt_set_rays(fspt_target *target, const float *pos, const float *dir);
+int fspt_read_rays(fspt_target *target, float *pos, float *dir);
+
+/* drawTracer(i) (main.js:758-807) -> tracer.fs:436-518.  One sample for every
+ * pixel from the current ray buffers, running-mean accumulate with weight
+ * tick.  num_bounces is tracer.fs:9's compile-time NUM_BOUNCES made a
+ * run-time argument (reference value 4).                                     */
+int fspt_trace(fspt_target *target, uint32_t tick, float rand_base,
+               float env_theta, uint32_t num_bounces);
+
+/* tick() loop (main.js:838-857): n_ticks x (drawCamera + drawTracer) starting
+ * at tick first_tick, with Math.random()*10000 (main.js:748,777) replaced by
+ * the documented xorshift64* stream seeded with seed: per tick two draws,
+ * camera first.  Ray generation is fused into the path kernel (no ray-buffer
+ * round trip); results are identical to the fspt_camera + fspt_trace pair.   */
+typedef struct fspt_camera_params {
+  float P[3];
+  float I[3];
+  float fov_scale;
+  float lens[2];
+  float env_theta;
+  uint32_t num_bounces;
+} fspt_camera_params;
+int fspt_render(fspt_target *target, const fspt_camera_params *cam,
+                uint32_t first_tick, uint32_t n_ticks, uint64_t seed);
+/* The host PRNG used by fspt_render: state' = xorshift64*(state); returns a
+ * float in [0,10000) as float(u >> 40) * 2^-24 * 10000.  Exposed so a host can
+ * reproduce the stream for the two-call (camera + trace) form. */
+float fspt_rand_base_next(uint64_t *state);
+
+/* clear() (main.js:826-836). */
+int fspt_clear(fspt_target *target);
+int fspt_sync(fspt_target *target);
+/* What draw.fs:87 reads: RGBA32F, W*H*4 floats, row 0 = bottom, a = 1.
+ * Blocking (syncs the stream first). */
+int fspt_read_radiance(fspt_target *target, float *out);
+
+/* ------------------------------------------------------------------------
+ * intersectScene (tracer.fs:366-404) as a stand-alone entry: n rays
+ * (origin xyz, dir xyz: 6 floats each) -> closest hit t and triangle index
+ * (-1 = miss, t = 1e5), optionally the loop-iteration and leaf-visit counts
+ * per ray (what bvh_test.fs:173-231 visualises).  Host pointers.
+ * ---------------------------------------------------------------------- */
+int fspt_intersect(fspt_scene *scene, const float *rays, uint32_t n, float *t_out,
+                   int32_t *index_out, uint32_t *steps_out, uint32_t *leaves_out);
+
+/* Work counters for the byte accounting of SURVEY 8d, summed over every
+ * sample traced since the last fspt_clear / fspt_counters_reset when
+ * counting is enabled (a slower kernel variant; off by default). */
+typedef struct fspt_counters {
+  uint64_t samples;     /* tracer.fs main() invocations                      */
+  uint64_t rays;        /* intersectScene calls            (tracer.fs:366)   */
+  uint64_t steps;       /* while(idx>-1) iterations        (tracer.fs:373)   */
+  uint64_t leaves;      /* processLeaf calls               (tracer.fs:380)   */
+  uint64_t shades;      /* bounce-loop iterations          (tracer.fs:446)   */
+  uint64_t env_lookups; /* envSample calls                 (tracer.fs:416)   */
+} fspt_counters;
+int fspt_enable_counters(fspt_target *target, int enable);
+int fspt_get_counters(fspt_target *target, fspt_counters *out);
+int fspt_counters_reset(fspt_target *target);
+
+/* Device-side evaluation of the deterministic math primitives (DESIGN.md
+ * "fspt-math"), for bitwise comparison against the oracle's C versions.
+ * op: see FSPT_MATH_* ; a, b: n inputs each (b may be NULL for unary ops). */
+enum {
+  FSPT_MATH_SIN = 0, FSPT_MATH_COS = 1, FSPT_MATH_ATAN2 = 2, FSPT_MATH_ASIN = 3,
+  FSPT_MATH_EXP2 = 4, FSPT_MATH_DIV = 5, FSPT_MATH_SQRT = 6, FSPT_MATH_RND = 7,
+  FSPT_MATH_FRACT = 8
+};
+int fspt_math_eval(int device, int op, const float *a, const float *b, uint32_t n,
+                   float *out);
+
+/* Timing of the most recent fspt_trace / fspt_render on this target, measured
+ * with HIP events on the target's own stream around the path-trace kernel(s):
+ * total milliseconds and number of kernel launches. Blocking. */
+int fspt_last_kernel_ms(fspt_target *target, float *ms, uint32_t *launches);
+
+/* ------------------------------------------------------------------------
+ * Scene pipeline (host side, CPU).  A native equivalent of
+ * obj_loader.js + bvh.js + the packing loops of initBVH, making the same
+ * decisions in the same float64 arithmetic, for scenes too large for the
+ * JS builder (1M triangles: 2.5 min / 4 GB in Node).
+ * ---------------------------------------------------------------------- */
+typedef struct fspt_prop_desc {
+  /* transforms of one scene-JSON prop (obj_loader.js:20-38): rotations
+   * (axis xyz, angle) applied in order, then scale, then translate.         */
+  const double *rotate; /* n_rotate x 4: axis.x axis.y axis.z angle          */
+  uint32_t n_rotate;
+  double scale;
+  double translate[3];
+  /* normals: 0 = "flat"/default, 1 = "smooth", 2 = "mesh" (obj_loader.js:144,196) */
+  uint32_t normals_mode;
+  /* resolved material (getMaterial, main.js:206-270): atlas layer ids etc.  */
+  double diffuse_layer, emissive_layer, normal_layer, mr_layer;
+  double emittance[3];
+  double ior, dielectric;
+} fspt_prop_desc;
+
+int fspt_builder_create(fspt_builder **out);
+int fspt_builder_destroy(fspt_builder *b);
+/* parseMesh (obj_loader.js:6-215) for one prop: v / vt / vn / f lines, fan
+ * triangulation, negative indices, per-prop transforms, normals, tangents. */
+int fspt_builder_add_obj(fspt_builder *b, const char *obj_text, size_t len,
+                         const fspt_prop_desc *prop);
+/* new BVH(geometry, leaf_size) + serializeTree + packing loops
+ * (bvh.js:5-91, main.js:355-392). */
+int fspt_builder_build(fspt_builder *b, uint32_t leaf_size);
+int fspt_builder_counts(const fspt_builder *b, uint32_t *n_nodes, uint32_t *n_tris,
+                        uint32_t *depth);
+/* Copies the packed reference-layout arrays (sizes from fspt_builder_counts:
+ * bvh 9*n_nodes, tri 9*n_tris, mat 12*n_tris, norm 27*n_tris, uv 6*n_tris). */
+int fspt_builder_get(const fspt_builder *b, float *bvh, float *tri, float *mat,
+                     float *norm, float *uv);
+/* ProcessEnvRadiance (env_sampler.js:1-74) on raw RGBE bytes.  Writes up to
+ * cap bins (4 uint32 each) and the real count to *n_bins. */
+int fspt_env_bins(const uint8_t *rgbe, uint32_t w, uint32_t h, uint32_t *bins,
+                  uint32_t cap, uint32_t *n_bins);
+
+const char *fspt_last_error(void);
+int fspt_abi_version(void);
+/* Number of visible HIP devices (0 when none / no driver). */
+int fspt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSPT_H */

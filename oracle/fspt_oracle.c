@@ -1,0 +1,683 @@
+/*
+ * fspt_oracle.c — TEST INFRASTRUCTURE.  CPU restatement of the reference's
+ * path-trace hot path, in plain C, on the REFERENCE's data layout.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this; the product (fspt_amd/, libfspt.so) never does.
+ *
+ * Follows, function by function (cites are /root/reference/shader/...):
+ *   camera.fs:19-46     rnd, getScreen, getAA, getDOF, main
+ *   tracer.fs:100-179   indexToCoords/create* accessors (flat arrays here)
+ *   tracer.fs:181       rnd
+ *   tracer.fs:194-298   misWeights ... evalLambert
+ *   tracer.fs:300-326   rayTriangleIntersect, rayBoxIntersect
+ *   tracer.fs:328-353   barycentric*
+ *   tracer.fs:355-404   processLeaf, intersectScene (explicit stack[64])
+ *   tracer.fs:410-434   envColor, envSample, sampleEnv
+ *   tracer.fs:436-518   main (bounce loop, running-mean accumulate)
+ * Arithmetic: oracle_math.h ("fspt-math" spec).  Texture fetches follow the
+ * GL ES 3.0 sampler state the reference sets (main.js:170-180, 548-559,
+ * 570-574): data textures NEAREST (flat arrays), atlas bilinear REPEAT,
+ * environment bilinear on the RGBE bytes with S=REPEAT, T=CLAMP_TO_EDGE.
+ *
+ * Parity status: PINNED against the reference GLSL executed on SwiftShader in
+ * the build container (tests/golden/glsl_*.npz, made by tools/make_glsl_goldens.py)
+ * — staged as SURVEY.md App. D (primary hits, first-hit shading inputs,
+ * converged means); see DESIGN.md §Parity.
+ *
+ * Documented deviations from the GLSL:
+ *   - refraction's unbounded `i--` (tracer.fs:488) is capped at
+ *     ORACLE_MAX_PATH_ITERS loop iterations;
+ *   - radianceBins index clamped to ENV_BINS-1 (tracer.fs:423-424);
+ *   - triangle fetches past the end of triTex return the padBuffer() fill
+ *     value -1 (main.js:150-152);
+ *   - asin input clamped to [-1,1].
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "oracle_math.h"
+
+#define MAX_T 100000.0f
+#define EPSILON 0.000001f
+#define M_PI_F 3.14159265f
+#define M_TAU_F (M_PI_F * 2.0f)
+#define INV_PI_F (1.0f / M_PI_F)
+#define ORACLE_MAX_PATH_ITERS 64
+
+typedef struct { float x, y, z; } vec3;
+typedef struct { float x, y; } vec2;
+
+typedef struct {
+  const float *bvh; uint32_t n_nodes;
+  const float *tri; uint32_t n_tris;
+  const float *mat; const float *norm; const float *uv;
+  const uint8_t *atlas; uint32_t atlas_res, atlas_layers;
+  const uint8_t *env; uint32_t env_w, env_h;
+  const uint32_t *bins; uint32_t n_bins;
+  uint32_t leaf_size;
+} oracle_scene;
+
+typedef struct {
+  uint64_t samples, rays, steps, leaves, shades, env_lookups;
+} oracle_counters;
+
+/* ---- vec helpers (explicit fma placement = the spec) ------------------- */
+static inline vec3 v3(float x, float y, float z) { vec3 v = {x, y, z}; return v; }
+static inline vec3 v_add(vec3 a, vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline vec3 v_sub(vec3 a, vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline vec3 v_mul(vec3 a, vec3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline vec3 v_scale(vec3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline vec3 v_neg(vec3 a) { return v3(-a.x, -a.y, -a.z); }
+/* a*s + b, fused */
+static inline vec3 v_fma(vec3 a, float s, vec3 b) {
+  return v3(om_fma(a.x, s, b.x), om_fma(a.y, s, b.y), om_fma(a.z, s, b.z));
+}
+static inline float v_dot(vec3 a, vec3 b) {
+  return om_fma(a.z, b.z, om_fma(a.y, b.y, a.x * b.x));
+}
+static inline vec3 v_cross(vec3 a, vec3 b) {
+  return v3(om_fma(a.y, b.z, -(a.z * b.y)), om_fma(a.z, b.x, -(a.x * b.z)),
+            om_fma(a.x, b.y, -(a.y * b.x)));
+}
+static inline vec3 v_normalize(vec3 a) {
+  float inv = 1.0f / sqrtf(v_dot(a, a));
+  return v_scale(a, inv);
+}
+/* w.x*a + w.y*b + w.z*c */
+static inline vec3 v_bary(vec3 w, vec3 a, vec3 b, vec3 c) {
+  return v3(om_fma(w.z, c.x, om_fma(w.y, b.x, w.x * a.x)),
+            om_fma(w.z, c.y, om_fma(w.y, b.y, w.x * a.y)),
+            om_fma(w.z, c.z, om_fma(w.y, b.z, w.x * a.z)));
+}
+static inline float f_lerp(float x, float y, float a) { return om_fma(a, y - x, x); }
+
+/* ---- rnd (tracer.fs:181, camera.fs:19) --------------------------------- */
+static inline float rnd(float *seed) {
+  *seed = *seed + 0.211324865405187f;
+  return om_fract(om_sin(*seed) * 43758.5453123f);
+}
+
+/* ---- data accessors (tracer.fs:105-179) -------------------------------- */
+static inline int32_t node_word(const oracle_scene *s, int node, int w) {
+  return (int32_t)om_f2bits(s->bvh[(size_t)node * 9 + w]);
+}
+static inline void fetch_tri(const oracle_scene *s, int index, vec3 *a, vec3 *b, vec3 *c) {
+  if (index < 0 || (uint32_t)index >= s->n_tris) { /* padBuffer fill, main.js:150-152 */
+    *a = *b = *c = v3(-1.0f, -1.0f, -1.0f);
+    return;
+  }
+  const float *p = s->tri + (size_t)index * 9;
+  *a = v3(p[0], p[1], p[2]); *b = v3(p[3], p[4], p[5]); *c = v3(p[6], p[7], p[8]);
+}
+
+/* ---- rayTriangleIntersect (tracer.fs:300-315) --------------------------- */
+static inline float ray_tri(vec3 o, vec3 d, vec3 v1, vec3 v2, vec3 v3_) {
+  vec3 e1 = v_sub(v2, v1);
+  vec3 e2 = v_sub(v3_, v1);
+  vec3 p = v_cross(d, e2);
+  float det = v_dot(e1, p);
+  if (om_abs(det) < EPSILON) return MAX_T;
+  float invDet = 1.0f / det;
+  vec3 t = v_sub(o, v1);
+  float u = v_dot(t, p) * invDet;
+  if (u < 0.0f || u > 1.0f) return MAX_T;
+  vec3 q = v_cross(t, e1);
+  float v = v_dot(d, q) * invDet;
+  if (v < 0.0f || u + v > 1.0f) return MAX_T;
+  float dist = v_dot(e2, q) * invDet;
+  return dist > EPSILON ? dist : MAX_T;
+}
+
+/* ---- rayBoxIntersect (tracer.fs:317-326) -------------------------------- */
+static inline float ray_box(const float *bmin, const float *bmax, vec3 o, vec3 inv) {
+  float t1x = (bmin[0] - o.x) * inv.x, t2x = (bmax[0] - o.x) * inv.x;
+  float t1y = (bmin[1] - o.y) * inv.y, t2y = (bmax[1] - o.y) * inv.y;
+  float t1z = (bmin[2] - o.z) * inv.z, t2z = (bmax[2] - o.z) * inv.z;
+  float tMax = om_min(om_min(om_max(t1x, t2x), om_max(t1y, t2y)), om_max(t1z, t2z));
+  float tMin = om_max(om_max(om_min(t1x, t2x), om_min(t1y, t2y)), om_min(t1z, t2z));
+  return (tMax >= tMin && tMax > 0.0f) ? tMin : MAX_T;
+}
+
+/* ---- intersectScene (tracer.fs:366-404) + processLeaf (355-364) --------- */
+typedef struct { float t; int index; } hit_t;
+
+static hit_t intersect_scene(const oracle_scene *s, vec3 o, vec3 d, oracle_counters *c,
+                             uint32_t *steps_out, uint32_t *leaves_out) {
+  hit_t result = {MAX_T, -1};
+  int stack[64];
+  int ptr = 0;
+  stack[ptr++] = -1;
+  int idx = 0;
+  uint32_t steps = 0, leaves = 0;
+  /* tracer.fs:318 recomputes 1/dir in every box test; same value hoisted */
+  vec3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  while (idx > -1) {
+    steps++;
+    int left = node_word(s, idx, 0);
+    int right = node_word(s, idx, 1);
+    int tris = node_word(s, idx, 2);
+    if (tris > -1) {
+      leaves++;
+      for (uint32_t i = 0; i < s->leaf_size; ++i) {
+        vec3 a, b, cc;
+        fetch_tri(s, tris + (int)i, &a, &b, &cc);
+        float res = ray_tri(o, d, a, b, cc);
+        if (res < result.t) { result.index = tris + (int)i; result.t = res; }
+      }
+    } else {
+      float leftHit = ray_box(s->bvh + (size_t)left * 9 + 3, s->bvh + (size_t)left * 9 + 6, o, inv);
+      float rightHit = ray_box(s->bvh + (size_t)right * 9 + 3, s->bvh + (size_t)right * 9 + 6, o, inv);
+      if (leftHit < result.t && rightHit < result.t) {
+        int deferred;
+        if (leftHit > rightHit) { idx = right; deferred = left; }
+        else { idx = left; deferred = right; }
+        if (ptr < 64) stack[ptr++] = deferred;
+        continue;
+      } else if (leftHit < result.t) { idx = left; continue; }
+      else if (rightHit < result.t) { idx = right; continue; }
+    }
+    idx = stack[--ptr];
+  }
+  if (c) { c->rays++; c->steps += steps; c->leaves += leaves; }
+  if (steps_out) *steps_out = steps;
+  if (leaves_out) *leaves_out = leaves;
+  return result;
+}
+
+/* ---- texture fetches ---------------------------------------------------- */
+static inline int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+static inline int wrap_clamp(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+static inline float safe_floor_coord(float u) {
+  float f = om_floor(u);
+  if (!(f > -1.0e9f && f < 1.0e9f)) f = 0.0f;
+  return f;
+}
+/* bilinear RGBA8, returns 4 channels in [0,1] */
+static void tex_bilinear(const uint8_t *texels, int w, int h, float s, float t,
+                         int repeat_t, float out[4]) {
+  float u = om_fma(s, (float)w, -0.5f), v = om_fma(t, (float)h, -0.5f);
+  float fu = safe_floor_coord(u), fv = safe_floor_coord(v);
+  float a = u - fu, b = v - fv;
+  if (!(a >= 0.0f && a <= 1.0f)) a = 0.0f;
+  if (!(b >= 0.0f && b <= 1.0f)) b = 0.0f;
+  int i0 = (int)fu, j0 = (int)fv;
+  int i1 = wrap_repeat(i0 + 1, w); i0 = wrap_repeat(i0, w);
+  int j1, j0w;
+  if (repeat_t) { j1 = wrap_repeat(j0 + 1, h); j0w = wrap_repeat(j0, h); }
+  else { j1 = wrap_clamp(j0 + 1, h); j0w = wrap_clamp(j0, h); }
+  const uint8_t *p00 = texels + ((size_t)j0w * w + i0) * 4;
+  const uint8_t *p10 = texels + ((size_t)j0w * w + i1) * 4;
+  const uint8_t *p01 = texels + ((size_t)j1 * w + i0) * 4;
+  const uint8_t *p11 = texels + ((size_t)j1 * w + i1) * 4;
+  for (int ch = 0; ch < 4; ++ch) {
+    float t00 = (float)p00[ch] / 255.0f, t10 = (float)p10[ch] / 255.0f;
+    float t01 = (float)p01[ch] / 255.0f, t11 = (float)p11[ch] / 255.0f;
+    out[ch] = f_lerp(f_lerp(t00, t10, a), f_lerp(t01, t11, a), b);
+  }
+}
+/* texture(texArray, vec3(uv, layer)) (tracer.fs:453-456; sampler main.js:548-555) */
+static void atlas_fetch(const oracle_scene *s, vec2 uv, float layer, float out[4]) {
+  int l = (int)om_floor(layer + 0.5f);
+  if (l < 0) l = 0;
+  if (l > (int)s->atlas_layers - 1) l = (int)s->atlas_layers - 1;
+  const uint8_t *base = s->atlas + (size_t)l * s->atlas_res * s->atlas_res * 4;
+  tex_bilinear(base, (int)s->atlas_res, (int)s->atlas_res, uv.x, uv.y, 1, out);
+}
+/* envColor (tracer.fs:410-414) */
+static vec3 env_color(const oracle_scene *s, float cx, float cy) {
+  if (!s->env) return v3(0.0f, 0.0f, 0.0f); /* black default env, main.js:303-307 */
+  float rgbe[4];
+  tex_bilinear(s->env, (int)s->env_w, (int)s->env_h, cx, cy, 0, rgbe);
+  float sc = om_exp2(om_fma(rgbe[3], 255.0f, -128.0f));
+  return v3(rgbe[0] * sc, rgbe[1] * sc, rgbe[2] * sc);
+}
+/* envSample (tracer.fs:416-419) */
+static vec3 env_sample(const oracle_scene *s, vec3 dir, float envTheta, oracle_counters *c) {
+  if (c) c->env_lookups++;
+  float cx = envTheta + om_atan2(dir.z, dir.x) / M_TAU_F;
+  float cy = om_fma(om_asin(-dir.y), INV_PI_F, 0.5f);
+  return env_color(s, cx, cy);
+}
+/* sampleEnv (tracer.fs:421-434) */
+static void sample_env(const oracle_scene *s, float envTheta, float *seed, vec3 *dir, float *pdf) {
+  float nb = (float)s->n_bins;
+  int idx = (int)(nb * rnd(seed));
+  if (idx > (int)s->n_bins - 1) idx = (int)s->n_bins - 1;
+  if (idx < 0) idx = 0;
+  const uint32_t *b = s->bins + (size_t)idx * 4;
+  float bx = (float)b[0], by = (float)b[1], bz = (float)b[2], bw = (float)b[3];
+  float dx = (float)s->env_w, dy = (float)s->env_h;
+  if (!s->env) { dx = 1.0f; dy = 2048.0f; } /* createEnvironmentMapPixels, main.js:183 */
+  float r1 = rnd(seed);
+  float r2 = rnd(seed);
+  float ux = -envTheta + om_fma(bz - bx, r1, bx) / dx;
+  float uy = 0.0f + om_fma(bw - by, r2, by) / dy;
+  float theta = ux * M_TAU_F;
+  float phi = uy * M_PI_F;
+  float sinPhi = om_sin(phi);
+  *dir = v3(om_cos(theta) * sinPhi, om_cos(phi), om_sin(theta) * sinPhi);
+  float nominal = (dx * dy) / nb;
+  *pdf = nominal / (((((bz - bx) * (bw - by)) * M_TAU_F) * M_PI_F) * sinPhi);
+}
+
+/* ---- BRDF helpers (tracer.fs:194-298) ----------------------------------- */
+static inline vec2 mis_weights(float a, float b) {
+  vec2 r;
+  if (a > EPSILON && b > EPSILON) {
+    float a2 = a * a, b2 = b * b, s = a2 + b2;
+    r.x = a2 / s; r.y = b2 / s;
+  } else { r.x = 1.0f; r.y = 0.0f; }
+  return r;
+}
+static inline float gtr2(float ndh, float a) {
+  float a2 = a * a;
+  float t = om_fma((a2 - 1.0f) * ndh, ndh, 1.0f);
+  return a2 / ((M_PI_F * t) * t);
+}
+static inline float smithG(float ndv, float alphaG) {
+  float a = alphaG * alphaG, b = ndv * ndv;
+  return 1.0f / (ndv + sqrtf(om_fma(-a, b, a + b)));
+}
+static inline float gtr2_pdf(vec3 incident, vec3 normal, float rough, vec3 bsdfDir) {
+  float alpha = om_max(0.001f, rough);
+  vec3 h = v_normalize(v_add(bsdfDir, incident));
+  float cosTheta = om_abs(v_dot(h, normal));
+  float pdf = gtr2(cosTheta, alpha) * cosTheta;
+  return pdf / (4.0f * om_abs(v_dot(bsdfDir, h)));
+}
+static inline float schlick(vec3 incident, vec3 normal, float nx, float ny) {
+  float r0 = (nx - ny) / (nx + ny);
+  r0 *= r0;
+  float cosTheta = v_dot(normal, incident);
+  if (nx > ny) {
+    float n = nx / ny;
+    float sinTheta2 = (n * n) * om_fma(-cosTheta, cosTheta, 1.0f);
+    if (sinTheta2 > 1.0f) return 1.0f;
+    cosTheta = sqrtf(1.0f - sinTheta2);
+  }
+  float x = 1.0f - cosTheta;
+  float q = ((((1.0f - r0) * x) * x) * x) * x;
+  return om_fma(q, x, r0);
+}
+static inline void local_frame(vec3 n, vec3 *tangent, vec3 *bitangent) {
+  vec3 up = (om_abs(n.z) < 0.999f) ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+  *tangent = v_normalize(v_cross(up, n));
+  *bitangent = v_cross(n, *tangent);
+}
+static inline vec3 frame_combine(vec3 t, vec3 b, vec3 n, vec3 h) {
+  return v3(om_fma(n.x, h.z, om_fma(b.x, h.y, t.x * h.x)),
+            om_fma(n.y, h.z, om_fma(b.y, h.y, t.y * h.x)),
+            om_fma(n.z, h.z, om_fma(b.z, h.y, t.z * h.x)));
+}
+static vec3 sample_microfacet(vec3 normal, float rough, float *seed) {
+  float r1 = rnd(seed), r2 = rnd(seed);
+  vec3 t, b; local_frame(normal, &t, &b);
+  float a = om_max(0.001f, rough);
+  float phi = r1 * M_TAU_F;
+  float cosTheta = sqrtf((1.0f - r2) / om_fma(om_fma(a, a, -1.0f), r2, 1.0f));
+  float sinTheta = om_clamp(sqrtf(om_fma(-cosTheta, cosTheta, 1.0f)), 0.0f, 1.0f);
+  float sinPhi = om_sin(phi), cosPhi = om_cos(phi);
+  vec3 h = v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+  return frame_combine(t, b, normal, h);
+}
+static vec3 sample_lambert(vec3 normal, float *seed) {
+  float r1 = rnd(seed), r2 = rnd(seed);
+  vec3 t, b; local_frame(normal, &t, &b);
+  float r = sqrtf(r1);
+  float phi = M_TAU_F * r2;
+  vec3 d;
+  d.x = r * om_cos(phi);
+  d.y = r * om_sin(phi);
+  d.z = sqrtf(om_max(0.0f, om_fma(-d.y, d.y, om_fma(-d.x, d.x, 1.0f))));
+  return frame_combine(t, b, normal, d);
+}
+static vec3 eval_specular(vec3 incident, vec3 normal, vec3 diffuse, float metallic, float rough,
+                          vec3 bsdfDir) {
+  float ndl = v_dot(normal, bsdfDir);
+  float ndv = v_dot(normal, incident);
+  vec3 H = v_normalize(v_add(bsdfDir, incident));
+  float ndh = v_dot(normal, H);
+  float a = om_max(0.001f, rough);
+  float Ds = gtr2(ndh, a);
+  float om = 1.0f - metallic;
+  vec3 Fs = v3(om_fma(diffuse.x, metallic, om), om_fma(diffuse.y, metallic, om),
+               om_fma(diffuse.z, metallic, om));
+  float roughg = om_fma(rough, 0.5f, 0.5f);
+  roughg = roughg * roughg;
+  float Gs = smithG(ndl, roughg) * smithG(ndv, roughg);
+  return v3((Gs * Fs.x) * Ds, (Gs * Fs.y) * Ds, (Gs * Fs.z) * Ds);
+}
+
+/* ---- barycentricWeights (tracer.fs:339-353) ----------------------------- */
+static inline vec3 bary_weights(vec3 a, vec3 b, vec3 c, vec3 p) {
+  vec3 v0 = v_sub(b, a), v1 = v_sub(c, a), v2 = v_sub(p, a);
+  float d00 = v_dot(v0, v0), d01 = v_dot(v0, v1), d11 = v_dot(v1, v1);
+  float d20 = v_dot(v2, v0), d21 = v_dot(v2, v1);
+  float invDenom = 1.0f / om_fma(d00, d11, -(d01 * d01));
+  float v = om_fma(d11, d20, -(d01 * d21)) * invDenom;
+  float w = om_fma(d00, d21, -(d01 * d20)) * invDenom;
+  float u = (1.0f - v) - w;
+  return v3(u, v, w);
+}
+
+/* Per-pixel debug record of the first shading event (parity stage D3). */
+typedef struct {
+  float t; int32_t index;
+  float origin[3]; float bary[3]; float uv[2];
+  float diffuse[3]; float emissive[3]; float mr[2]; float tex_normal[3];
+  float macro_normal[3]; float bary_normal[3];
+} oracle_first_hit;
+
+/* ---- tracer.fs main (436-518) for one pixel ----------------------------- */
+static void trace_pixel(const oracle_scene *s, vec3 ro, vec3 rd, uint32_t tick, float randBase,
+                        float envTheta, uint32_t numBounces, float *accum /*rgba*/,
+                        oracle_counters *c, oracle_first_hit *fh) {
+  float seed = 0.0f;
+  if (c) c->samples++;
+  hit_t result = intersect_scene(s, ro, rd, c, NULL, NULL);
+  vec3 color = v3(0.0f, 0.0f, 0.0f);
+  if (fh) { memset(fh, 0, sizeof(*fh)); fh->t = result.t; fh->index = result.index; }
+  if (result.index < 0) {
+    color = v_add(color, env_sample(s, rd, envTheta, c));
+  } else {
+    vec3 thr = v3(1.0f, 1.0f, 1.0f);
+    int iters = 0;
+    for (int i = 0; i < (int)numBounces && iters < ORACLE_MAX_PATH_ITERS; ++i, ++iters) {
+      if (c) c->shades++;
+      int ti = result.index;
+      const float *m = s->mat + (size_t)ti * 12;
+      float layDiffuse = m[0], laySpec = m[1], layNormal = m[2], layRough = m[3];
+      float ior = m[9], dielectric = m[10];
+      vec3 a, b, cc;
+      fetch_tri(s, ti, &a, &b, &cc);
+      const float *tuv = s->uv + (size_t)ti * 6;
+      vec3 origin = v_fma(rd, result.t, ro);
+      vec3 w = bary_weights(a, b, cc, origin);
+      vec2 tc;
+      tc.x = om_fma(w.z, tuv[4], om_fma(w.y, tuv[2], w.x * tuv[0]));
+      tc.y = om_fma(w.z, tuv[5], om_fma(w.y, tuv[3], w.x * tuv[1]));
+      float td[4], te[4], tm[4], tn[4];
+      atlas_fetch(s, tc, layDiffuse, td);
+      atlas_fetch(s, tc, laySpec, te);
+      atlas_fetch(s, tc, layRough, tm);
+      atlas_fetch(s, tc, layNormal, tn);
+      vec3 texDiffuse = v3(td[0], td[1], td[2]);
+      vec3 texEmissive = v3(te[0], te[1], te[2]);
+      float metallic = tm[0], rough = tm[1];
+      vec3 texNormal = v3((tn[0] - 0.5f) * 2.0f, (tn[1] - 0.5f) * 2.0f, (tn[2] - 0.0f) * 1.0f);
+      rough = rough * rough;
+      seed = om_fma(origin.z, 4761.52835f, ((origin.x * randBase) * origin.y) * 1.396529836f);
+      const float *nn = s->norm + (size_t)ti * 27;
+      vec3 n1 = v3(nn[0], nn[1], nn[2]), t1 = v3(nn[3], nn[4], nn[5]), b1 = v3(nn[6], nn[7], nn[8]);
+      vec3 n2 = v3(nn[9], nn[10], nn[11]), t2 = v3(nn[12], nn[13], nn[14]), b2 = v3(nn[15], nn[16], nn[17]);
+      vec3 n3 = v3(nn[18], nn[19], nn[20]), t3 = v3(nn[21], nn[22], nn[23]), b3 = v3(nn[24], nn[25], nn[26]);
+      vec3 baryNormal = v_bary(w, n1, n2, n3);
+      vec3 baryTangent = v_bary(w, t1, t2, t3);
+      vec3 baryBitangent = v_bary(w, b1, b2, b3);
+      vec3 macroNormal = v_normalize(
+          v3(om_fma(texNormal.z, baryNormal.x, om_fma(texNormal.y, baryBitangent.x, texNormal.x * baryTangent.x)),
+             om_fma(texNormal.z, baryNormal.y, om_fma(texNormal.y, baryBitangent.y, texNormal.x * baryTangent.y)),
+             om_fma(texNormal.z, baryNormal.z, om_fma(texNormal.y, baryBitangent.z, texNormal.x * baryTangent.z))));
+      if (fh && iters == 0) {
+        fh->origin[0] = origin.x; fh->origin[1] = origin.y; fh->origin[2] = origin.z;
+        fh->bary[0] = w.x; fh->bary[1] = w.y; fh->bary[2] = w.z;
+        fh->uv[0] = tc.x; fh->uv[1] = tc.y;
+        fh->diffuse[0] = td[0]; fh->diffuse[1] = td[1]; fh->diffuse[2] = td[2];
+        fh->emissive[0] = te[0]; fh->emissive[1] = te[1]; fh->emissive[2] = te[2];
+        fh->mr[0] = tm[0]; fh->mr[1] = tm[1];
+        fh->tex_normal[0] = texNormal.x; fh->tex_normal[1] = texNormal.y; fh->tex_normal[2] = texNormal.z;
+        fh->macro_normal[0] = macroNormal.x; fh->macro_normal[1] = macroNormal.y; fh->macro_normal[2] = macroNormal.z;
+        fh->bary_normal[0] = baryNormal.x; fh->bary_normal[1] = baryNormal.y; fh->bary_normal[2] = baryNormal.z;
+      }
+      int inside = v_dot(v_neg(rd), baryNormal) < 0.0f;
+      float nsx = inside ? ior : 1.0f, nsy = inside ? 1.0f : ior;
+      if (inside) macroNormal = v_neg(macroNormal);
+      vec3 off = v_scale(v_scale(macroNormal, EPSILON), 2.0f);
+      ro = v_add(origin, off);
+
+      color = v3(om_fma((thr.x * texEmissive.x) * texDiffuse.x, 30.0f, color.x),
+                 om_fma((thr.y * texEmissive.y) * texDiffuse.y, 30.0f, color.y),
+                 om_fma((thr.z * texEmissive.z) * texDiffuse.z, 30.0f, color.z));
+      vec3 incident = v_neg(rd);
+      vec3 envThroughput, bsdfThroughput;
+      float bsdfPdf;
+      vec3 microNormal = sample_microfacet(macroNormal, rough, &seed);
+      vec3 envDir; float envPdf;
+      sample_env(s, envTheta, &seed, &envDir, &envPdf);
+      float cosEnv = v_dot(macroNormal, envDir);
+      float F = schlick(incident, microNormal, nsx, nsy);
+      int specular = om_fma(1.0f, metallic, F * (1.0f - metallic)) > rnd(&seed);
+      if (specular) {
+        /* reflect(-incident, microNormal) = I - 2*dot(N,I)*N */
+        vec3 I = v_neg(incident);
+        float k = 2.0f * v_dot(microNormal, I);
+        rd = v3(om_fma(-k, microNormal.x, I.x), om_fma(-k, microNormal.y, I.y), om_fma(-k, microNormal.z, I.z));
+        bsdfPdf = gtr2_pdf(incident, macroNormal, rough, rd);
+        vec3 es = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, rd);
+        float cl = om_clamp(v_dot(macroNormal, rd), 0.0f, 1.0f);
+        bsdfThroughput = v3((es.x * cl) / bsdfPdf, (es.y * cl) / bsdfPdf, (es.z * cl) / bsdfPdf);
+        vec3 ee = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, envDir);
+        float ce = om_clamp(cosEnv, 0.0f, 1.0f);
+        envThroughput = v3((ee.x * ce) / envPdf, (ee.y * ce) / envPdf, (ee.z * ce) / envPdf);
+      } else if (dielectric >= 0.0f) {
+        bsdfPdf = 1.0f;
+        bsdfThroughput = v3(1.0f, 1.0f, 1.0f);
+        envThroughput = v3(0.0f, 0.0f, 0.0f);
+        ro = v_sub(origin, off);
+        /* refract(-incident, microNormal, ns.x/ns.y) */
+        vec3 I = v_neg(incident);
+        float eta = nsx / nsy;
+        float dNI = v_dot(microNormal, I);
+        float kk = 1.0f - (eta * eta) * (1.0f - dNI * dNI);
+        if (kk < 0.0f) rd = v3(0.0f, 0.0f, 0.0f);
+        else {
+          float sc = om_fma(eta, dNI, sqrtf(kk));
+          rd = v3(om_fma(eta, I.x, -(sc * microNormal.x)), om_fma(eta, I.y, -(sc * microNormal.y)),
+                  om_fma(eta, I.z, -(sc * microNormal.z)));
+        }
+        i--; /* tracer.fs:488 */
+      } else {
+        rd = sample_lambert(macroNormal, &seed);
+        bsdfPdf = om_abs(v_dot(rd, macroNormal)) * INV_PI_F;
+        float cl = om_clamp(v_dot(macroNormal, rd), 0.0f, 1.0f);
+        bsdfThroughput = v3(((texDiffuse.x * INV_PI_F) * cl) / bsdfPdf, ((texDiffuse.y * INV_PI_F) * cl) / bsdfPdf,
+                            ((texDiffuse.z * INV_PI_F) * cl) / bsdfPdf);
+        float ce = om_clamp(cosEnv, 0.0f, 1.0f);
+        envThroughput = v3(((texDiffuse.x * INV_PI_F) * ce) / envPdf, ((texDiffuse.y * INV_PI_F) * ce) / envPdf,
+                           ((texDiffuse.z * INV_PI_F) * ce) / envPdf);
+      }
+      if (inside) { /* tracer.fs:497 */
+        bsdfThroughput = v3(om_max(1.0f - (((1.0f - texDiffuse.x) * result.t) * dielectric), 0.0f),
+                            om_max(1.0f - (((1.0f - texDiffuse.y) * result.t) * dielectric), 0.0f),
+                            om_max(1.0f - (((1.0f - texDiffuse.z) * result.t) * dielectric), 0.0f));
+      }
+      vec2 weights = mis_weights(envPdf, bsdfPdf);
+      if (dielectric < 0.0f && cosEnv > 0.0f) {
+        hit_t shadow = intersect_scene(s, ro, envDir, c, NULL, NULL);
+        if (shadow.index == -1) {
+          vec3 es = env_sample(s, envDir, envTheta, c);
+          color = v3(om_fma((thr.x * envThroughput.x) * es.x, weights.x, color.x),
+                     om_fma((thr.y * envThroughput.y) * es.y, weights.x, color.y),
+                     om_fma((thr.z * envThroughput.z) * es.z, weights.x, color.z));
+        }
+      }
+      result = intersect_scene(s, ro, rd, c, NULL, NULL);
+      thr = v_mul(thr, bsdfThroughput);
+      if (result.index == -1) {
+        vec3 es = env_sample(s, rd, envTheta, c);
+        color = v3(om_fma(thr.x * es.x, weights.y, color.x), om_fma(thr.y * es.y, weights.y, color.y),
+                   om_fma(thr.z * es.z, weights.y, color.z));
+        break;
+      }
+    }
+  }
+  color = v3(om_clamp(color.x, 0.0f, 1024.0f), om_clamp(color.y, 0.0f, 1024.0f), om_clamp(color.z, 0.0f, 1024.0f));
+  float ft = (float)tick;
+  float den = ft + 1.0f;
+  accum[0] = om_fma(accum[0], ft, color.x) / den;
+  accum[1] = om_fma(accum[1], ft, color.y) / den;
+  accum[2] = om_fma(accum[2], ft, color.z) / den;
+  accum[3] = 1.0f;
+}
+
+/* ---- camera.fs main (37-46) for one pixel ------------------------------- */
+static void camera_pixel(uint32_t x, uint32_t y, uint32_t W, uint32_t H, const float P[3], const float I[3],
+                         float fovScale, const float lens[2], float randBase, float *pos, float *dir) {
+  float fx = (float)x + 0.5f, fy = (float)y + 0.5f; /* gl_FragCoord */
+  float resx = (float)W, resy = (float)H;
+  /* uv = interpolated clip-space corner (camera.vs:8, main.js:601-605) */
+  float uvx = om_fma(fx / resx, 2.0f, -1.0f), uvy = om_fma(fy / resy, 2.0f, -1.0f);
+  float seed = om_fma(fx, resy, randBase) + fy;
+  vec3 Iv = v3(I[0], I[1], I[2]), Pv = v3(P[0], P[1], P[2]);
+  vec3 basisX = v_normalize(v_cross(Iv, v3(0.0f, 1.0f, 0.0f)));
+  vec3 basisY = v_normalize(v_cross(basisX, Iv));
+  /* getScreen (camera.fs:21-24) */
+  float icx = uvx * (resx / resy), icy = uvy * 1.0f;
+  vec3 screen;
+  screen.x = (om_fma(icy * basisY.x, fovScale, (icx * basisX.x) * fovScale) + Iv.x) + Pv.x;
+  screen.y = (om_fma(icy * basisY.y, fovScale, (icx * basisX.y) * fovScale) + Iv.y) + Pv.y;
+  screen.z = (om_fma(icy * basisY.z, fovScale, (icx * basisX.z) * fovScale) + Iv.z) + Pv.z;
+  /* getAA (camera.fs:26-30) */
+  float theta = (rnd(&seed) * M_PI_F) * 2.0f;
+  float r = sqrtf(rnd(&seed)) * 1.414f;
+  float ct = om_cos(theta), st = om_sin(theta);
+  vec3 aa;
+  aa.x = (r * ((basisX.x * ct) / resx + (basisY.x * st) / resy)) * fovScale;
+  aa.y = (r * ((basisX.y * ct) / resx + (basisY.y * st) / resy)) * fovScale;
+  aa.z = (r * ((basisX.z * ct) / resx + (basisY.z * st) / resy)) * fovScale;
+  /* getDOF (camera.fs:32-35) */
+  float theta2 = (rnd(&seed) * M_PI_F) * 2.0f;
+  float c2 = om_cos(theta2), s2 = om_sin(theta2);
+  float sq = sqrtf(rnd(&seed));
+  vec3 dof;
+  dof.x = (om_fma(s2, basisY.x, c2 * basisX.x) * lens[1]) * sq;
+  dof.y = (om_fma(s2, basisY.y, c2 * basisX.y) * lens[1]) * sq;
+  dof.z = (om_fma(s2, basisY.z, c2 * basisX.z) * lens[1]) * sq;
+  vec3 o = v_add(Pv, dof);
+  vec3 tgt = v3(om_fma(dof.x, lens[0], screen.x + aa.x), om_fma(dof.y, lens[0], screen.y + aa.y),
+                om_fma(dof.z, lens[0], screen.z + aa.z));
+  vec3 d = v_normalize(v_sub(tgt, o));
+  pos[0] = o.x; pos[1] = o.y; pos[2] = o.z; pos[3] = 1.0f;
+  dir[0] = d.x; dir[1] = d.y; dir[2] = d.z; dir[3] = 1.0f;
+}
+
+/* ======================= exported entry points ========================== */
+
+void oracle_camera(uint32_t W, uint32_t H, const float P[3], const float I[3], float fovScale,
+                   const float lens[2], float randBase, float *pos, float *dir) {
+#pragma omp parallel for schedule(static)
+  for (int64_t y = 0; y < (int64_t)H; ++y)
+    for (uint32_t x = 0; x < W; ++x) {
+      size_t o = ((size_t)y * W + x) * 4;
+      camera_pixel(x, (uint32_t)y, W, H, P, I, fovScale, lens, randBase, pos + o, dir + o);
+    }
+}
+
+/* One tick of drawTracer (main.js:758-807): every pixel whose tile belongs to
+ * this shard (tile index % n_shards == shard; n_shards = 1 -> all). */
+void oracle_trace(const oracle_scene *s, uint32_t W, uint32_t H, const float *pos, const float *dir,
+                  uint32_t tick, float randBase, float envTheta, uint32_t numBounces, float *accum,
+                  oracle_counters *counters, oracle_first_hit *first_hits, uint32_t shard,
+                  uint32_t n_shards, uint32_t tile) {
+  oracle_counters total;
+  memset(&total, 0, sizeof(total));
+  if (n_shards == 0) n_shards = 1;
+  if (tile == 0) tile = 32;
+  uint32_t tiles_x = (W + tile - 1) / tile;
+#pragma omp parallel
+  {
+    oracle_counters local;
+    memset(&local, 0, sizeof(local));
+#pragma omp for schedule(dynamic, 4)
+    for (int64_t y = 0; y < (int64_t)H; ++y)
+      for (uint32_t x = 0; x < W; ++x) {
+        uint32_t tid = ((uint32_t)y / tile) * tiles_x + x / tile;
+        if (tid % n_shards != shard) continue;
+        size_t p = (size_t)y * W + x;
+        vec3 ro = v3(pos[p * 4], pos[p * 4 + 1], pos[p * 4 + 2]);
+        vec3 rd = v3(dir[p * 4], dir[p * 4 + 1], dir[p * 4 + 2]);
+        trace_pixel(s, ro, rd, tick, randBase, envTheta, numBounces, accum + p * 4,
+                    counters ? &local : NULL, first_hits ? first_hits + p : NULL);
+      }
+#pragma omp critical
+    {
+      total.samples += local.samples; total.rays += local.rays; total.steps += local.steps;
+      total.leaves += local.leaves; total.shades += local.shades; total.env_lookups += local.env_lookups;
+    }
+  }
+  if (counters) {
+    counters->samples += total.samples; counters->rays += total.rays; counters->steps += total.steps;
+    counters->leaves += total.leaves; counters->shades += total.shades;
+    counters->env_lookups += total.env_lookups;
+  }
+}
+
+void oracle_intersect(const oracle_scene *s, const float *rays, uint32_t n, float *t_out, int32_t *index_out,
+                      uint32_t *steps_out, uint32_t *leaves_out) {
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    vec3 o = v3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
+    vec3 d = v3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    uint32_t st, lv;
+    hit_t h = intersect_scene(s, o, d, NULL, &st, &lv);
+    t_out[i] = h.t; index_out[i] = h.index;
+    if (steps_out) steps_out[i] = st;
+    if (leaves_out) leaves_out[i] = lv;
+  }
+}
+
+/* Host PRNG replacing Math.random()*10000 (main.js:748,777): xorshift64*. */
+float oracle_rand_base_next(uint64_t *state) {
+  uint64_t x = *state;
+  x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+  *state = x;
+  uint64_t r = x * 2685821657736338717ULL;
+  return ((float)(r >> 40) * (1.0f / 16777216.0f)) * 10000.0f;
+}
+
+/* n_ticks x (drawCamera + drawTracer), the reference tick() loop (main.js:838-857). */
+void oracle_render(const oracle_scene *s, uint32_t W, uint32_t H, const float P[3], const float I[3],
+                   float fovScale, const float lens[2], float envTheta, uint32_t numBounces,
+                   uint32_t first_tick, uint32_t n_ticks, uint64_t seed, float *accum,
+                   oracle_counters *counters, uint32_t shard, uint32_t n_shards, uint32_t tile) {
+  float *pos = (float *)malloc((size_t)W * H * 4 * sizeof(float));
+  float *dir = (float *)malloc((size_t)W * H * 4 * sizeof(float));
+  uint64_t st = seed;
+  for (uint32_t k = 0; k < n_ticks; ++k) {
+    float rb_cam = oracle_rand_base_next(&st);
+    float rb_trace = oracle_rand_base_next(&st);
+    oracle_camera(W, H, P, I, fovScale, lens, rb_cam, pos, dir);
+    oracle_trace(s, W, H, pos, dir, first_tick + k, rb_trace, envTheta, numBounces, accum, counters, NULL,
+                 shard, n_shards, tile);
+  }
+  free(pos); free(dir);
+}
+
+/* math primitives for bitwise comparison with the device (fspt_math_eval) */
+void oracle_math_eval(int op, const float *a, const float *b, uint32_t n, float *out) {
+  for (uint32_t i = 0; i < n; ++i) {
+    float x = a[i], y = b ? b[i] : 0.0f;
+    switch (op) {
+      case 0: out[i] = om_sin(x); break;
+      case 1: out[i] = om_cos(x); break;
+      case 2: out[i] = om_atan2(x, y); break;
+      case 3: out[i] = om_asin(x); break;
+      case 4: out[i] = om_exp2(x); break;
+      case 5: out[i] = x / y; break;
+      case 6: out[i] = sqrtf(x); break;
+      case 7: { float sd = x; out[i] = rnd(&sd); break; }
+      case 8: out[i] = om_fract(x); break;
+      default: out[i] = 0.0f;
+    }
+  }
+}
+
+int oracle_has_fma(void) {
+#if defined(__x86_64__)
+  return __builtin_cpu_supports("fma") ? 1 : 0;
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,139 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (fspt_amd) never imports this.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_F = C.POINTER(C.c_float)
+
+
+class OScene(C.Structure):
+    _fields_ = [
+        ("bvh", _F), ("n_nodes", C.c_uint32),
+        ("tri", _F), ("n_tris", C.c_uint32),
+        ("mat", _F), ("norm", _F), ("uv", _F),
+        ("atlas", C.POINTER(C.c_uint8)), ("atlas_res", C.c_uint32), ("atlas_layers", C.c_uint32),
+        ("env", C.POINTER(C.c_uint8)), ("env_w", C.c_uint32), ("env_h", C.c_uint32),
+        ("bins", C.POINTER(C.c_uint32)), ("n_bins", C.c_uint32),
+        ("leaf_size", C.c_uint32),
+    ]
+
+
+class OCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "steps", "leaves", "shades", "env_lookups")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class OFirstHit(C.Structure):
+    _fields_ = [("t", C.c_float), ("index", C.c_int32), ("origin", C.c_float * 3), ("bary", C.c_float * 3),
+                ("uv", C.c_float * 2), ("diffuse", C.c_float * 3), ("emissive", C.c_float * 3),
+                ("mr", C.c_float * 2), ("tex_normal", C.c_float * 3), ("macro_normal", C.c_float * 3),
+                ("bary_normal", C.c_float * 3)]
+
+
+FIRST_HIT_DTYPE = np.dtype([("t", "f4"), ("index", "i4"), ("origin", "f4", 3), ("bary", "f4", 3), ("uv", "f4", 2),
+                            ("diffuse", "f4", 3), ("emissive", "f4", 3), ("mr", "f4", 2), ("tex_normal", "f4", 3),
+                            ("macro_normal", "f4", 3), ("bary_normal", "f4", 3)])
+assert FIRST_HIT_DTYPE.itemsize == C.sizeof(OFirstHit)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built: run `make -C oracle`")
+        l = C.CDLL(LIB_PATH)
+        l.oracle_rand_base_next.restype = C.c_float
+        l.oracle_rand_base_next.argtypes = [C.POINTER(C.c_uint64)]
+        l.oracle_has_fma.restype = C.c_int
+        if not l.oracle_has_fma():
+            raise RuntimeError("oracle needs a CPU with FMA (built with -mfma)")
+        _lib = l
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(_F)
+
+
+def oscene(arrays):
+    """OScene viewing a fspt_amd.scene.SceneArrays-like object (keep it alive)."""
+    s = OScene()
+    s.bvh = _fp(arrays.bvh); s.n_nodes = arrays.bvh.size // 9
+    s.tri = _fp(arrays.tri); s.n_tris = arrays.tri.size // 9
+    s.mat = _fp(arrays.mat); s.norm = _fp(arrays.norm); s.uv = _fp(arrays.uv)
+    s.atlas = arrays.atlas.ctypes.data_as(C.POINTER(C.c_uint8))
+    s.atlas_res = arrays.atlas_res; s.atlas_layers = arrays.atlas_layers
+    if arrays.env is not None:
+        s.env = arrays.env.ctypes.data_as(C.POINTER(C.c_uint8)); s.env_w = arrays.env_w; s.env_h = arrays.env_h
+    else:
+        s.env = None; s.env_w = 0; s.env_h = 0
+    s.bins = arrays.bins.ctypes.data_as(C.POINTER(C.c_uint32)); s.n_bins = arrays.bins.size // 4
+    s.leaf_size = arrays.leaf_size
+    return s
+
+
+def camera(W, H, P, I, fov_scale, lens, rand_base):
+    pos = np.zeros((H, W, 4), np.float32); d = np.zeros((H, W, 4), np.float32)
+    lib().oracle_camera(C.c_uint32(W), C.c_uint32(H), (C.c_float * 3)(*P), (C.c_float * 3)(*I), C.c_float(fov_scale),
+                        (C.c_float * 2)(*lens), C.c_float(rand_base), _fp(pos), _fp(d))
+    return pos, d
+
+
+def trace(arrays, W, H, pos, d, tick, rand_base, env_theta, num_bounces, accum, counters=None, first_hits=False,
+          shard=0, n_shards=1, tile=32):
+    s = oscene(arrays)
+    pos = np.ascontiguousarray(pos, np.float32); d = np.ascontiguousarray(d, np.float32)
+    assert accum.dtype == np.float32 and accum.flags.c_contiguous
+    fh = np.zeros(W * H, FIRST_HIT_DTYPE) if first_hits else None
+    lib().oracle_trace(C.byref(s), C.c_uint32(W), C.c_uint32(H), _fp(pos), _fp(d), C.c_uint32(tick),
+                       C.c_float(rand_base), C.c_float(env_theta), C.c_uint32(num_bounces), _fp(accum),
+                       C.byref(counters) if counters is not None else None,
+                       fh.ctypes.data_as(C.c_void_p) if fh is not None else None,
+                       C.c_uint32(shard), C.c_uint32(n_shards), C.c_uint32(tile))
+    return fh
+
+
+def render(arrays, W, H, P, I, fov_scale, lens, env_theta, num_bounces, first_tick, n_ticks, seed, accum,
+           counters=None, shard=0, n_shards=1, tile=32):
+    s = oscene(arrays)
+    assert accum.dtype == np.float32 and accum.flags.c_contiguous
+    lib().oracle_render(C.byref(s), C.c_uint32(W), C.c_uint32(H), (C.c_float * 3)(*P), (C.c_float * 3)(*I),
+                        C.c_float(fov_scale), (C.c_float * 2)(*lens), C.c_float(env_theta), C.c_uint32(num_bounces),
+                        C.c_uint32(first_tick), C.c_uint32(n_ticks), C.c_uint64(seed), _fp(accum),
+                        C.byref(counters) if counters is not None else None,
+                        C.c_uint32(shard), C.c_uint32(n_shards), C.c_uint32(tile))
+
+
+def intersect(arrays, rays):
+    s = oscene(arrays)
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    n = rays.shape[0]
+    t = np.zeros(n, np.float32); idx = np.zeros(n, np.int32)
+    steps = np.zeros(n, np.uint32); leaves = np.zeros(n, np.uint32)
+    lib().oracle_intersect(C.byref(s), _fp(rays), C.c_uint32(n), _fp(t), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                           steps.ctypes.data_as(C.POINTER(C.c_uint32)), leaves.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return t, idx, steps, leaves
+
+
+def math_eval(op, a, b=None):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.zeros_like(a)
+    bb = np.ascontiguousarray(b, np.float32) if b is not None else None
+    lib().oracle_math_eval(C.c_int(op), _fp(a), _fp(bb) if bb is not None else None, C.c_uint32(a.size), _fp(out))
+    return out
+
+
+def rand_base_stream(seed, n):
+    st = C.c_uint64(seed)
+    return [float(lib().oracle_rand_base_next(C.byref(st))) for _ in range(n)]

@@ -1,0 +1,150 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.
+Integer/index results and every float32 result must be bit-identical
+(compared with ==, i.e. up to the sign of zero)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import random_rays
+from fspt_amd import PathTracer, Scene, _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pt(arrays, W, H, cam, bounces=4):
+    pt = PathTracer(arrays, W, H, num_bounces=bounces)
+    pt.set_camera(cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["focal_depth"], cam["aperture"])
+    return pt
+
+
+@pytest.mark.parametrize("op,name", [(0, "sin"), (1, "cos"), (2, "atan2"), (3, "asin"), (4, "exp2"), (5, "div"),
+                                     (6, "sqrt"), (7, "rnd"), (8, "fract")])
+def test_math_bitwise(op, name):
+    rng = np.random.default_rng(op)
+    n = 1 << 16
+    if name in ("sin", "cos", "rnd", "fract"):
+        a = np.concatenate([rng.uniform(-10, 10, n // 4), rng.uniform(-3e4, 3e4, n // 4),
+                            rng.uniform(-3e6, 3e6, n // 4), rng.normal(size=n // 4) * 1e-3]).astype(np.float32)
+        b = None
+    elif name == "asin":
+        a = rng.uniform(-1.01, 1.01, n).astype(np.float32); b = None
+    elif name == "exp2":
+        a = rng.uniform(-140, 140, n).astype(np.float32); b = None
+    elif name == "sqrt":
+        a = np.abs(rng.normal(size=n) * 10 ** rng.uniform(-20, 20, n)).astype(np.float32); b = None
+    else:
+        a = (rng.normal(size=n) * 10 ** rng.uniform(-6, 6, n)).astype(np.float32)
+        b = (rng.normal(size=n) * 10 ** rng.uniform(-6, 6, n)).astype(np.float32)
+    out = np.zeros(n, np.float32)
+    L.check(L.lib().fspt_math_eval(0, op, L.fptr(a), L.fptr(b) if b is not None else None, n, L.fptr(out)))
+    ref = O.math_eval(op, a, b)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), name
+    if name == "sin":
+        assert np.abs(ref - np.sin(a.astype(np.float64))).max() < 3e-7
+    if name == "div":
+        assert np.array_equal(ref, a / b)
+
+
+def test_camera_bitwise(small_scene, camera):
+    W, H = 160, 96
+    pt = make_pt(small_scene, W, H, camera)
+    for rb in (0.0, 1234.567, 9999.99):
+        pt.drawCamera(rb)
+        pos, d = pt.readRays()
+        rpos, rd = O.camera(W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], rb)
+        assert np.array_equal(pos, rpos) and np.array_equal(d, rd)
+
+
+@pytest.mark.parametrize("which", ["small", "medium"])
+def test_intersect_bitwise(which, small_scene, medium_scene):
+    arrays = small_scene if which == "small" else medium_scene
+    rays = random_rays(arrays, 20000, seed=11)
+    sc = Scene(arrays)
+    t, idx, steps, leaves = sc.intersect(rays)
+    rt, ridx, rsteps, rleaves = O.intersect(arrays, rays)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+    assert np.array_equal(steps, rsteps) and np.array_equal(leaves, rleaves)
+    assert (idx >= 0).mean() > 0.2
+
+
+@pytest.mark.parametrize("bounces", [1, 4, 8])
+def test_trace_two_call_bitwise(small_scene, camera, bounces):
+    """drawCamera + drawTracer, tick by tick, against the oracle (same randBase values)."""
+    W, H = 96, 64
+    pt = make_pt(small_scene, W, H, camera, bounces)
+    pt.enable_counters(True)
+    pt.clear()
+    rbs = O.rand_base_stream(9, 6)
+    acc = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    for k in range(3):
+        pt.drawCamera(rbs[2 * k]); pt.drawTracer(k, rbs[2 * k + 1])
+        pos, d = O.camera(W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], rbs[2 * k])
+        O.trace(small_scene, W, H, pos, d, k, rbs[2 * k + 1], camera["env_theta"], bounces, acc, counters=oc)
+        got = pt.readRadiance()
+        assert np.array_equal(got, acc), f"tick {k}: {(got != acc).any(-1).sum()} pixels differ"
+    assert pt.counters() == oc.as_dict()
+
+
+def test_render_fused_bitwise(medium_scene, camera):
+    """fspt_render (ray generation fused into the path kernel) == oracle tick loop."""
+    W, H = 128, 80
+    pt = make_pt(medium_scene, W, H, camera, 8)
+    pt.seed(42)
+    pt.render(5)
+    got = pt.readRadiance()
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"],
+             8, 0, 5, 42, want)
+    assert np.array_equal(got, want)
+    # and the two-call form continues the same stream
+    pt2 = make_pt(medium_scene, W, H, camera, 8)
+    pt2.seed(42)
+    for _ in range(5):
+        pt2.tick()
+    assert np.array_equal(pt2.readRadiance(), want)
+
+
+def test_ragged_resolution_and_shards(small_scene, camera):
+    """Width/height not multiples of the tile; 3 shards sum to the full frame."""
+    W, H = 77, 45
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"],
+             4, 0, 2, 5, want)
+    total = np.zeros_like(want)
+    for s in range(3):
+        pt = make_pt(small_scene, W, H, camera, 4)
+        pt.set_shard(s, 3, 16)
+        pt.seed(5)
+        pt.render(2)
+        part = pt.readRadiance()
+        ref = np.zeros_like(want)
+        O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"],
+                 camera["env_theta"], 4, 0, 2, 5, ref, shard=s, n_shards=3, tile=16)
+        assert np.array_equal(part, ref)
+        total += part
+    assert np.array_equal(total, want)
+
+
+def test_clear_and_inject_rays(small_scene, camera):
+    W, H = 64, 40
+    pt = make_pt(small_scene, W, H, camera)
+    pos, d = O.camera(W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], 77.0)
+    pt.setRays(pos, d)
+    pt.drawTracer(0, 321.0)
+    a = pt.readRadiance()
+    pt.clear()
+    assert not pt.readRadiance().any()
+    pt.drawTracer(0, 321.0)
+    assert np.array_equal(pt.readRadiance(), a)
+    acc = np.zeros((H, W, 4), np.float32)
+    O.trace(small_scene, W, H, pos, d, 0, 321.0, camera["env_theta"], 4, acc)
+    assert np.array_equal(a, acc)
+
+
+def test_trace_before_rays_is_state_error(small_scene):
+    pt = PathTracer(small_scene, 16, 16)
+    with pytest.raises(L.FsptError) as e:
+        pt.drawTracer(0, 1.0)
+    assert e.value.code == -6
