@@ -681,3 +681,39 @@ int oracle_has_fma(void) {
   return 1;
 #endif
 }
+
+/* Probes of the deterministic BRDF / environment helpers on caller-supplied
+ * inputs (parity stage D3 against the GLSL run with the same inputs).
+ * in: n x 8 floats = (a.xyz, rough, b.xyz, metallic); out: n x 4 floats.
+ *   which 0: schlick(normalize(a), N, ns=(1,1.4)), schlick(.., ns=(1.4,1)), gtr2Pdf(normalize(a),N,rough^2-free,normalize(b)), 0
+ *   which 1: evalSpecular(normalize(a), N, D, metallic, rough, normalize(b)).rgb, smith-free 0
+ *   which 2: misWeights(a.x, a.y), lambertPdf(N, normalize(b)), 0
+ *   which 3: envSample(normalize(a)) with envTheta = rough, 0
+ * N = normalize(0.1,1,0.2), D = (0.8,0.6,0.4). */
+void oracle_brdf_probe(const oracle_scene *s, int which, const float *in, uint32_t n, float *out) {
+  vec3 N = v_normalize(v3(0.1f, 1.0f, 0.2f));
+  vec3 D = v3(0.8f, 0.6f, 0.4f);
+  for (uint32_t i = 0; i < n; ++i) {
+    const float *p = in + (size_t)i * 8;
+    vec3 a = v3(p[0], p[1], p[2]), b = v3(p[4], p[5], p[6]);
+    float rough = p[3], metallic = p[7];
+    float *o = out + (size_t)i * 4;
+    o[0] = o[1] = o[2] = o[3] = 0.0f;
+    if (which == 0) {
+      vec3 an = v_normalize(a), bn = v_normalize(b);
+      o[0] = schlick(an, N, 1.0f, 1.4f);
+      o[1] = schlick(an, N, 1.4f, 1.0f);
+      o[2] = gtr2_pdf(an, N, rough, bn);
+    } else if (which == 1) {
+      vec3 r = eval_specular(v_normalize(a), N, D, metallic, rough, v_normalize(b));
+      o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    } else if (which == 2) {
+      vec2 w = mis_weights(a.x, a.y);
+      o[0] = w.x; o[1] = w.y;
+      o[2] = om_abs(v_dot(v_normalize(b), N)) * INV_PI_F;
+    } else if (which == 3) {
+      vec3 r = env_sample(s, v_normalize(a), rough, NULL);
+      o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    }
+  }
+}

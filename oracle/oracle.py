@@ -137,3 +137,11 @@ def math_eval(op, a, b=None):
 def rand_base_stream(seed, n):
     st = C.c_uint64(seed)
     return [float(lib().oracle_rand_base_next(C.byref(st))) for _ in range(n)]
+
+
+def brdf_probe(arrays, which, inputs):
+    s = oscene(arrays)
+    inputs = np.ascontiguousarray(inputs, np.float32).reshape(-1, 8)
+    out = np.zeros((inputs.shape[0], 4), np.float32)
+    lib().oracle_brdf_probe(C.byref(s), C.c_int(which), _fp(inputs), C.c_uint32(inputs.shape[0]), _fp(out))
+    return out

@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/* from the REFERENCE run in the build container.
+
+  js_*    : the reference's own JS scene pipeline (bvh.js, obj_loader.js,
+            env_sampler.js) under Node, via tools/js_ref         -> stage D0
+  glsl_*  : the reference's own GLSL (camera.fs, tracer.fs) executed on
+            SwiftShader via tools/glsl_oracle                     -> stages D1-D5
+            
+
+Needs /root/reference, node and the kaleido SwiftShader; none of them exist on
+the GPU box, so only the committed vectors travel.  Re-run with
+    python tools/make_goldens.py [js] [glsl] [converged]
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools", "js_ref"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "glsl_oracle"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from fspt_amd import scene as S  # noqa: E402  (host-side helpers only: OBJ text, env image, packer)
+
+
+# ---------------------------------------------------------------------------
+# inputs shared by generator and tests (kept tiny so the fixtures stay small)
+# ---------------------------------------------------------------------------
+VARIANT_OBJ = """# quads, negative indices, vn, two groups
+v -1 0 -1
+v 1 0 -1
+v 1 0 1
+v -1 0 1
+v 0 1.5 0
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vn 0 1 0
+vn 0.6 0.8 0
+vn -0.6 0.8 0
+usemtl floor
+f 1/1/1 2/2/1 3/3/1 4/4/1
+usemtl roof
+f 1/1/2 2/2/2 5/3/1
+f -4/2/3 -3/3/3 -1/4/1
+f 3/1/2 4/2/3 5/3/1
+usemtl floor
+f 4/1/1 1/2/1 5/3/1
+"""
+
+
+def small_inputs():
+    props = S.bunny_props()
+    texts = {"synthetic/cube_sphere.obj": S.cube_sphere_obj(8), "synthetic/quad.obj": S.QUAD_OBJ}
+    env, w, h = S.synthetic_env(64, 32)
+    return props, texts, env, w, h
+
+
+def variant_inputs():
+    props = [
+        {"path": "variant.obj", "scale": 0.8, "rotate": [{"angle": 0.3, "axis": [0, 1, 0]}, {"angle": -0.2, "axis": [1, 0, 0]}],
+         "translate": [0.1, -0.2, 0.3], "diffuse": [0.9, 0.2, 0.1], "emittance": [0, 0, 0],
+         "metallicRoughness": [1, 0.25, 0], "normals": "mesh", "ior": 1.5, "dielectric": 0.5},
+        {"path": "variant.obj", "scale": 0.5, "rotate": [{"angle": 1.1, "axis": [0, 0, 1]}],
+         "translate": [1.5, 0.4, -0.6], "diffuse": [0.2, 0.9, 0.3], "emittance": [0, 0, 0],
+         "metallicRoughness": [0, 0.6, 0], "normals": "smooth", "emission": [0.3, 0.3, 0.1]},
+        {"path": "synthetic/quad.obj", "scale": 6, "rotate": [], "translate": [0, -1.0, 0], "emittance": [0, 0, 0],
+         "normals": "flat"},
+    ]
+    texts = {"variant.obj": VARIANT_OBJ, "synthetic/quad.obj": S.QUAD_OBJ}
+    # 60x30: midpoint splits go fractional (env_sampler.js:34-36) yet stay under SwiftShader's 261-vec4 uniform limit
+    env, w, h = S.synthetic_env(60, 30, sun_deg=8.0)
+    return props, texts, env, w, h
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_js():
+    import js_ref as J
+    for name, (props, texts, env, w, h) in (("small", small_inputs()), ("variant", variant_inputs())):
+        pk = S.TexturePacker()
+        mats = [S.get_material(p, pk) for p in props]
+        out = J.run(J.scene_job(props, texts, mats))
+        bins = J.run(J.env_job(env, w, h))["bins"]
+        np.savez_compressed(os.path.join(GOLD, f"js_scene_{name}.npz"), bvh=out["bvh"], tri=out["tri"], mat=out["mat"],
+                            norm=out["norm"], uv=out["uv"], bins=bins, depth=np.int32(out["depth"]),
+                            props=json.dumps(props), texts=json.dumps(texts), env=env, env_w=w, env_h=h)
+        print("js", name, out["bvh"].size // 9, "nodes", out["tri"].size // 9, "tris", bins.size // 4, "bins")
+    # env bins on an odd-sized image (NaN / fractional-edge quirks of env_sampler.js:25-47, 73)
+    env, w, h = S.synthetic_env(100, 37, sun_deg=6.0)
+    np.savez_compressed(os.path.join(GOLD, "js_env_bins_odd.npz"), env=env, env_w=w, env_h=h,
+                        bins=J.run(J.env_job(env, w, h))["bins"])
+    # 70k-triangle scene: digests only (arrays are ~17 MB)
+    props = S.bunny_props()
+    texts = {"synthetic/cube_sphere.obj": S.cube_sphere_obj(76), "synthetic/quad.obj": S.QUAD_OBJ}
+    pk = S.TexturePacker()
+    mats = [S.get_material(p, pk) for p in props]
+    t0 = time.time()
+    out = J.run(J.scene_job(props, texts, mats))
+    env, w, h = S.synthetic_env(2048, 1024)
+    bins = J.run(J.env_job(env, w, h))["bins"]
+    dig = {k: sha(out[k]) for k in ("bvh", "tri", "mat", "norm", "uv")}
+    dig.update(bins=sha(bins), n_bins=int(bins.size // 4), depth=int(out["depth"]), n_nodes=int(out["bvh"].size // 9),
+               n_tris=int(out["tri"].size // 9), js_seconds=round(time.time() - t0, 1), js_build_ms=out["build_ms"])
+    # Known libm-vs-V8(fdlibm) last-bit differences: Math.atan2/Math.asin of the spherical-UV
+    # fallback (obj_loader.js:64-71) feed the tangents; record where the native pipeline (glibc)
+    # differs so the test can prove "identical except these floats".
+    nat = S.build_scene(props, texts)
+    exc = {}
+    for k in ("bvh", "tri", "mat", "norm", "uv"):
+        d = np.where(getattr(nat, k).view(np.uint32) != out[k].view(np.uint32))[0]
+        if d.size:
+            ulp = np.abs(getattr(nat, k).view(np.int32)[d].astype(np.int64) - out[k].view(np.int32)[d].astype(np.int64))
+            exc[k] = {"index": d.tolist(), "js_bits": out[k].view(np.uint32)[d].tolist(), "max_ulp": int(ulp.max())}
+    dig["libm_exceptions"] = exc
+    json.dump(dig, open(os.path.join(GOLD, "js_scene_70k_digest.json"), "w"), indent=1)
+    print("js 70k", dig)
+
+
+def load_scene(name):
+    z = np.load(os.path.join(GOLD, f"js_scene_{name}.npz"))
+    props = json.loads(str(z["props"]))
+    pk = S.TexturePacker()
+    for p in props:
+        S.get_material(p, pk)
+    atlas = pk.get_pixels()
+    return S.SceneArrays(bvh=z["bvh"], tri=z["tri"], mat=z["mat"], norm=z["norm"], uv=z["uv"], atlas=atlas,
+                         atlas_res=pk.res, atlas_layers=len(pk.image_set), env=z["env"], env_w=int(z["env_w"]),
+                         env_h=int(z["env_h"]), bins=z["bins"], leaf_size=4, depth=int(z["depth"]))
+
+
+FC_REP = "(floor(gl_FragCoord.xy * 0.5) + vec2(0.5))"
+
+# One probe program for every stage (SwiftShader 4.1 crashes on the third program linked in a
+# context): the reference's own functions are called unmodified, only main() is replaced and an
+# extra `uniform int probeSel` picks what is written.
+PROBE_MAIN = """uniform int probeSel;
+void main(void) {
+  vec2 FC = FCOORD;
+  vec4 A = texelFetch(cameraPosTex, ivec2(FC), 0);
+  vec4 B = texelFetch(cameraDirTex, ivec2(FC), 0);
+  vec4 o = vec4(0.0);
+  if (probeSel >= 200) {
+    vec3 N = normalize(vec3(0.1, 1.0, 0.2));
+    vec3 D = vec3(0.8, 0.6, 0.4);
+    if (probeSel == 200) o = vec4(schlick(normalize(A.xyz), N, vec2(1.0, 1.4)), schlick(normalize(A.xyz), N, vec2(1.4, 1.0)),
+                                  gtr2Pdf(normalize(A.xyz), N, vec2(B.w, A.w), normalize(B.xyz)), 0.0);
+    if (probeSel == 201) o = vec4(evalSpecular(normalize(A.xyz), N, D, vec2(B.w, A.w), normalize(B.xyz)), 0.0);
+    if (probeSel == 202) o = vec4(misWeights(A.x, A.y), lambertPdf(N, vec2(0.0), normalize(B.xyz)), 0.0);
+    if (probeSel == 203) o = vec4(envSample(normalize(A.xyz)), 0.0);
+  } else {
+    Ray r = Ray(A.xyz, B.xyz);
+    Hit h = intersectScene(r);
+    if (probeSel == 100) {
+      o = vec4(h.t, float(h.index), 0.0, 1.0);
+    } else if (h.index < 0) {
+      o = vec4(0.0, 0.0, 0.0, -1.0);
+      if (probeSel == 0) o = vec4(envSample(r.dir), -1.0);
+    } else {
+      Material m = createMaterial(h.index);
+      vec3 P = r.origin + r.dir * h.t;
+      vec3 w = barycentricWeights(createTriangle(h.index), P);
+      vec2 tc = barycentricTexCoord(w, createTexCoords(h.index));
+      vec3 tN = (texture(texArray, vec3(tc, m.mapIndices.normal)).rgb - vec3(0.5, 0.5, 0.0)) * vec3(2.0, 2.0, 1.0);
+      vec3 bN;
+      vec3 mN = barycentricNormal(w, createNormals(h.index), tN, bN);
+      if (probeSel == 0) o = vec4(P, h.t);
+      if (probeSel == 1) o = vec4(w, float(h.index));
+      if (probeSel == 2) o = vec4(tc, texture(texArray, vec3(tc, m.mapIndices.roughness)).rg);
+      if (probeSel == 3) o = vec4(texture(texArray, vec3(tc, m.mapIndices.diffuse)).rgb, m.ior);
+      if (probeSel == 4) o = vec4(tN, m.dielectric);
+      if (probeSel == 5) o = vec4(mN, 1.0);
+      if (probeSel == 6) o = vec4(bN, 1.0);
+      if (probeSel == 7) o = vec4(texture(texArray, vec3(tc, m.mapIndices.specular)).rgb, 1.0);
+    }
+  }
+  fragColor = o;
+}
+"""
+HIT, BRDF = 100, 200
+
+
+def probe(g, sel):
+    if not getattr(g, "_probe_ready", False):
+        g.tracer(main_override=PROBE_MAIN.replace("FCOORD", FC_REP if g.rep == 2 else "gl_FragCoord.xy"))
+        g._probe_ready = True
+    g.set_int("probeSel", sel)
+    g.draw_tracer(0, 0.0, g._env_theta)
+    img, mism = g.read_screen(0)
+    assert mism == 0, f"{mism} replica mismatches"
+    return img
+
+
+def make_glsl():
+    import glsl_ref as G
+    import oracle as O
+    cam = dict(S.BUNNY_CAMERA)
+    lens = S.lens_features(cam["focal_depth"], cam["aperture"])
+    g = G.GlslRef()
+    print(g.renderer)
+    arrays = load_scene("small")
+    g.scene(arrays)
+    g._env_theta = cam["env_theta"]
+    W, H = 64, 40
+    g.target(W, H, replicate=True)
+    out = dict(W=W, H=H, renderer=g.renderer, env_theta=np.float32(cam["env_theta"]))
+    # D1: the GLSL's own camera rays (informational: depends on SwiftShader's sin())
+    g.draw_camera(cam["P"], cam["I"], cam["fov_scale"], lens, 1234.5)
+    out["cam_pos"], out["cam_dir"] = g.read_camera()
+    out["cam_rand_base"] = np.float32(1234.5)
+    # rays both sides trace from here on: aperture 0 pinhole rays without jitter dependence -> take
+    # the oracle's camera at a fixed randBase and inject them ("inject the oracle's ray textures")
+    pos, d = O.camera(W, H, cam["P"], cam["I"], cam["fov_scale"], lens, 4321.0)
+    g.set_camera(pos, d)
+    out["rays_pos"], out["rays_dir"] = pos, d
+    t0 = time.time()
+    hit = probe(g, HIT)                     # D2
+    out["hit_t"], out["hit_index"] = hit[..., 0], hit[..., 1].astype(np.int32)
+    for sel in range(8):                             # D3
+        out[f"shade{sel}"] = probe(g, sel)
+    rng = np.random.default_rng(7)
+    A = rng.normal(size=(H, W, 4)).astype(np.float32)
+    B = rng.normal(size=(H, W, 4)).astype(np.float32)
+    A[..., 1] = np.abs(A[..., 1]) + 0.05           # incident in N's hemisphere (mostly)
+    B[..., 1] = np.abs(B[..., 1]) + 0.05
+    A[..., 3] = rng.uniform(0.002, 1.0, size=(H, W))  # rough
+    B[..., 3] = rng.uniform(0.0, 1.0, size=(H, W))    # metallic
+    g.set_camera(A, B)
+    out["brdf_A"], out["brdf_B"] = A, B
+    for sel in range(3):
+        out[f"brdf{sel}"] = probe(g, BRDF + sel)
+    A2 = A.copy(); A2[..., 3] = np.float32(cam["env_theta"])  # envSample uses the envTheta uniform
+    g.set_camera(A2, B)
+    out["brdf3"] = probe(g, BRDF + 3)
+    print("probes", round(time.time() - t0, 1), "s")
+    np.savez_compressed(os.path.join(GOLD, "glsl_stages_small.npz"), **out)
+
+
+
+CONVERGED = {"small": (48, 32, 1536, 4, None, None), "variant": (48, 32, 1536, 4, [0.3, 1.2, 3.4], [-0.05, -0.3, -0.95])}
+
+
+def make_converged(name):
+    """D5: converged mean of the unmodified tracer.fs (quad-replicated), two independent
+    randBase streams (their difference is the oracle-vs-oracle noise floor).  One scene per
+    process: a fresh GL context holds exactly one tracer program."""
+    import glsl_ref as G
+    import oracle as O
+    cam = dict(S.BUNNY_CAMERA)
+    lens = S.lens_features(cam["focal_depth"], cam["aperture"])
+    Wc, Hc, spp, bounces, P, I = CONVERGED[name]
+    P = P or cam["P"]; I = I or cam["I"]
+    arrays = load_scene(name)
+    g = G.GlslRef()
+    g.scene(arrays)
+    g.target(Wc, Hc, replicate=True)
+    g.tracer(num_bounces=bounces)
+    imgs = []
+    for stream in (11, 12):
+        rbs = O.rand_base_stream(stream, 2 * spp)
+        g.clear()
+        t0 = time.time()
+        for k in range(spp):
+            g.draw_camera(P, I, cam["fov_scale"], lens, rbs[2 * k])
+            g.draw_tracer(k, rbs[2 * k + 1], cam["env_theta"])
+        img, mm = g.read_screen((spp - 1) % 2)
+        print("converged", name, "stream", stream, spp, "spp", round(time.time() - t0, 1), "s", "mismatch", mm,
+              "mean", img[..., :3].mean((0, 1)), flush=True)
+        assert mm == 0
+        imgs.append(img)
+    np.savez_compressed(os.path.join(GOLD, f"glsl_converged_{name}.npz"), a=imgs[0], b=imgs[1], W=Wc, H=Hc, spp=spp,
+                        bounces=bounces, P=np.float32(P), I=np.float32(I), fov_scale=np.float32(cam["fov_scale"]),
+                        lens=np.float32(lens), env_theta=np.float32(cam["env_theta"]), renderer=g.renderer,
+                        streams=np.int32([11, 12]))
+
+
+if __name__ == "__main__":
+    import subprocess
+    what = sys.argv[1:] or ["js", "glsl", "converged"]
+    os.makedirs(GOLD, exist_ok=True)
+    for w in what:
+        if w == "js":
+            make_js()
+        elif w == "glsl":
+            make_glsl()
+        elif w == "converged":
+            for name in CONVERGED:
+                subprocess.check_call([sys.executable, "-u", os.path.abspath(__file__), "converged:" + name])
+        elif w.startswith("converged:"):
+            make_converged(w.split(":", 1)[1])
