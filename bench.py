@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--mesh-n", type=int, default=76, help="cube-sphere resolution: 12*n^2 triangles (289 -> 1M)")
     ap.add_argument("--aperture", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--batch", type=int, default=8, help="ticks per wavefront batch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,6 +111,7 @@ def main():
     pt = fspt_amd.PathTracer(arrays, W, H, device=local_rank, num_bounces=args.bounces)
     pt.set_camera(**cam)
     pt.set_shard(rank, n_gpus, 32)
+    pt.set_pipeline(args.pipeline, args.batch)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     pt.bind_accumulator(accum.data_ptr(), keep=accum)
     pt.seed(1)
@@ -141,8 +144,10 @@ def main():
     total_samples = float(W) * H * args.steps
     value = total_samples / elapsed / 1e6
 
-    # ---- algorithmic bytes (counting variant of the same kernel, outside the timed region) ----
+    # ---- stage timing of the TIMED region (HIP events recorded on the target's stream around
+    #      every kernel launch) + algorithmic work (counting variant, outside the timed region) ----
     if rank == 0:
+        stages = pt.last_stage_ms() if args.pipeline == "wavefront" else None
         pt.enable_counters(True)
         L = fspt_amd._lib
         L.check(L.lib().fspt_counters_reset(pt._t))
@@ -150,14 +155,30 @@ def main():
         cnt = pt.counters()
         pt.enable_counters(False)
         bps = fspt_amd.bytes_per_sample(cnt)
-        samples_per_launch = cnt["samples"]
-        avg_launch_s = kernel_ms / 1e3 / max(1, launches)
-        achieved = bps * samples_per_launch / avg_launch_s / 1e9
-        per_sample = {k: round(v / max(1, cnt["samples"]), 4) for k, v in cnt.items() if k != "samples"}
+        spt = cnt["samples"]  # samples per tick on this rank
+        per_sample = {k: round(v / max(1, spt), 4) for k, v in cnt.items() if k != "samples"}
+        if stages is not None:
+            # dominant kernel: intersectScene = fspt::k_wf_trace.  Its algorithmic bytes are the S and L terms
+            # of SURVEY 8d: 60 B per traversal step + 144 B per leaf visit (reference layout).
+            tr_ms, tr_n = stages["trace"]
+            trace_bytes = (60.0 * cnt["steps"] + 144.0 * cnt["leaves"]) * args.steps
+            achieved = trace_bytes / (tr_ms / 1e3) / 1e9
+            avg_launch_ms = tr_ms / max(1, tr_n)
+            kernel = "fspt::k_wf_trace<false>"
+            extra = {"launches": tr_n, "bytes_per_launch": round(trace_bytes / max(1, tr_n)),
+                     "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stages.items()},
+                     "stage_launches": {k: v[1] for k, v in stages.items()},
+                     "pipeline_GBps": round(bps * spt * args.steps / (kernel_ms / 1e3) / 1e9, 2)}
+        else:
+            avg_launch_ms = kernel_ms / max(1, launches)
+            achieved = bps * spt / (avg_launch_ms / 1e3) / 1e9
+            kernel = "fspt::k_trace<true,false>"
+            extra = {"launches": launches}
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel": "fspt::k_trace<true,false>", "avg_launch_ms": round(avg_launch_s * 1e3, 4),
-                    "bytes_per_sample": round(bps, 1), "per_sample": per_sample}
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
+                    "avg_launch_ms": round(avg_launch_ms, 4), "bytes_per_sample": round(bps, 1),
+                    "per_sample": per_sample}
+        roofline.update(extra)
         out = {
             "metric": "Msamples/s at 1920x1080 depth 8 (bunny, 70k tri)",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -166,7 +187,7 @@ def main():
             "config": {"workload": f"bunny-synthetic {arrays.n_tris} tri, {W}x{H}, depth {args.bounces}, "
                                    f"1 spp/step, aperture {cam['aperture']}",
                        "scene_bytes": arrays.nbytes(), "bvh_nodes": arrays.n_nodes, "bvh_depth": arrays.depth,
-                       "env_bins": int(arrays.bins.size // 4), "sharding": f"32x32 tiles round-robin over {n_gpus}",
+                       "env_bins": int(arrays.bins.size // 4), "sharding": f"32x32 tiles round-robin over {n_gpus}", "pipeline": args.pipeline, "batch_ticks": args.batch,
                        "scene_build_s": round(build_s, 2)},
             "roofline": roofline,
         }

@@ -38,6 +38,7 @@ struct fspt_scene {
   fspt::DScene d{};
   void *nodes = nullptr, *tris = nullptr, *shade = nullptr, *atlas = nullptr, *env = nullptr, *bins = nullptr;
   uint32_t depth = 0, n_nodes = 0, n_tris = 0, n_interior = 0;
+  bool has_dielectric = false; // some triangle can refract (tracer.fs:481-488: unbounded path length)
 };
 
 struct fspt_target {
@@ -56,6 +57,17 @@ struct fspt_target {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   uint32_t last_launches = 0;
+  // wavefront pipeline
+  int pipeline = 1;           // 0 = megakernel, 1 = wavefront
+  uint32_t batch_ticks = 8;   // ticks traced together by the wavefront pipeline
+  void *wf_mem[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  fspt::WfCounts *wf_counts = nullptr;
+  uint32_t wf_slots = 0;      // allocated path slots
+  // per-launch stage timing (HIP events on the target's stream)
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_kind;   // kernel class of pair i
+  uint32_t ev_used = 0;       // pairs used by the last render
+  bool ev_overflow = false;
 };
 
 static int check_device(int device) {
@@ -184,6 +196,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     o[6] = v[6] - v[0]; o[7] = v[7] - v[1]; o[8] = v[8] - v[2]; // e2 = v3 - v1 (tracer.fs:302)
   }
   // ---- shading records ---------------------------------------------------------
+  bool has_dielectric = false;
   std::vector<float> shade((size_t)T * 40, 0.0f);
   for (uint32_t i = 0; i < T; ++i) {
     float *o = &shade[(size_t)i * 40];
@@ -192,6 +205,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     const float *m = desc->mat + (size_t)i * 12;
     o[33] = m[0]; o[34] = m[1]; o[35] = m[2]; o[36] = m[3]; // diffuse, emissive("specular"), normal, mr layers
     o[37] = m[9]; o[38] = m[10];                             // ior, dielectric
+    if (m[10] >= 0.0f) has_dielectric = true;
   }
 
   int rc = check_device(device);
@@ -237,6 +251,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   s->n_nodes = N;
   s->n_tris = T;
   s->n_interior = n_interior;
+  s->has_dielectric = has_dielectric;
   *out = s;
   return FSPT_OK;
 }
@@ -259,6 +274,9 @@ int fspt_scene_depth(const fspt_scene *s, uint32_t *depth) {
 // target
 // ---------------------------------------------------------------------------
 static const uint32_t WORK_RING = 4096;
+static const uint32_t WF_ROUNDS_MAX = fspt::MAX_PATH_ITERS + 4;
+static const uint32_t EV_PAIRS = 4096;
+static const uint64_t WF_SLOT_BUDGET = 32ull << 20; // path slots (about 124 B each)
 
 int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **out) {
   if (!scene || !out || W == 0 || H == 0) { fspt_set_error("fspt_target_create: bad argument"); return FSPT_E_INVALID; }
@@ -294,6 +312,9 @@ int fspt_target_destroy(fspt_target *t) {
   hipSetDevice(t->scene->device);
   if (t->stream) hipStreamSynchronize(t->stream);
   hipFree(t->accum_own); hipFree(t->ray_pos); hipFree(t->ray_dir); hipFree(t->work_counters); hipFree(t->counters);
+  for (void *m : t->wf_mem) hipFree(m);
+  hipFree(t->wf_counts);
+  for (hipEvent_t e : t->ev_pool) hipEventDestroy(e);
   if (t->ev0) hipEventDestroy(t->ev0);
   if (t->ev1) hipEventDestroy(t->ev1);
   if (t->stream) hipStreamDestroy(t->stream);
@@ -368,10 +389,131 @@ static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
   p.n_owned_tiles = (n_tiles > t->shard) ? (n_tiles - t->shard + t->n_shards - 1) / t->n_shards : 0;
 }
 
+static int wf_ensure(fspt_target *t, uint32_t slots) {
+  if (t->wf_slots >= slots && t->wf_counts) return FSPT_OK;
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  for (void *&m : t->wf_mem) { if (m) { HIP_TRY(hipFree(m)); m = nullptr; } }
+  // ray_o ray_d thr col shd pend (float4) | hit (float2) | shadow_hit (int) | q_ext[2] q_shd[2] (u32)
+  const size_t sz[12] = {16, 16, 16, 16, 16, 16, 8, 4, 4, 4, 4, 4};
+  for (int i = 0; i < 12; ++i) HIP_TRY(hipMalloc(&t->wf_mem[i], (size_t)slots * sz[i]));
+  if (!t->wf_counts) HIP_TRY(hipMalloc((void **)&t->wf_counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2)));
+  t->wf_slots = slots;
+  return FSPT_OK;
+}
+
+static int ev_begin(fspt_target *t, int kind) {
+  if (t->ev_used >= EV_PAIRS) { t->ev_overflow = true; return -1; }
+  if (t->ev_pool.size() < (size_t)(t->ev_used + 1) * 2) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { t->ev_overflow = true; return -1; }
+    t->ev_pool.push_back(a); t->ev_pool.push_back(b);
+    t->ev_kind.push_back(kind);
+  }
+  int i = (int)t->ev_used++;
+  t->ev_kind[i] = kind;
+  hipEventRecord(t->ev_pool[2 * i], t->stream);
+  return i;
+}
+static void ev_end(fspt_target *t, int i) { if (i >= 0) hipEventRecord(t->ev_pool[2 * i + 1], t->stream); }
+
+// n_ticks ticks through the wavefront pipeline.  rays_from_buffers: two-call form (n_ticks == 1).
+static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
+                            const float *rb_cam, const float *rb_trace, bool rays_from_buffers) {
+  fspt::TraceP tp{};
+  fill_trace_params(t, tp);
+  const uint32_t work_total = tp.n_owned_tiles * tp.tile * tp.tile;
+  if (work_total == 0) return FSPT_OK;
+  uint32_t batch = t->batch_ticks;
+  if (batch > (uint32_t)fspt::WF_MAX_BATCH) batch = fspt::WF_MAX_BATCH;
+  uint64_t fit = WF_SLOT_BUDGET / work_total;
+  if (fit < 1) fit = 1;
+  if (batch > fit) batch = (uint32_t)fit;
+  if (batch > n_ticks) batch = n_ticks;
+  if (batch < 1) batch = 1;
+  if ((uint64_t)batch * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
+  int rc = wf_ensure(t, batch * work_total);
+  if (rc) return rc;
+
+  fspt::WfP p{};
+  p.scene = t->scene->d;
+  p.ray_o = (float4 *)t->wf_mem[0]; p.ray_d = (float4 *)t->wf_mem[1]; p.thr = (float4 *)t->wf_mem[2];
+  p.col = (float4 *)t->wf_mem[3]; p.shd = (float4 *)t->wf_mem[4]; p.pend = (float4 *)t->wf_mem[5];
+  p.hit = (float2 *)t->wf_mem[6]; p.shadow_hit = (int *)t->wf_mem[7];
+  p.q_ext[0] = (uint32_t *)t->wf_mem[8]; p.q_ext[1] = (uint32_t *)t->wf_mem[9];
+  p.q_shd[0] = (uint32_t *)t->wf_mem[10]; p.q_shd[1] = (uint32_t *)t->wf_mem[11];
+  p.counts = t->wf_counts;
+  p.W = t->W; p.H = t->H; p.work_total = work_total;
+  p.env_theta = cam->env_theta; p.num_bounces = cam->num_bounces;
+  std::memcpy(p.cam.P, cam->P, 12); std::memcpy(p.cam.I, cam->I, 12);
+  p.cam.fov_scale = cam->fov_scale; p.cam.lens[0] = cam->lens[0]; p.cam.lens[1] = cam->lens[1];
+  p.ray_pos = t->ray_pos; p.ray_dir = t->ray_dir;
+  p.accum = t->accum;
+  p.counters = t->count ? t->counters : nullptr;
+  p.shard = tp.shard; p.n_shards = tp.n_shards; p.tile = tp.tile; p.tiles_x = tp.tiles_x; p.tiles_y = tp.tiles_y;
+  p.n_owned_tiles = tp.n_owned_tiles;
+  const int cus = t->scene->num_cus;
+  const bool gen = !rays_from_buffers;
+  const uint32_t nb = cam->num_bounces;
+
+  auto launch = [&](int kind) -> int {
+    int e = ev_begin(t, kind);
+    hipError_t err = fspt::launch_wf(kind, p, gen, t->count, cus, t->stream);
+    ev_end(t, e);
+    if (err != hipSuccess) { fspt_set_error("wavefront launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
+    return FSPT_OK;
+  };
+
+  uint32_t done = 0;
+  while (done < n_ticks) {
+    uint32_t nbt = n_ticks - done < batch ? n_ticks - done : batch;
+    p.n_batch = nbt;
+    p.first_tick = first_tick + done;
+    for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
+    HIP_TRY(hipMemsetAsync(t->wf_counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), t->stream));
+    p.round = 0;
+    if ((rc = launch(fspt::WF_K_GEN))) return rc;
+    if ((rc = launch(fspt::WF_K_TRACE))) return rc;
+    // round r: logic consumes the results of trace r-1 and shades bounce r-1; after round nb+1 every path
+    // has finished unless a refraction kept `i` from advancing (tracer.fs:488)
+    uint32_t r = 1;
+    for (; r <= nb + 1; ++r) {
+      p.round = r;
+      if ((rc = launch(fspt::WF_K_LOGIC))) return rc;
+      if (r <= nb || t->scene->has_dielectric) { if ((rc = launch(fspt::WF_K_TRACE))) return rc; }
+    }
+    if (t->scene->has_dielectric) {
+      for (; r < WF_ROUNDS_MAX; ++r) {
+        fspt::WfCounts c;
+        HIP_TRY(hipMemcpyAsync(&c, t->wf_counts + (r - 1), sizeof(c), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (c.n_ext == 0) break;
+        p.round = r;
+        if ((rc = launch(fspt::WF_K_LOGIC))) return rc;
+        if ((rc = launch(fspt::WF_K_TRACE))) return rc;
+      }
+    }
+    if ((rc = launch(fspt::WF_K_RESOLVE))) return rc;
+    done += nbt;
+  }
+  return FSPT_OK;
+}
+
 int fspt_trace(fspt_target *t, uint32_t tick, float rand_base, float env_theta, uint32_t num_bounces) {
   if (!t) { fspt_set_error("fspt_trace: NULL target"); return FSPT_E_INVALID; }
   if (!t->rays_valid) { fspt_set_error("fspt_trace: call fspt_camera or fspt_set_rays first"); return FSPT_E_STATE; }
   HIP_TRY(hipSetDevice(t->scene->device));
+  if (t->pipeline == 1) {
+    fspt_camera_params cp{};
+    cp.env_theta = env_theta; cp.num_bounces = num_bounces;
+    t->ev_used = 0; t->ev_overflow = false;
+    HIP_TRY(hipEventRecord(t->ev0, t->stream));
+    int rc = render_wavefront(t, &cp, tick, 1, nullptr, &rand_base, true);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(t->ev1, t->stream));
+    t->timed = true; t->last_launches = 1;
+    return FSPT_OK;
+  }
+  t->ev_used = 0;
   fspt::TraceP p{};
   fill_trace_params(t, p);
   p.tick = tick; p.rand_base = rand_base; p.rand_base_cam = 0.0f; p.env_theta = env_theta; p.num_bounces = num_bounces;
@@ -388,6 +530,18 @@ int fspt_render(fspt_target *t, const fspt_camera_params *cam, uint32_t first_ti
   if (!t || !cam) { fspt_set_error("fspt_render: NULL argument"); return FSPT_E_INVALID; }
   if (n_ticks == 0) return FSPT_OK;
   HIP_TRY(hipSetDevice(t->scene->device));
+  t->ev_used = 0; t->ev_overflow = false;
+  if (t->pipeline == 1) {
+    std::vector<float> rbc(n_ticks), rbt(n_ticks);
+    uint64_t st0 = seed;
+    for (uint32_t k = 0; k < n_ticks; ++k) { rbc[k] = fspt_rand_base_next(&st0); rbt[k] = fspt_rand_base_next(&st0); }
+    HIP_TRY(hipEventRecord(t->ev0, t->stream));
+    int rc = render_wavefront(t, cam, first_tick, n_ticks, rbc.data(), rbt.data(), false);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(t->ev1, t->stream));
+    t->timed = true; t->last_launches = n_ticks;
+    return FSPT_OK;
+  }
   fspt::TraceP p{};
   fill_trace_params(t, p);
   std::memcpy(p.cam.P, cam->P, 12); std::memcpy(p.cam.I, cam->I, 12);
@@ -443,6 +597,30 @@ int fspt_last_kernel_ms(fspt_target *t, float *ms, uint32_t *launches) {
   HIP_TRY(hipEventSynchronize(t->ev1));
   HIP_TRY(hipEventElapsedTime(ms, t->ev0, t->ev1));
   if (launches) *launches = t->last_launches;
+  return FSPT_OK;
+}
+
+int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks) {
+  if (!t) { fspt_set_error("fspt_target_set_pipeline: NULL target"); return FSPT_E_INVALID; }
+  if (pipeline != 0 && pipeline != 1) { fspt_set_error("pipeline must be 0 (megakernel) or 1 (wavefront)"); return FSPT_E_INVALID; }
+  if (batch_ticks > (uint32_t)fspt::WF_MAX_BATCH) { fspt_set_error("batch_ticks must be <= %d", fspt::WF_MAX_BATCH); return FSPT_E_INVALID; }
+  t->pipeline = pipeline;
+  if (batch_ticks) t->batch_ticks = batch_ticks;
+  return FSPT_OK;
+}
+
+int fspt_last_stage_ms(fspt_target *t, float ms[4], uint32_t launches[4]) {
+  if (!t || !ms || !launches) { fspt_set_error("fspt_last_stage_ms: NULL argument"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  for (int k = 0; k < 4; ++k) { ms[k] = 0.0f; launches[k] = 0; }
+  for (uint32_t i = 0; i < t->ev_used; ++i) {
+    float e = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&e, t->ev_pool[2 * i], t->ev_pool[2 * i + 1]));
+    int k = t->ev_kind[i];
+    if (k >= 0 && k < 4) { ms[k] += e; launches[k]++; }
+  }
+  if (t->ev_overflow) { fspt_set_error("stage timing: more than %u launches, timing truncated", EV_PAIRS); return FSPT_E_STATE; }
   return FSPT_OK;
 }
 

@@ -81,6 +81,58 @@ struct IntersectP {
   uint32_t *leaves_out;
 };
 
+// ---------------------------------------------------------------------------
+// Wavefront pipeline (fspt_render's default): the same per-path arithmetic cut
+// into queue-driven kernels so that every lane of a wave does the same kind of
+// work:  gen -> [ trace <-> logic ] x rounds -> resolve.
+//   slot s = j * work_total + w  : sample of tick (first_tick + j) for work
+//   index w (pixel via work_to_pixel); a batch holds n_batch ticks.
+// Path state lives in HBM as float4 SoA arrays (coalesced 16-byte accesses):
+//   ray_o  ro.xyz, -            ray_d  rd.xyz, -
+//   thr    accumulatedReflectance.xyz, weights.y
+//   col    color.xyz, flags (bits: 0-7 bounce, 8-15 iters, 16 primary, 17 hasShadow)
+//   shd    envDir.xyz, weights.x     pend  reflectance*envThroughput.xyz, -
+//   hit    (t, index) of the extension/primary ray;  shadow_hit  index of the NEE ray
+// Queues hold slot ids; WF_DEAD marks a skipped entry (ragged tile edge).
+// ---------------------------------------------------------------------------
+constexpr uint32_t WF_DEAD = 0xFFFFFFFFu;
+constexpr int WF_MAX_BATCH = 32;
+constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17;
+
+struct WfCounts { // one per round, zeroed before the batch
+  uint32_t n_ext;  // entries of q_ext for this round
+  uint32_t n_shd;  // entries of q_shd for this round
+  uint32_t head;   // trace kernel work-pool head
+  uint32_t pad;
+};
+
+struct WfP {
+  DScene scene;
+  float4 *ray_o, *ray_d, *thr, *col, *shd, *pend;
+  float2 *hit;
+  int *shadow_hit;
+  uint32_t *q_ext[2];
+  uint32_t *q_shd[2];
+  WfCounts *counts;
+  uint32_t round;
+  uint32_t W, H;
+  uint32_t work_total; // work indices per tick (owned tiles * tile^2)
+  uint32_t n_batch;    // ticks in this batch (<= WF_MAX_BATCH)
+  uint32_t first_tick;
+  float rb_cam[WF_MAX_BATCH];
+  float rb_trace[WF_MAX_BATCH];
+  float env_theta;
+  uint32_t num_bounces;
+  CameraP cam;
+  const float4 *ray_pos, *ray_dir; // ray buffers (two-call form, n_batch == 1)
+  float4 *accum;
+  unsigned long long *counters;
+  uint32_t shard, n_shards, tile, tiles_x, tiles_y, n_owned_tiles;
+};
+
+enum { WF_K_GEN = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3 };
+hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream);
+
 // launchers (fspt_kernels.hip)
 hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream);
 hipError_t launch_camera(uint32_t W, uint32_t H, const CameraP &cam, float rand_base, float4 *pos, float4 *dir,

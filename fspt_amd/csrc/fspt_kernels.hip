@@ -518,10 +518,53 @@ FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randB
   ps.primary = false;
 }
 
+// One S step of a live path (tracer.fs:500-512 + the loop bound of 446): consume the
+// shadow result hitA and the primary/extension result (tB, hitB); either shade the next
+// bounce (new rays in ps) or finish.  Returns true when the path is finished; ps.color
+// then holds the un-clamped sample colour.  Shared by the megakernel and the wavefront
+// pipeline so both run the same arithmetic in the same order.
+template <bool COUNT>
+FM_DEV bool advance_path(const DScene &S, Path &ps, int hitA, float tB, int hitB, float randBase, float envTheta,
+                         uint32_t numBounces, Counters &cnt) {
+  // NEE result (tracer.fs:500-505)
+  if (ps.hasShadow && hitA == -1) {
+    V3 es = env_sample<COUNT>(S, ps.envDir, envTheta, cnt);
+    ps.color = v3(fma_(ps.pend.x * es.x, ps.wx, ps.color.x), fma_(ps.pend.y * es.y, ps.wx, ps.color.y),
+                  fma_(ps.pend.z * es.z, ps.wx, ps.color.z));
+  }
+  ps.hasShadow = false;
+  if (hitB == -1) {
+    // tracer.fs:442-443 (primary: weight 1, reflectance 1) / 509-512
+    V3 es = env_sample<COUNT>(S, ps.rd, envTheta, cnt);
+    float wgt = ps.primary ? 1.0f : ps.wy;
+    V3 thr = ps.primary ? v3(1.0f, 1.0f, 1.0f) : ps.thr;
+    ps.color = v3(fma_(thr.x * es.x, wgt, ps.color.x), fma_(thr.y * es.y, wgt, ps.color.y),
+                  fma_(thr.z * es.z, wgt, ps.color.z));
+    return true;
+  }
+  if (ps.bounce >= (int)numBounces || ps.iters >= MAX_PATH_ITERS) return true; // tracer.fs:446 bound, live hit
+  shade_hit<COUNT>(S, ps, tB, hitB, randBase, envTheta, cnt);
+  return false;
+}
+
+// tracer.fs:515-517: clamp + running mean with weight tick
+FM_DEV float4 accumulate_sample(float4 prev, V3 color, uint32_t tick) {
+  float ft = (float)tick;
+  float den = ft + 1.0f;
+  float cr = clamp_(color.x, 0.0f, 1024.0f), cg = clamp_(color.y, 0.0f, 1024.0f), cb = clamp_(color.z, 0.0f, 1024.0f);
+  float4 o4;
+  o4.x = fma_(prev.x, ft, cr) / den;
+  o4.y = fma_(prev.y, ft, cg) / den;
+  o4.z = fma_(prev.z, ft, cb) / den;
+  o4.w = 1.0f;
+  return o4;
+}
+
 // Work index -> pixel.  The frame is cut into tile x tile pixel tiles dealt
 // round-robin to shards; inside a tile pixels are enumerated in 8x8 blocks so
 // that the 64 lanes of a wave start on a compact screen patch.
-FM_DEV bool work_to_pixel(const TraceP &p, uint32_t idx, uint32_t &x, uint32_t &y) {
+template <class P>
+FM_DEV bool work_to_pixel(const P &p, uint32_t idx, uint32_t &x, uint32_t &y) {
   uint32_t tile = p.tile;
   uint32_t per_tile = tile * tile;
   uint32_t k = idx / per_tile, local = idx - k * per_tile;
@@ -569,40 +612,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
     // ================= S phase =================
     bool need_pixel = (ps.pix < 0);
     if (ps.pix >= 0) {
-      // NEE result (tracer.fs:500-505)
-      if (ps.hasShadow && hitA == -1) {
-        V3 es = env_sample<COUNT>(S, ps.envDir, p.env_theta, cnt);
-        ps.color = v3(fma_(ps.pend.x * es.x, ps.wx, ps.color.x), fma_(ps.pend.y * es.y, ps.wx, ps.color.y),
-                      fma_(ps.pend.z * es.z, ps.wx, ps.color.z));
-      }
-      ps.hasShadow = false;
-      bool finished = false;
-      if (hitB == -1) {
-        // tracer.fs:442-443 (primary: weight 1, reflectance 1) / 509-512
-        V3 es = env_sample<COUNT>(S, ps.rd, p.env_theta, cnt);
-        float wgt = ps.primary ? 1.0f : ps.wy;
-        V3 thr = ps.primary ? v3(1.0f, 1.0f, 1.0f) : ps.thr;
-        ps.color = v3(fma_(thr.x * es.x, wgt, ps.color.x), fma_(thr.y * es.y, wgt, ps.color.y),
-                      fma_(thr.z * es.z, wgt, ps.color.z));
-        finished = true;
-      } else if (ps.bounce >= (int)p.num_bounces || ps.iters >= MAX_PATH_ITERS) {
-        finished = true; // tracer.fs:446 loop bound reached with a live hit
-      } else {
-        shade_hit<COUNT>(S, ps, tB, hitB, p.rand_base, p.env_theta, cnt);
-      }
-      if (finished) {
-        // tracer.fs:515-517
-        float4 prev = p.accum[ps.pix];
-        float ft = (float)p.tick;
-        float den = ft + 1.0f;
-        float cr = clamp_(ps.color.x, 0.0f, 1024.0f), cg = clamp_(ps.color.y, 0.0f, 1024.0f),
-              cb = clamp_(ps.color.z, 0.0f, 1024.0f);
-        float4 o4;
-        o4.x = fma_(prev.x, ft, cr) / den;
-        o4.y = fma_(prev.y, ft, cg) / den;
-        o4.z = fma_(prev.z, ft, cb) / den;
-        o4.w = 1.0f;
-        p.accum[ps.pix] = o4;
+      if (advance_path<COUNT>(S, ps, hitA, tB, hitB, p.rand_base, p.env_theta, p.num_bounces, cnt)) {
+        p.accum[ps.pix] = accumulate_sample(p.accum[ps.pix], ps.color, p.tick);
         ps.pix = -1;
         need_pixel = true;
       }
@@ -664,6 +675,307 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
       if (lane == 0) atomicAdd(p.counters + i, x);
     }
+  }
+}
+
+// ===========================================================================
+// Wavefront pipeline: gen -> [trace <-> logic] x rounds -> resolve
+// (layout and slot numbering: fspt_device.hpp)
+// ===========================================================================
+#define WF_TRACE_CHUNK 512u
+#define WF_LOGIC_THREADS 512
+
+FM_DEV uint32_t lane_rank(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// ---- gen: camera.fs main for every (tick, pixel) of the batch; queue = identity -------
+template <bool GEN_RAYS, bool COUNT>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_wf_gen(const WfP p) {
+  const uint32_t total = p.n_batch * p.work_total;
+  uint32_t nsamples = 0;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
+    uint32_t j = s / p.work_total, w = s - j * p.work_total;
+    uint32_t x, y;
+    uint32_t entry = WF_DEAD;
+    if (work_to_pixel(p, w, x, y)) {
+      V3 o, d;
+      if (GEN_RAYS) {
+        camera_ray(x, y, p.W, p.H, p.cam, p.rb_cam[j], o, d);
+      } else {
+        float4 po = p.ray_pos[y * p.W + x], di = p.ray_dir[y * p.W + x];
+        o = v3(po.x, po.y, po.z);
+        d = v3(di.x, di.y, di.z);
+      }
+      p.ray_o[s] = make_float4(o.x, o.y, o.z, 0.0f);
+      p.ray_d[s] = make_float4(d.x, d.y, d.z, 0.0f);
+      p.thr[s] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+      p.col[s] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(WF_FLAG_PRIMARY));
+      entry = s;
+      nsamples++;
+    }
+    p.q_ext[0][s] = entry;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.counts[0].n_ext = total;
+  if (COUNT) {
+    unsigned long long x = nsamples;
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && x) atomicAdd(p.counters + 0, x);
+  }
+}
+
+// ---- trace: intersectScene for a queue of rays; persistent waves, per-lane refill -------
+// Items [0, n_shd) are the NEE shadow rays of q_shd, items [n_shd, n_shd + n_ext) the
+// primary/extension rays of q_ext.  A lane whose ray is finished writes its result and
+// takes the next item from the wave's pool, so all 64 lanes keep traversing.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_wf_trace(const WfP p) {
+  extern __shared__ int lds_stack[];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const DScene &S = p.scene;
+  int *stack = lds_stack + (size_t)wave * S.stack_n * WAVE + lane;
+  const float4 *__restrict__ nodes = S.nodes;
+  const float4 *__restrict__ tris = S.tris;
+  const uint32_t leaf_size = S.leaf_size;
+  const uint32_t *__restrict__ q_ext = p.q_ext[p.round & 1];
+  const uint32_t *__restrict__ q_shd = p.q_shd[p.round & 1];
+  WfCounts *cn = p.counts + p.round;
+  const uint32_t n_shd = cn->n_shd;
+  const uint32_t total = n_shd + cn->n_ext;
+
+  // pool chunk: large while rays are plentiful (few atomics), one wave-load when they are scarce
+  // (late rounds), so that every resident wave gets work
+  const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
+  uint32_t chunk = (total / (n_waves * 4u)) & ~63u;
+  chunk = chunk < 64u ? 64u : (chunk > WF_TRACE_CHUNK ? WF_TRACE_CHUNK : chunk);
+
+  uint32_t c_rays = 0, c_steps = 0, c_leaves = 0;
+  uint32_t pool_next = 0, pool_end = 0;
+  bool exhausted = false;
+
+  bool idle = true;
+  bool is_shadow = false;
+  uint32_t slot = 0;
+  V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0);
+  float t = MAX_T;
+  int hit = -1, cur = REF_SENTINEL, sp = 0;
+
+  while (true) {
+    // ---- refill idle lanes ----
+    while (true) {
+      unsigned long long need = __ballot(idle);
+      if (need == 0ull) break;
+      uint32_t avail = pool_end - pool_next;
+      if (avail == 0u) {
+        if (exhausted) break;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&cn->head, chunk);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= total) { exhausted = true; break; }
+        pool_next = base;
+        pool_end = min(base + chunk, total);
+        continue;
+      }
+      uint32_t rank = lane_rank(need);
+      uint32_t want = (uint32_t)__popcll(need);
+      uint32_t take = want < avail ? want : avail;
+      if (idle && rank < take) {
+        uint32_t item = pool_next + rank;
+        bool sh = item < n_shd;
+        uint32_t s = sh ? q_shd[item] : q_ext[item - n_shd];
+        if (s != WF_DEAD) {
+          float4 ro = p.ray_o[s];
+          float4 rd = sh ? p.shd[s] : p.ray_d[s];
+          o = v3(ro.x, ro.y, ro.z);
+          d = v3(rd.x, rd.y, rd.z);
+          inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          t = MAX_T;
+          hit = -1;
+          cur = S.root_ref;
+          sp = 0;
+          slot = s;
+          is_shadow = sh;
+          idle = false;
+          if (COUNT) c_rays++;
+        }
+      }
+      pool_next += take;
+    }
+    if (__ballot(!idle) == 0ull) break;
+
+    // ---- interior nodes ----
+    while (cur >= 0) {
+      if (COUNT) c_steps++;
+      const float4 *n = nodes + (size_t)cur * NODE_F4;
+      float4 n0 = n[0], n1 = n[1], n2 = n[2];
+      int4 n3 = *reinterpret_cast<const int4 *>(n + 3);
+      float tl = ray_box(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv);
+      float tr = ray_box(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv);
+      bool hl = tl < t, hr = tr < t;
+      bool swap = tl > tr;
+      int nearRef = swap ? n3.y : n3.x;
+      int farRef = swap ? n3.x : n3.y;
+      if (hl && hr) {
+        stack[sp * WAVE] = farRef;
+        sp++;
+        cur = nearRef;
+      } else if (hl) {
+        cur = n3.x;
+      } else if (hr) {
+        cur = n3.y;
+      } else if (sp > 0) {
+        sp--;
+        cur = stack[sp * WAVE];
+      } else {
+        cur = REF_SENTINEL;
+      }
+    }
+    // ---- leaf ----
+    if (!idle && cur != REF_SENTINEL) {
+      if (COUNT) { c_steps++; c_leaves++; }
+      int ts = ~cur;
+      const float4 *tp = tris + (size_t)ts * TRI_F4;
+      if (leaf_size == 4) {
+        float4 a[4], b[4], c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = tp[i * 3]; b[i] = tp[i * 3 + 1]; c[i] = tp[i * 3 + 2]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float res = ray_tri(o, d, v3(a[i].x, a[i].y, a[i].z), v3(a[i].w, b[i].x, b[i].y), v3(b[i].z, b[i].w, c[i].x));
+          if (res < t) { t = res; hit = ts + i; }
+        }
+      } else {
+        for (uint32_t i = 0; i < leaf_size; ++i) {
+          float4 a = tp[i * 3], b = tp[i * 3 + 1], c = tp[i * 3 + 2];
+          float res = ray_tri(o, d, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x));
+          if (res < t) { t = res; hit = ts + (int)i; }
+        }
+      }
+      if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
+      else cur = REF_SENTINEL;
+    }
+    // ---- finished rays: write the result, lane becomes idle ----
+    if (!idle && cur == REF_SENTINEL) {
+      if (is_shadow) p.shadow_hit[slot] = hit;
+      else p.hit[slot] = make_float2(t, __int_as_float(hit));
+      idle = true;
+    }
+  }
+  if (COUNT) {
+    unsigned long long v[3] = {c_rays, c_steps, c_leaves};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      unsigned long long x = v[i];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+      if (lane == 0 && x) atomicAdd(p.counters + 1 + i, x);
+    }
+  }
+}
+
+// ---- logic: one S step for every live path of the round; compacts survivors -------------
+template <bool COUNT>
+__global__ __launch_bounds__(WF_LOGIC_THREADS) void k_wf_logic(const WfP p) {
+  __shared__ uint32_t s_cnt[2][WF_LOGIC_THREADS / WAVE];
+  __shared__ uint32_t s_base[2];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const DScene &S = p.scene;
+  const uint32_t rd_i = (p.round - 1) & 1, wr_i = p.round & 1;
+  const uint32_t *__restrict__ q_in = p.q_ext[rd_i];
+  uint32_t *__restrict__ q_out = p.q_ext[wr_i];
+  uint32_t *__restrict__ q_shd_out = p.q_shd[wr_i];
+  const uint32_t n_in = p.counts[p.round - 1].n_ext;
+  WfCounts *cn = p.counts + p.round;
+  Counters cnt = {0, 0, 0, 0, 0, 0};
+
+  for (uint32_t base = blockIdx.x * WF_LOGIC_THREADS; base < n_in; base += gridDim.x * WF_LOGIC_THREADS) {
+    uint32_t i = base + threadIdx.x;
+    uint32_t s = (i < n_in) ? q_in[i] : WF_DEAD;
+    bool survive = false, shadow = false;
+    if (s != WF_DEAD) {
+      float4 ro = p.ray_o[s], rd = p.ray_d[s], th = p.thr[s], co = p.col[s];
+      float2 h = p.hit[s];
+      uint32_t flags = __float_as_uint(co.w);
+      Path ps;
+      ps.ro = v3(ro.x, ro.y, ro.z);
+      ps.rd = v3(rd.x, rd.y, rd.z);
+      ps.thr = v3(th.x, th.y, th.z);
+      ps.wy = th.w;
+      ps.color = v3(co.x, co.y, co.z);
+      ps.bounce = (int)(flags & 255u);
+      ps.iters = (int)((flags >> 8) & 255u);
+      ps.primary = (flags & WF_FLAG_PRIMARY) != 0u;
+      ps.hasShadow = (flags & WF_FLAG_SHADOW) != 0u;
+      ps.pix = 0;
+      ps.wx = 0.0f;
+      ps.envDir = v3(0.0f, 0.0f, 0.0f);
+      ps.pend = v3(0.0f, 0.0f, 0.0f);
+      int hitA = -1;
+      if (ps.hasShadow) {
+        float4 sd = p.shd[s], pe = p.pend[s];
+        ps.envDir = v3(sd.x, sd.y, sd.z);
+        ps.wx = sd.w;
+        ps.pend = v3(pe.x, pe.y, pe.z);
+        hitA = p.shadow_hit[s];
+      }
+      uint32_t j = s / p.work_total;
+      bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), p.rb_trace[j], p.env_theta,
+                                          p.num_bounces, cnt);
+      if (finished) {
+        p.col[s] = make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f);
+      } else {
+        uint32_t nf = ((uint32_t)ps.bounce & 255u) | (((uint32_t)ps.iters & 255u) << 8) |
+                      (ps.hasShadow ? WF_FLAG_SHADOW : 0u);
+        p.ray_o[s] = make_float4(ps.ro.x, ps.ro.y, ps.ro.z, 0.0f);
+        p.ray_d[s] = make_float4(ps.rd.x, ps.rd.y, ps.rd.z, 0.0f);
+        p.thr[s] = make_float4(ps.thr.x, ps.thr.y, ps.thr.z, ps.wy);
+        p.col[s] = make_float4(ps.color.x, ps.color.y, ps.color.z, __uint_as_float(nf));
+        if (ps.hasShadow) {
+          p.shd[s] = make_float4(ps.envDir.x, ps.envDir.y, ps.envDir.z, ps.wx);
+          p.pend[s] = make_float4(ps.pend.x, ps.pend.y, ps.pend.z, 0.0f);
+        }
+        survive = true;
+        shadow = ps.hasShadow;
+      }
+    }
+    // block-aggregated append of survivors (q_ext) and their shadow rays (q_shd): 2 atomics per block
+    unsigned long long m0 = __ballot(survive), m1 = __ballot(shadow);
+    if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      uint32_t tot = 0;
+      for (int w2 = 0; w2 < WF_LOGIC_THREADS / WAVE; ++w2) { uint32_t c = s_cnt[threadIdx.x][w2]; s_cnt[threadIdx.x][w2] = tot; tot += c; }
+      s_base[threadIdx.x] = tot ? atomicAdd(threadIdx.x == 0 ? &cn->n_ext : &cn->n_shd, tot) : 0u;
+    }
+    __syncthreads();
+    if (survive) q_out[s_base[0] + s_cnt[0][wave] + lane_rank(m0)] = s;
+    if (shadow) q_shd_out[s_base[1] + s_cnt[1][wave] + lane_rank(m1)] = s;
+    __syncthreads();
+  }
+  if (COUNT) {
+    unsigned long long v[2] = {cnt.shades, cnt.envs};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned long long x = v[i];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+      if (lane == 0 && x) atomicAdd(p.counters + 4 + i, x);
+    }
+  }
+}
+
+// ---- resolve: tracer.fs:515-517 for the batch's ticks in order, per pixel --------------
+__global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < p.work_total; w += gridDim.x * blockDim.x) {
+    uint32_t x, y;
+    if (!work_to_pixel(p, w, x, y)) continue;
+    uint32_t pix = y * p.W + x;
+    float4 acc = p.accum[pix];
+    for (uint32_t j = 0; j < p.n_batch; ++j) {
+      float4 c = p.col[(size_t)j * p.work_total + w];
+      acc = accumulate_sample(acc, v3(c.x, c.y, c.z), p.first_tick + j);
+    }
+    p.accum[pix] = acc;
   }
 }
 
@@ -739,6 +1051,35 @@ hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus,
   } else {
     if (count) hipLaunchKernelGGL((k_trace<false, true>), g, b, lds, stream, p);
     else hipLaunchKernelGGL((k_trace<false, false>), g, b, lds, stream, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream) {
+  const uint32_t total = p.n_batch * p.work_total;
+  if (total == 0) return hipSuccess;
+  if (kernel == WF_K_GEN) {
+    uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 16u);
+    if (gen_rays) {
+      if (count) hipLaunchKernelGGL((k_wf_gen<true, true>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
+      else hipLaunchKernelGGL((k_wf_gen<true, false>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
+    } else {
+      if (count) hipLaunchKernelGGL((k_wf_gen<false, true>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
+      else hipLaunchKernelGGL((k_wf_gen<false, false>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
+    }
+  } else if (kernel == WF_K_TRACE) {
+    // persistent: the grid only has to fill the machine; the pool head balances the work
+    uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
+    size_t lds = stack_bytes(p.scene);
+    if (count) hipLaunchKernelGGL((k_wf_trace<true>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);
+    else hipLaunchKernelGGL((k_wf_trace<false>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);
+  } else if (kernel == WF_K_LOGIC) {
+    uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * 4u);
+    if (count) hipLaunchKernelGGL((k_wf_logic<true>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL((k_wf_logic<false>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
+  } else {
+    uint32_t grid = min((p.work_total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 16u);
+    hipLaunchKernelGGL(k_wf_resolve, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
   }
   return hipGetLastError();
 }

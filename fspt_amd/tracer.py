@@ -101,6 +101,16 @@ class PathTracer:
         self._keep = keep
         L.check(L.lib().fspt_target_bind_accumulator(self._t, C.c_void_p(device_ptr)))
 
+    def set_pipeline(self, pipeline, batch_ticks=0):
+        """'wavefront' (default) or 'megakernel'; results are bit-identical."""
+        code = {"megakernel": 0, "wavefront": 1}.get(pipeline, pipeline)
+        L.check(L.lib().fspt_target_set_pipeline(self._t, int(code), int(batch_ticks)))
+
+    def last_stage_ms(self):
+        ms = (C.c_float * 4)(); n = (C.c_uint32 * 4)()
+        L.check(L.lib().fspt_last_stage_ms(self._t, ms, n))
+        return {k: (ms[i], n[i]) for i, k in enumerate(("gen", "trace", "logic", "resolve"))}
+
     def enable_counters(self, on=True):
         L.check(L.lib().fspt_enable_counters(self._t, 1 if on else 0))
 

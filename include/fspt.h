@@ -154,6 +154,15 @@ int fspt_render(fspt_target *target, const fspt_camera_params *cam,
  * reproduce the stream for the two-call (camera + trace) form. */
 float fspt_rand_base_next(uint64_t *state);
 
+/* Execution strategy of fspt_trace / fspt_render (results are bit-identical):
+ *   pipeline 1 (default) "wavefront": gen -> [trace <-> logic] x rounds -> resolve, queue-driven
+ *              kernels over batch_ticks ticks at a time (0 keeps the current batch size, max 32);
+ *   pipeline 0 "megakernel": one persistent kernel per tick (path regeneration). */
+int fspt_target_set_pipeline(fspt_target *target, int pipeline, uint32_t batch_ticks);
+/* Per-kernel-class timing of the most recent fspt_trace / fspt_render (wavefront pipeline):
+ * summed HIP-event durations and launch counts for {gen, trace, logic, resolve}. Blocking. */
+int fspt_last_stage_ms(fspt_target *target, float ms[4], uint32_t launches[4]);
+
 /* clear() (main.js:826-836). */
 int fspt_clear(fspt_target *target);
 int fspt_sync(fspt_target *target);

@@ -11,8 +11,12 @@ from fspt_amd import PathTracer, Scene, _lib as L
 pytestmark = pytest.mark.gpu
 
 
-def make_pt(arrays, W, H, cam, bounces=4):
+PIPELINES = ["wavefront", "megakernel"]
+
+
+def make_pt(arrays, W, H, cam, bounces=4, pipeline="wavefront", batch=0):
     pt = PathTracer(arrays, W, H, num_bounces=bounces)
+    pt.set_pipeline(pipeline, batch)
     pt.set_camera(cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["focal_depth"], cam["aperture"])
     return pt
 
@@ -68,11 +72,12 @@ def test_intersect_bitwise(which, small_scene, medium_scene):
     assert (idx >= 0).mean() > 0.2
 
 
+@pytest.mark.parametrize("pipeline", PIPELINES)
 @pytest.mark.parametrize("bounces", [1, 4, 8])
-def test_trace_two_call_bitwise(small_scene, camera, bounces):
+def test_trace_two_call_bitwise(small_scene, camera, bounces, pipeline):
     """drawCamera + drawTracer, tick by tick, against the oracle (same randBase values)."""
     W, H = 96, 64
-    pt = make_pt(small_scene, W, H, camera, bounces)
+    pt = make_pt(small_scene, W, H, camera, bounces, pipeline)
     pt.enable_counters(True)
     pt.clear()
     rbs = O.rand_base_stream(9, 6)
@@ -87,10 +92,12 @@ def test_trace_two_call_bitwise(small_scene, camera, bounces):
     assert pt.counters() == oc.as_dict()
 
 
-def test_render_fused_bitwise(medium_scene, camera):
-    """fspt_render (ray generation fused into the path kernel) == oracle tick loop."""
+@pytest.mark.parametrize("pipeline,batch", [("wavefront", 0), ("wavefront", 2), ("wavefront", 32), ("megakernel", 0)])
+def test_render_fused_bitwise(medium_scene, camera, pipeline, batch):
+    """fspt_render (ray generation fused into the path kernels) == oracle tick loop, for both
+    execution strategies and for batches smaller / larger than the tick count."""
     W, H = 128, 80
-    pt = make_pt(medium_scene, W, H, camera, 8)
+    pt = make_pt(medium_scene, W, H, camera, 8, pipeline, batch)
     pt.seed(42)
     pt.render(5)
     got = pt.readRadiance()
@@ -99,14 +106,15 @@ def test_render_fused_bitwise(medium_scene, camera):
              8, 0, 5, 42, want)
     assert np.array_equal(got, want)
     # and the two-call form continues the same stream
-    pt2 = make_pt(medium_scene, W, H, camera, 8)
+    pt2 = make_pt(medium_scene, W, H, camera, 8, pipeline, batch)
     pt2.seed(42)
     for _ in range(5):
         pt2.tick()
     assert np.array_equal(pt2.readRadiance(), want)
 
 
-def test_ragged_resolution_and_shards(small_scene, camera):
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_ragged_resolution_and_shards(small_scene, camera, pipeline):
     """Width/height not multiples of the tile; 3 shards sum to the full frame."""
     W, H = 77, 45
     want = np.zeros((H, W, 4), np.float32)
@@ -114,7 +122,7 @@ def test_ragged_resolution_and_shards(small_scene, camera):
              4, 0, 2, 5, want)
     total = np.zeros_like(want)
     for s in range(3):
-        pt = make_pt(small_scene, W, H, camera, 4)
+        pt = make_pt(small_scene, W, H, camera, 4, pipeline)
         pt.set_shard(s, 3, 16)
         pt.seed(5)
         pt.render(2)
@@ -148,3 +156,35 @@ def test_trace_before_rays_is_state_error(small_scene):
     with pytest.raises(L.FsptError) as e:
         pt.drawTracer(0, 1.0)
     assert e.value.code == -6
+
+
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_refractive_scene_bitwise(pipeline):
+    """Dielectric material (tracer.fs:481-488: refraction does `i--`, so paths outlive NUM_BOUNCES
+    rounds) + mesh normals + metallic: the reference-JS-built 'variant' golden scene."""
+    from test_goldens import scene_from_golden
+    arrays = scene_from_golden("variant")
+    W, H = 96, 64
+    cam = dict(P=[0.3, 1.2, 3.4], I=[-0.05, -0.3, -0.95], fov_scale=0.5, env_theta=1.66, focal_depth=2.0, aperture=0.02)
+    cam["lens"] = [0.5, 0.02]
+    pt = make_pt(arrays, W, H, cam, 4, pipeline)
+    pt.enable_counters(True)
+    pt.clear()
+    pt.seed(3)
+    pt.render(3)
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 4, 0, 3, 3, want,
+             counters=oc)
+    assert np.array_equal(pt.readRadiance(), want)
+    assert pt.counters() == oc.as_dict()
+    if pipeline == "wavefront":  # refraction really extended paths beyond NUM_BOUNCES + 1 rounds
+        assert pt.last_stage_ms()["logic"][1] > 4 + 1
+
+
+def test_stage_timing(small_scene, camera):
+    pt = make_pt(small_scene, 64, 48, camera, 4, "wavefront", 2)
+    pt.render(4)
+    st = pt.last_stage_ms()
+    assert st["gen"][1] == 2 and st["resolve"][1] == 2 and st["trace"][1] == 2 * 5 and st["logic"][1] == 2 * 5
+    assert all(v[0] > 0 for v in st.values())

@@ -67,7 +67,7 @@ def variant_inputs():
     props = [
         {"path": "variant.obj", "scale": 0.8, "rotate": [{"angle": 0.3, "axis": [0, 1, 0]}, {"angle": -0.2, "axis": [1, 0, 0]}],
          "translate": [0.1, -0.2, 0.3], "diffuse": [0.9, 0.2, 0.1], "emittance": [0, 0, 0],
-         "metallicRoughness": [1, 0.25, 0], "normals": "mesh", "ior": 1.5, "dielectric": 0.5},
+         "metallicRoughness": [0, 0.25, 0], "normals": "mesh", "ior": 1.5, "dielectric": 0.5},
         {"path": "variant.obj", "scale": 0.5, "rotate": [{"angle": 1.1, "axis": [0, 0, 1]}],
          "translate": [1.5, 0.4, -0.6], "diffuse": [0.2, 0.9, 0.3], "emittance": [0, 0, 0],
          "metallicRoughness": [0, 0.6, 0], "normals": "smooth", "emission": [0.3, 0.3, 0.1]},
