@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--aperture", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel"])
-    ap.add_argument("--batch", type=int, default=8, help="ticks per wavefront batch")
+    ap.add_argument("--batch", type=int, default=32, help="ticks per wavefront batch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfspt.so")
+LIB_PATH = os.environ.get("FSPT_LIB") or os.path.join(_HERE, "libfspt.so")  # FSPT_LIB: A/B builds of the same ABI
 
 
 class FsptError(RuntimeError):

@@ -59,7 +59,7 @@ struct fspt_target {
   uint32_t last_launches = 0;
   // wavefront pipeline
   int pipeline = 1;           // 0 = megakernel, 1 = wavefront
-  uint32_t batch_ticks = 8;   // ticks traced together by the wavefront pipeline
+  uint32_t batch_ticks = 32;  // ticks traced together by the wavefront pipeline
   void *wf_mem[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   fspt::WfCounts *wf_counts = nullptr;
   uint32_t wf_slots = 0;      // allocated path slots
@@ -276,7 +276,7 @@ int fspt_scene_depth(const fspt_scene *s, uint32_t *depth) {
 static const uint32_t WORK_RING = 4096;
 static const uint32_t WF_ROUNDS_MAX = fspt::MAX_PATH_ITERS + 4;
 static const uint32_t EV_PAIRS = 4096;
-static const uint64_t WF_SLOT_BUDGET = 32ull << 20; // path slots (about 124 B each)
+static const uint64_t WF_SLOT_BUDGET = 160ull << 20; // path slots, 124 B each (20 GB of the 288 GB HBM)
 
 int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **out) {
   if (!scene || !out || W == 0 || H == 0) { fspt_set_error("fspt_target_create: bad argument"); return FSPT_E_INVALID; }
@@ -428,10 +428,13 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
   uint64_t fit = WF_SLOT_BUDGET / work_total;
   if (fit < 1) fit = 1;
   if (batch > fit) batch = (uint32_t)fit;
-  if (batch > n_ticks) batch = n_ticks;
   if (batch < 1) batch = 1;
   if ((uint64_t)batch * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
-  int rc = wf_ensure(t, batch * work_total);
+  // path-state buffers are sized for the configured batch once (not for this call's tick count), so a
+  // short first call does not cause a reallocation later; small one-off renders only pay for what they use
+  uint32_t alloc_batch = (n_ticks >= batch || t->wf_slots) ? batch : n_ticks;
+  if (batch > n_ticks) batch = n_ticks;
+  int rc = wf_ensure(t, alloc_batch * work_total);
   if (rc) return rc;
 
   fspt::WfP p{};

@@ -85,8 +85,11 @@ struct IntersectP {
 // Wavefront pipeline (fspt_render's default): the same per-path arithmetic cut
 // into queue-driven kernels so that every lane of a wave does the same kind of
 // work:  gen -> [ trace <-> logic ] x rounds -> resolve.
-//   slot s = j * work_total + w  : sample of tick (first_tick + j) for work
-//   index w (pixel via work_to_pixel); a batch holds n_batch ticks.
+//   slot s = w * n_batch + j  : sample of tick (first_tick + j) for work index w
+//   (pixel via work_to_pixel); a batch holds n_batch ticks.  Pixel-major on purpose:
+//   the ticks of one pixel are neighbours in every queue, so a wave's primary rays are
+//   near-identical (coherent traversal, broadcast node loads) and neighbouring paths
+//   shade the same triangle/material.
 // Path state lives in HBM as float4 SoA arrays (coalesced 16-byte accesses):
 //   ray_o  ro.xyz, -            ray_d  rd.xyz, -
 //   thr    accumulatedReflectance.xyz, weights.y
@@ -96,13 +99,14 @@ struct IntersectP {
 // Queues hold slot ids; WF_DEAD marks a skipped entry (ragged tile edge).
 // ---------------------------------------------------------------------------
 constexpr uint32_t WF_DEAD = 0xFFFFFFFFu;
-constexpr int WF_MAX_BATCH = 32;
+constexpr int WF_MAX_BATCH = 64;
 constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17;
 
 struct WfCounts { // one per round, zeroed before the batch
   uint32_t n_ext;  // entries of q_ext for this round
   uint32_t n_shd;  // entries of q_shd for this round
-  uint32_t head;   // trace kernel work-pool head
+  uint32_t head;   // trace kernel work-pool head (one head: XCD-segmented pools measured 50 % slower,
+                   // static segments unbalance the XCDs and the L2 hit rate did not move - profiles/r01)
   uint32_t pad;
 };
 

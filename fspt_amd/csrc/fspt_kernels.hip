@@ -695,7 +695,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_gen(const WfP p) {
   const uint32_t total = p.n_batch * p.work_total;
   uint32_t nsamples = 0;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
-    uint32_t j = s / p.work_total, w = s - j * p.work_total;
+    uint32_t w = s / p.n_batch, j = s - w * p.n_batch; // pixel-major: the batch's ticks of a pixel are adjacent
     uint32_t x, y;
     uint32_t entry = WF_DEAD;
     if (work_to_pixel(p, w, x, y)) {
@@ -728,8 +728,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_gen(const WfP p) {
 // Items [0, n_shd) are the NEE shadow rays of q_shd, items [n_shd, n_shd + n_ext) the
 // primary/extension rays of q_ext.  A lane whose ray is finished writes its result and
 // takes the next item from the wave's pool, so all 64 lanes keep traversing.
+// 6 waves/SIMD minimum -> <= 80 VGPRs: measured best of {5, 7, 8(spills)} waves/SIMD (profiles/r01)
+#ifndef WF_TRACE_WAVES
+#define WF_TRACE_WAVES 6
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_wf_trace(const WfP p) {
+__global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(const WfP p) {
   extern __shared__ int lds_stack[];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
@@ -874,8 +878,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_trace(const WfP p) {
 }
 
 // ---- logic: one S step for every live path of the round; compacts survivors -------------
+// 4 waves/SIMD (<= 128 VGPRs, 2 spilled): measured best of {3, 4, 5(39 spills)} (profiles/r01)
+#ifndef WF_LOGIC_WAVES
+#define WF_LOGIC_WAVES 4
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(WF_LOGIC_THREADS) void k_wf_logic(const WfP p) {
+__global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(const WfP p) {
   __shared__ uint32_t s_cnt[2][WF_LOGIC_THREADS / WAVE];
   __shared__ uint32_t s_base[2];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -919,7 +927,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS) void k_wf_logic(const WfP p) {
         ps.pend = v3(pe.x, pe.y, pe.z);
         hitA = p.shadow_hit[s];
       }
-      uint32_t j = s / p.work_total;
+      uint32_t j = s % p.n_batch;
       bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), p.rb_trace[j], p.env_theta,
                                           p.num_bounces, cnt);
       if (finished) {
@@ -972,7 +980,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
     uint32_t pix = y * p.W + x;
     float4 acc = p.accum[pix];
     for (uint32_t j = 0; j < p.n_batch; ++j) {
-      float4 c = p.col[(size_t)j * p.work_total + w];
+      float4 c = p.col[(size_t)w * p.n_batch + j];
       acc = accumulate_sample(acc, v3(c.x, c.y, c.z), p.first_tick + j);
     }
     p.accum[pix] = acc;

@@ -156,7 +156,7 @@ float fspt_rand_base_next(uint64_t *state);
 
 /* Execution strategy of fspt_trace / fspt_render (results are bit-identical):
  *   pipeline 1 (default) "wavefront": gen -> [trace <-> logic] x rounds -> resolve, queue-driven
- *              kernels over batch_ticks ticks at a time (0 keeps the current batch size, max 32);
+ *              kernels over batch_ticks ticks at a time (0 keeps the current batch size, max 64);
  *   pipeline 0 "megakernel": one persistent kernel per tick (path regeneration). */
 int fspt_target_set_pipeline(fspt_target *target, int pipeline, uint32_t batch_ticks);
 /* Per-kernel-class timing of the most recent fspt_trace / fspt_render (wavefront pipeline):

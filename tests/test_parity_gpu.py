@@ -92,7 +92,7 @@ def test_trace_two_call_bitwise(small_scene, camera, bounces, pipeline):
     assert pt.counters() == oc.as_dict()
 
 
-@pytest.mark.parametrize("pipeline,batch", [("wavefront", 0), ("wavefront", 2), ("wavefront", 32), ("megakernel", 0)])
+@pytest.mark.parametrize("pipeline,batch", [("wavefront", 0), ("wavefront", 2), ("wavefront", 64), ("megakernel", 0)])
 def test_render_fused_bitwise(medium_scene, camera, pipeline, batch):
     """fspt_render (ray generation fused into the path kernels) == oracle tick loop, for both
     execution strategies and for batches smaller / larger than the tick count."""

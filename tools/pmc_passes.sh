@@ -19,15 +19,18 @@ for set in \
   timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > $O/p$i.log 2>&1
 done
 python3 - "$O" <<'PY'
-import csv,glob,sys,collections
+import csv,glob,sys,collections,re
 O=sys.argv[1]
 agg=collections.OrderedDict()
 for f in sorted(glob.glob(O+'/p*/*/*_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        if 'k_trace' in r['Kernel_Name'] and 'true, false' in r['Kernel_Name'] or ('k_trace' in r['Kernel_Name'] and 'false>' in r['Kernel_Name']):
-            agg.setdefault(r['Counter_Name'],[]).append(float(r['Counter_Value']))
+        m=re.search(r'(k_wf_\w+|k_trace|k_camera)(<[^>]*>)?', r['Kernel_Name'])
+        if not m: continue
+        k=m.group(0)
+        if 'true>' in k and 'k_wf' in k and ', false' not in k and k.endswith('<true>'): continue  # counting variants
+        agg.setdefault((k,r['Counter_Name']),[]).append(float(r['Counter_Value']))
 with open(O+'/summary.txt','w') as out:
-    for k,v in agg.items():
-        out.write(f"{k:40s} n={len(v):3d} mean_per_launch={sum(v)/len(v):.6g}\n")
+    for (k,c),v in agg.items():
+        out.write(f"{k:28s} {c:36s} launches={len(v):4d} sum={sum(v):.6g} mean={sum(v)/len(v):.6g}\n")
 print(open(O+'/summary.txt').read())
 PY
