@@ -26,13 +26,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def frame_for(n_gpus, w, h):
-    fac = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}.get(n_gpus)
-    if fac is None:
-        fac = (n_gpus, 1)
-    return w * fac[0], h * fac[1]
-
-
 def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=15.0):
     """The oracle (kind 'port': plain-C restatement, OpenMP over rows) timed on
     this host's cores on a bounded, uniformly tile-sampled part of the SAME
@@ -94,15 +87,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libfspt has no CPU path)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if n_gpus > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from fspt_amd import distributed as D
+    dist = D.init_process_group(backend="nccl", device=torch.device("cuda", local_rank)) if n_gpus > 1 else None
 
     t0 = time.perf_counter()
     arrays = S.bunny_scene(n=args.mesh_n)
     build_s = time.perf_counter() - t0
-    W, H = frame_for(n_gpus, args.width, args.height)
+    W, H = D.weak_frame(n_gpus, args.width, args.height)
     cam = dict(S.BUNNY_CAMERA)
     if args.aperture is not None:
         cam["aperture"] = args.aperture
@@ -110,7 +101,7 @@ def main():
 
     pt = fspt_amd.PathTracer(arrays, W, H, device=local_rank, num_bounces=args.bounces)
     pt.set_camera(**cam)
-    pt.set_shard(rank, n_gpus, 32)
+    pt.set_shard(rank, n_gpus, D.TILE)
     pt.set_pipeline(args.pipeline, args.batch)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     pt.bind_accumulator(accum.data_ptr(), keep=accum)
@@ -131,8 +122,7 @@ def main():
     t_start = time.perf_counter()
     pt.render(args.steps)
     pt.sync()
-    if dist is not None:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    D.reduce_radiance(accum, dst=0)  # the one exchange step (RCCL sum-reduce to rank 0)
     barrier()
     elapsed = time.perf_counter() - t_start
     kernel_ms, launches = pt.last_kernel_ms()

@@ -395,7 +395,10 @@ static int wf_ensure(fspt_target *t, uint32_t slots) {
   for (void *&m : t->wf_mem) { if (m) { HIP_TRY(hipFree(m)); m = nullptr; } }
   // ray_o ray_d thr col shd pend (float4) | hit (float2) | shadow_hit (int) | q_ext[2] q_shd[2] (u32)
   const size_t sz[12] = {16, 16, 16, 16, 16, 16, 8, 4, 4, 4, 4, 4};
-  for (int i = 0; i < 12; ++i) HIP_TRY(hipMalloc(&t->wf_mem[i], (size_t)slots * sz[i]));
+  for (int i = 0; i < 12; ++i) {
+    HIP_TRY(hipMalloc(&t->wf_mem[i], (size_t)slots * sz[i]));
+    HIP_TRY(hipMemsetAsync(t->wf_mem[i], 0, (size_t)slots * sz[i], t->stream)); // touch every page once, now
+  }
   if (!t->wf_counts) HIP_TRY(hipMalloc((void **)&t->wf_counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2)));
   t->wf_slots = slots;
   return FSPT_OK;
@@ -430,11 +433,10 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
   if (batch > fit) batch = (uint32_t)fit;
   if (batch < 1) batch = 1;
   if ((uint64_t)batch * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
-  // path-state buffers are sized for the configured batch once (not for this call's tick count), so a
-  // short first call does not cause a reallocation later; small one-off renders only pay for what they use
-  uint32_t alloc_batch = (n_ticks >= batch || t->wf_slots) ? batch : n_ticks;
+  // path-state buffers are sized for the CONFIGURED batch at first use (not for this call's tick count):
+  // a short warm-up call must not cause a reallocation inside a later, longer call
+  int rc = wf_ensure(t, batch * work_total);
   if (batch > n_ticks) batch = n_ticks;
-  int rc = wf_ensure(t, alloc_batch * work_total);
   if (rc) return rc;
 
   fspt::WfP p{};

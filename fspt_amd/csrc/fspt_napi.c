@@ -1,0 +1,429 @@
+/*
+ * fspt_napi.c — thin N-API addon over the libfspt C ABI (include/fspt.h).
+ *
+ * The reference's host language is JavaScript; this is the binding a
+ * maintainer loads from main.js in place of the WebGL2 calls.
+ * Every export is a 1:1 wrapper: TypedArrays in, a caller-owned Float32Array
+ * out, libfspt error codes become JS Errors carrying fspt_last_error().
+ *
+ *   sceneCreate({bvh,tri,mat,norm,uv: Float32Array, atlas: Uint8Array, atlasRes,
+ *                atlasLayers, env: Uint8Array|null, envW, envH, bins: Uint32Array,
+ *                leafSize}, device)                -> scene handle   (initBVH uploads, main.js:408-437)
+ *   targetCreate(scene, W, H)                      -> target handle  (initBuffers, main.js:598-617)
+ *   camera(target, P[3], I[3], fovScale, lens[2], randBase)          (drawCamera, main.js:741-756)
+ *   trace(target, tick, randBase, envTheta, numBounces)              (drawTracer, main.js:758-807)
+ *   render(target, {P,I,fovScale,lens,envTheta,numBounces}, firstTick, nTicks, seed)
+ *   clear(target) / sync(target)                                     (clear, main.js:826-836)
+ *   readRadiance(target, Float32Array(W*H*4))                        (what draw.fs:87 reads)
+ *   setShard(target, shard, nShards, tile) / setPipeline(target, pipeline, batch)
+ *   enableCounters(target, on) / counters(target) -> object
+ *   buildScene(props[], leafSize) -> {bvh,tri,mat,norm,uv,depth}     (native obj_loader.js + bvh.js)
+ *   envBins(Uint8Array rgbe, w, h) -> Uint32Array                    (native env_sampler.js)
+ *   sceneDestroy / targetDestroy / deviceCount / abiVersion
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fspt.h"
+
+#define NAPI_OK(call)                                                  \
+  do {                                                                 \
+    if ((call) != napi_ok) {                                           \
+      napi_throw_error(env, NULL, "fspt_napi: N-API call failed: " #call); \
+      return NULL;                                                     \
+    }                                                                  \
+  } while (0)
+
+#define FSPT_OK_OR_THROW(call)                                         \
+  do {                                                                 \
+    int rc_ = (call);                                                  \
+    if (rc_ != 0) {                                                    \
+      char msg_[640];                                                  \
+      snprintf(msg_, sizeof(msg_), "libfspt error %d: %s", rc_, fspt_last_error()); \
+      napi_throw_error(env, NULL, msg_);                               \
+      return NULL;                                                     \
+    }                                                                  \
+  } while (0)
+
+static napi_value undefined(napi_env env) { napi_value u; napi_get_undefined(env, &u); return u; }
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv) {
+  size_t argc = want;
+  if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+    napi_throw_type_error(env, NULL, "fspt_napi: wrong number of arguments");
+    return -1;
+  }
+  return 0;
+}
+
+/* typed array -> pointer + element count; NULL/undefined allowed when optional */
+static int typed(napi_env env, napi_value v, napi_typedarray_type want, int optional, void **data, size_t *len) {
+  napi_valuetype vt;
+  napi_typeof(env, v, &vt);
+  if (optional && (vt == napi_undefined || vt == napi_null)) { *data = NULL; *len = 0; return 0; }
+  bool is = false;
+  napi_is_typedarray(env, v, &is);
+  napi_typedarray_type t;
+  if (!is || napi_get_typedarray_info(env, v, &t, len, data, NULL, NULL) != napi_ok || t != want) {
+    napi_throw_type_error(env, NULL, "fspt_napi: expected a TypedArray of the documented element type");
+    return -1;
+  }
+  return 0;
+}
+
+static int prop(napi_env env, napi_value obj, const char *name, napi_value *out) {
+  if (napi_get_named_property(env, obj, name, out) != napi_ok) {
+    napi_throw_type_error(env, NULL, "fspt_napi: missing property");
+    return -1;
+  }
+  return 0;
+}
+static int prop_u32(napi_env env, napi_value obj, const char *name, uint32_t *out) {
+  napi_value v;
+  if (prop(env, obj, name, &v)) return -1;
+  if (napi_get_value_uint32(env, v, out) != napi_ok) { napi_throw_type_error(env, NULL, name); return -1; }
+  return 0;
+}
+static int get_f64(napi_env env, napi_value v, double *out) {
+  if (napi_get_value_double(env, v, out) != napi_ok) { napi_throw_type_error(env, NULL, "fspt_napi: expected a number"); return -1; }
+  return 0;
+}
+static int prop_f64(napi_env env, napi_value obj, const char *name, double dflt, double *out) {
+  napi_value v; napi_valuetype vt;
+  if (napi_get_named_property(env, obj, name, &v) != napi_ok) { *out = dflt; return 0; }
+  napi_typeof(env, v, &vt);
+  if (vt == napi_undefined || vt == napi_null) { *out = dflt; return 0; }
+  return get_f64(env, v, out);
+}
+static int float_list(napi_env env, napi_value arr, float *out, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) {
+    napi_value e; double d;
+    if (napi_get_element(env, arr, i, &e) != napi_ok || napi_get_value_double(env, e, &d) != napi_ok) {
+      napi_throw_type_error(env, NULL, "fspt_napi: expected an array of numbers");
+      return -1;
+    }
+    out[i] = (float)d;
+  }
+  return 0;
+}
+static int unwrap(napi_env env, napi_value v, void **out) {
+  if (napi_get_value_external(env, v, out) != napi_ok || !*out) {
+    napi_throw_type_error(env, NULL, "fspt_napi: expected a handle");
+    return -1;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ scene */
+static napi_value SceneCreate(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  fspt_scene_desc d;
+  memset(&d, 0, sizeof(d));
+  napi_value v; void *p; size_t n;
+  if (prop(env, a[0], "bvh", &v) || typed(env, v, napi_float32_array, 0, &p, &n)) return NULL;
+  d.bvh = (const float *)p; d.n_nodes = (uint32_t)(n / 9);
+  if (prop(env, a[0], "tri", &v) || typed(env, v, napi_float32_array, 0, &p, &n)) return NULL;
+  d.tri = (const float *)p; d.n_tris = (uint32_t)(n / 9);
+  size_t nm, nn, nu;
+  if (prop(env, a[0], "mat", &v) || typed(env, v, napi_float32_array, 0, &p, &nm)) return NULL;
+  d.mat = (const float *)p;
+  if (prop(env, a[0], "norm", &v) || typed(env, v, napi_float32_array, 0, &p, &nn)) return NULL;
+  d.norm = (const float *)p;
+  if (prop(env, a[0], "uv", &v) || typed(env, v, napi_float32_array, 0, &p, &nu)) return NULL;
+  d.uv = (const float *)p;
+  if (nm != (size_t)d.n_tris * 12 || nn != (size_t)d.n_tris * 27 || nu != (size_t)d.n_tris * 6) {
+    napi_throw_range_error(env, NULL, "fspt_napi: mat/norm/uv lengths do not match tri (12/27/6 floats per triangle)");
+    return NULL;
+  }
+  if (prop(env, a[0], "atlas", &v) || typed(env, v, napi_uint8_array, 0, &p, &n)) return NULL;
+  d.atlas = (const uint8_t *)p;
+  if (prop_u32(env, a[0], "atlasRes", &d.atlas_res) || prop_u32(env, a[0], "atlasLayers", &d.atlas_layers)) return NULL;
+  if (n != (size_t)d.atlas_res * d.atlas_res * d.atlas_layers * 4) {
+    napi_throw_range_error(env, NULL, "fspt_napi: atlas length != atlasRes^2 * atlasLayers * 4");
+    return NULL;
+  }
+  if (prop(env, a[0], "env", &v) || typed(env, v, napi_uint8_array, 1, &p, &n)) return NULL;
+  d.env = (const uint8_t *)p;
+  if (d.env) {
+    if (prop_u32(env, a[0], "envW", &d.env_w) || prop_u32(env, a[0], "envH", &d.env_h)) return NULL;
+    if (n != (size_t)d.env_w * d.env_h * 4) { napi_throw_range_error(env, NULL, "fspt_napi: env length != envW*envH*4"); return NULL; }
+  }
+  if (prop(env, a[0], "bins", &v) || typed(env, v, napi_uint32_array, 0, &p, &n)) return NULL;
+  d.bins = (const uint32_t *)p; d.n_bins = (uint32_t)(n / 4);
+  if (prop_u32(env, a[0], "leafSize", &d.leaf_size)) return NULL;
+  int32_t device = 0;
+  napi_get_value_int32(env, a[1], &device);
+  fspt_scene *s = NULL;
+  FSPT_OK_OR_THROW(fspt_scene_create(&d, device, &s));
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, s, NULL, NULL, &ext));
+  return ext;
+}
+static napi_value SceneDestroy(napi_env env, napi_callback_info info) {
+  napi_value a[1]; void *h;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  FSPT_OK_OR_THROW(fspt_scene_destroy((fspt_scene *)h));
+  return undefined(env);
+}
+
+/* ----------------------------------------------------------------- target */
+static napi_value TargetCreate(napi_env env, napi_callback_info info) {
+  napi_value a[3]; void *h; uint32_t W, H;
+  if (get_args(env, info, 3, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &W));
+  NAPI_OK(napi_get_value_uint32(env, a[2], &H));
+  fspt_target *t = NULL;
+  FSPT_OK_OR_THROW(fspt_target_create((fspt_scene *)h, W, H, &t));
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, t, NULL, NULL, &ext));
+  return ext;
+}
+static napi_value TargetDestroy(napi_env env, napi_callback_info info) {
+  napi_value a[1]; void *h;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  FSPT_OK_OR_THROW(fspt_target_destroy((fspt_target *)h));
+  return undefined(env);
+}
+static napi_value Camera(napi_env env, napi_callback_info info) {
+  napi_value a[6]; void *h; float P[3], I[3], lens[2]; double fov, rb;
+  if (get_args(env, info, 6, a) || unwrap(env, a[0], &h)) return NULL;
+  if (float_list(env, a[1], P, 3) || float_list(env, a[2], I, 3) || get_f64(env, a[3], &fov) || float_list(env, a[4], lens, 2) ||
+      get_f64(env, a[5], &rb)) return NULL;
+  FSPT_OK_OR_THROW(fspt_camera((fspt_target *)h, P, I, (float)fov, lens, (float)rb));
+  return undefined(env);
+}
+static napi_value Trace(napi_env env, napi_callback_info info) {
+  napi_value a[5]; void *h; uint32_t tick, nb; double rb, theta;
+  if (get_args(env, info, 5, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &tick));
+  if (get_f64(env, a[2], &rb) || get_f64(env, a[3], &theta)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[4], &nb));
+  FSPT_OK_OR_THROW(fspt_trace((fspt_target *)h, tick, (float)rb, (float)theta, nb));
+  return undefined(env);
+}
+static napi_value Render(napi_env env, napi_callback_info info) {
+  napi_value a[5], v; void *h; uint32_t first, n; double seed, d;
+  if (get_args(env, info, 5, a) || unwrap(env, a[0], &h)) return NULL;
+  fspt_camera_params cp;
+  memset(&cp, 0, sizeof(cp));
+  if (prop(env, a[1], "P", &v) || float_list(env, v, cp.P, 3)) return NULL;
+  if (prop(env, a[1], "I", &v) || float_list(env, v, cp.I, 3)) return NULL;
+  if (prop(env, a[1], "lens", &v) || float_list(env, v, cp.lens, 2)) return NULL;
+  if (prop_f64(env, a[1], "fovScale", 0.5, &d)) return NULL; cp.fov_scale = (float)d;
+  if (prop_f64(env, a[1], "envTheta", 0.0, &d)) return NULL; cp.env_theta = (float)d;
+  if (prop_f64(env, a[1], "numBounces", 4.0, &d)) return NULL; cp.num_bounces = (uint32_t)d;
+  NAPI_OK(napi_get_value_uint32(env, a[2], &first));
+  NAPI_OK(napi_get_value_uint32(env, a[3], &n));
+  /* seed: BigInt (full 64-bit xorshift state) or a number < 2^53 */
+  uint64_t seed64 = 0;
+  napi_valuetype st;
+  napi_typeof(env, a[4], &st);
+  if (st == napi_bigint) {
+    bool lossless = true;
+    NAPI_OK(napi_get_value_bigint_uint64(env, a[4], &seed64, &lossless));
+  } else {
+    if (get_f64(env, a[4], &seed)) return NULL;
+    seed64 = (uint64_t)seed;
+  }
+  FSPT_OK_OR_THROW(fspt_render((fspt_target *)h, &cp, first, n, seed64));
+  return undefined(env);
+}
+static napi_value Clear(napi_env env, napi_callback_info info) {
+  napi_value a[1]; void *h;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  FSPT_OK_OR_THROW(fspt_clear((fspt_target *)h));
+  return undefined(env);
+}
+static napi_value Sync(napi_env env, napi_callback_info info) {
+  napi_value a[1]; void *h;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  FSPT_OK_OR_THROW(fspt_sync((fspt_target *)h));
+  return undefined(env);
+}
+static napi_value ReadRadiance(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h, *p; size_t n;
+  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h) || typed(env, a[1], napi_float32_array, 0, &p, &n)) return NULL;
+  /* the library writes W*H*4 floats: the caller sized the array from the same W,H */
+  FSPT_OK_OR_THROW(fspt_read_radiance((fspt_target *)h, (float *)p));
+  return a[1];
+}
+static napi_value SetShard(napi_env env, napi_callback_info info) {
+  napi_value a[4]; void *h; uint32_t s, n, tile;
+  if (get_args(env, info, 4, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &s));
+  NAPI_OK(napi_get_value_uint32(env, a[2], &n));
+  NAPI_OK(napi_get_value_uint32(env, a[3], &tile));
+  FSPT_OK_OR_THROW(fspt_target_set_shard((fspt_target *)h, s, n, tile));
+  return undefined(env);
+}
+static napi_value SetPipeline(napi_env env, napi_callback_info info) {
+  napi_value a[3]; void *h; int32_t p; uint32_t b;
+  if (get_args(env, info, 3, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_int32(env, a[1], &p));
+  NAPI_OK(napi_get_value_uint32(env, a[2], &b));
+  FSPT_OK_OR_THROW(fspt_target_set_pipeline((fspt_target *)h, p, b));
+  return undefined(env);
+}
+static napi_value EnableCounters(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h; bool on;
+  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_bool(env, a[1], &on));
+  FSPT_OK_OR_THROW(fspt_enable_counters((fspt_target *)h, on ? 1 : 0));
+  return undefined(env);
+}
+static napi_value GetCounters(napi_env env, napi_callback_info info) {
+  napi_value a[1]; void *h;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  fspt_counters c;
+  FSPT_OK_OR_THROW(fspt_get_counters((fspt_target *)h, &c));
+  napi_value o, v;
+  NAPI_OK(napi_create_object(env, &o));
+  const char *names[6] = {"samples", "rays", "steps", "leaves", "shades", "envLookups"};
+  uint64_t vals[6] = {c.samples, c.rays, c.steps, c.leaves, c.shades, c.env_lookups};
+  for (int i = 0; i < 6; ++i) {
+    NAPI_OK(napi_create_double(env, (double)vals[i], &v));
+    NAPI_OK(napi_set_named_property(env, o, names[i], v));
+  }
+  return o;
+}
+
+/* --------------------------------------------------------- scene pipeline */
+static napi_value f32_out(napi_env env, size_t n, float **data) {
+  napi_value ab, ta;
+  if (napi_create_arraybuffer(env, n * 4, (void **)data, &ab) != napi_ok) return NULL;
+  if (napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta) != napi_ok) return NULL;
+  return ta;
+}
+/* buildScene([{obj: string, rotate:[{axis:[x,y,z],angle}], scale, translate:[3], normals:'flat'|'smooth'|'mesh',
+ *              material:{diffuseIndex,specularIndex,normalIndex,roughnessIndex,emittance:[3],ior,dielectric}}], leafSize) */
+static napi_value BuildScene(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  uint32_t nprops = 0, leaf = 4;
+  NAPI_OK(napi_get_array_length(env, a[0], &nprops));
+  NAPI_OK(napi_get_value_uint32(env, a[1], &leaf));
+  fspt_builder *b = NULL;
+  FSPT_OK_OR_THROW(fspt_builder_create(&b));
+  napi_value result = NULL;
+  for (uint32_t i = 0; i < nprops; ++i) {
+    napi_value pr, v, m;
+    if (napi_get_element(env, a[0], i, &pr) != napi_ok) goto fail;
+    fspt_prop_desc pd;
+    memset(&pd, 0, sizeof(pd));
+    double rot[4 * 16];
+    uint32_t nrot = 0;
+    if (napi_get_named_property(env, pr, "rotate", &v) == napi_ok) {
+      bool isarr = false;
+      napi_is_array(env, v, &isarr);
+      if (isarr) {
+        napi_get_array_length(env, v, &nrot);
+        if (nrot > 16) nrot = 16;
+        for (uint32_t r = 0; r < nrot; ++r) {
+          napi_value re, ax, e;
+          napi_get_element(env, v, r, &re);
+          if (prop(env, re, "axis", &ax)) goto fail;
+          for (uint32_t k = 0; k < 3; ++k) { napi_get_element(env, ax, k, &e); if (get_f64(env, e, &rot[4 * r + k])) goto fail; }
+          if (prop_f64(env, re, "angle", 0.0, &rot[4 * r + 3])) goto fail;
+        }
+      }
+    }
+    pd.rotate = rot; pd.n_rotate = nrot;
+    if (prop_f64(env, pr, "scale", 1.0, &pd.scale)) goto fail;
+    if (napi_get_named_property(env, pr, "translate", &v) == napi_ok) {
+      bool isarr = false;
+      napi_is_array(env, v, &isarr);
+      if (isarr) for (uint32_t k = 0; k < 3; ++k) { napi_value e; napi_get_element(env, v, k, &e); if (get_f64(env, e, &pd.translate[k])) goto fail; }
+    }
+    pd.normals_mode = 0;
+    if (napi_get_named_property(env, pr, "normals", &v) == napi_ok) {
+      char buf[16]; size_t len = 0;
+      if (napi_get_value_string_utf8(env, v, buf, sizeof(buf), &len) == napi_ok) {
+        if (!strcmp(buf, "smooth")) pd.normals_mode = 1; else if (!strcmp(buf, "mesh")) pd.normals_mode = 2;
+      }
+    }
+    if (prop(env, pr, "material", &m)) goto fail;
+    if (prop_f64(env, m, "diffuseIndex", 0, &pd.diffuse_layer) || prop_f64(env, m, "specularIndex", 0, &pd.emissive_layer) ||
+        prop_f64(env, m, "normalIndex", 0, &pd.normal_layer) || prop_f64(env, m, "roughnessIndex", 0, &pd.mr_layer) ||
+        prop_f64(env, m, "ior", 1.4, &pd.ior) || prop_f64(env, m, "dielectric", -1, &pd.dielectric)) goto fail;
+    if (napi_get_named_property(env, m, "emittance", &v) == napi_ok) {
+      bool isarr = false;
+      napi_is_array(env, v, &isarr);
+      if (isarr) for (uint32_t k = 0; k < 3; ++k) { napi_value e; napi_get_element(env, v, k, &e); if (get_f64(env, e, &pd.emittance[k])) goto fail; }
+    }
+    if (prop(env, pr, "obj", &v)) goto fail;
+    size_t len = 0;
+    if (napi_get_value_string_utf8(env, v, NULL, 0, &len) != napi_ok) { napi_throw_type_error(env, NULL, "prop.obj must be the OBJ text"); goto fail; }
+    char *text = (char *)malloc(len + 1);
+    napi_get_value_string_utf8(env, v, text, len + 1, &len);
+    int rc = fspt_builder_add_obj(b, text, len, &pd);
+    free(text);
+    if (rc) { char msg[640]; snprintf(msg, sizeof(msg), "libfspt error %d: %s", rc, fspt_last_error()); napi_throw_error(env, NULL, msg); goto fail; }
+  }
+  {
+    int rc = fspt_builder_build(b, leaf);
+    if (rc) { char msg[640]; snprintf(msg, sizeof(msg), "libfspt error %d: %s", rc, fspt_last_error()); napi_throw_error(env, NULL, msg); goto fail; }
+    uint32_t nn, nt, depth;
+    fspt_builder_counts(b, &nn, &nt, &depth);
+    float *bvh, *tri, *mat, *norm, *uv;
+    napi_value o, v;
+    napi_create_object(env, &o);
+    napi_value tb = f32_out(env, (size_t)nn * 9, &bvh), tt = f32_out(env, (size_t)nt * 9, &tri), tm = f32_out(env, (size_t)nt * 12, &mat),
+               tn = f32_out(env, (size_t)nt * 27, &norm), tu = f32_out(env, (size_t)nt * 6, &uv);
+    if (!tb || !tt || !tm || !tn || !tu) { napi_throw_error(env, NULL, "fspt_napi: allocation failed"); goto fail; }
+    fspt_builder_get(b, bvh, tri, mat, norm, uv);
+    napi_set_named_property(env, o, "bvh", tb); napi_set_named_property(env, o, "tri", tt); napi_set_named_property(env, o, "mat", tm);
+    napi_set_named_property(env, o, "norm", tn); napi_set_named_property(env, o, "uv", tu);
+    napi_create_uint32(env, depth, &v); napi_set_named_property(env, o, "depth", v);
+    result = o;
+  }
+fail:
+  fspt_builder_destroy(b);
+  return result;
+}
+static napi_value EnvBins(napi_env env, napi_callback_info info) {
+  napi_value a[3]; void *p; size_t n; uint32_t w, h;
+  if (get_args(env, info, 3, a) || typed(env, a[0], napi_uint8_array, 0, &p, &n)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &w));
+  NAPI_OK(napi_get_value_uint32(env, a[2], &h));
+  if (n != (size_t)w * h * 4) { napi_throw_range_error(env, NULL, "fspt_napi: rgbe length != w*h*4"); return NULL; }
+  uint32_t nb = 0;
+  FSPT_OK_OR_THROW(fspt_env_bins((const uint8_t *)p, w, h, NULL, 0, &nb));
+  napi_value ab, ta; void *data;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nb * 16, &data, &ab));
+  NAPI_OK(napi_create_typedarray(env, napi_uint32_array, (size_t)nb * 4, ab, 0, &ta));
+  FSPT_OK_OR_THROW(fspt_env_bins((const uint8_t *)p, w, h, (uint32_t *)data, nb, &nb));
+  return ta;
+}
+static napi_value RandBaseNext(napi_env env, napi_callback_info info) {
+  /* state is a BigUint64Array(1) so the 64-bit xorshift state survives the JS boundary */
+  napi_value a[1]; void *p; size_t n;
+  if (get_args(env, info, 1, a) || typed(env, a[0], napi_biguint64_array, 0, &p, &n) || n < 1) return NULL;
+  napi_value v;
+  NAPI_OK(napi_create_double(env, (double)fspt_rand_base_next((uint64_t *)p), &v));
+  return v;
+}
+static napi_value DeviceCount(napi_env env, napi_callback_info info) {
+  napi_value v; napi_create_int32(env, fspt_device_count(), &v); return v;
+}
+static napi_value AbiVersion(napi_env env, napi_callback_info info) {
+  napi_value v; napi_create_int32(env, fspt_abi_version(), &v); return v;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+  struct { const char *name; napi_callback fn; } fns[] = {
+      {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
+      {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"render", Render}, {"clear", Clear},
+      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"setShard", SetShard}, {"setPipeline", SetPipeline},
+      {"enableCounters", EnableCounters}, {"counters", GetCounters}, {"buildScene", BuildScene}, {"envBins", EnvBins},
+      {"randBaseNext", RandBaseNext}, {"deviceCount", DeviceCount}, {"abiVersion", AbiVersion}};
+  for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
+    napi_value f;
+    if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+    if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
+  }
+  return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

@@ -1,0 +1,34 @@
+'use strict';
+// Driven by tests/test_node_host.py: node node_host_check.js <mode> <job.json> <out.json>
+const fs = require('fs');
+const path = require('path');
+const F = require(path.join(__dirname, '..', 'fspt_amd', 'js', 'fspt.js'));
+const mode = process.argv[2];
+const job = JSON.parse(fs.readFileSync(process.argv[3], 'utf8'));
+const out = {};
+const b64 = (ta) => Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength).toString('base64');
+const env = job.env ? { rgbe: Uint8Array.from(Buffer.from(job.env.rgbe_b64, 'base64')), width: job.env.width, height: job.env.height } : null;
+if (mode === 'exports') {
+  out.exports = Object.keys(F.addon).sort();
+  out.abi = F.addon.abiVersion();
+  out.devices = F.addon.deviceCount();
+} else if (mode === 'build') {
+  const s = F.buildScene(job.props, job.objs, env, 4);
+  for (const k of ['bvh', 'tri', 'mat', 'norm', 'uv', 'bins', 'atlas']) out[k] = b64(s[k]);
+  out.depth = s.depth; out.atlasLayers = s.atlasLayers;
+} else if (mode === 'nogpu') {
+  const s = F.buildScene(job.props, job.objs, env, 4);
+  try { new F.PathTracer(s, 16, 16, 0); out.error = null; } catch (e) { out.error = String(e.message); }
+} else if (mode === 'render') {
+  const s = F.buildScene(job.props, job.objs, env, 4);
+  const pt = new F.PathTracer(s, job.W, job.H, 0);
+  pt.eye = job.cam.P; pt.dir = job.cam.I; pt.fovScale = job.cam.fov_scale; pt.envTheta = job.cam.env_theta;
+  pt.lensFeatures = job.cam.lens; pt.numBounces = job.bounces;
+  pt.seed(job.seed);
+  for (let k = 0; k < job.ticks_two_call; k++) pt.tick();
+  pt.render(job.ticks_fused);
+  out.radiance = b64(pt.readRadiance());
+  pt.enableCounters(true);
+  pt.close();
+}
+fs.writeFileSync(process.argv[4], JSON.stringify(out));

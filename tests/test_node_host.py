@@ -1,0 +1,79 @@
+"""The JavaScript host (fspt_amd/js/fspt.js + the N-API addon) — the reference's host
+language.  Skipped when node / the Node headers are not installed."""
+import base64
+import json
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle as O
+from fspt_amd import scene as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ADDON = os.path.join(ROOT, "fspt_amd", "js", "fspt_napi.node")
+pytestmark = pytest.mark.skipif(shutil.which("node") is None or not os.path.exists(ADDON),
+                                reason="node or the built addon is missing")
+
+
+def run_node(mode, job):
+    with tempfile.TemporaryDirectory() as td:
+        jp, op = os.path.join(td, "job.json"), os.path.join(td, "out.json")
+        json.dump(job, open(jp, "w"))
+        subprocess.check_call(["node", os.path.join(ROOT, "tests", "node_host_check.js"), mode, jp, op], timeout=300)
+        return json.load(open(op))
+
+
+def small_job():
+    env, w, h = S.synthetic_env(64, 32)
+    return {"props": S.bunny_props(), "objs": {"synthetic/cube_sphere.obj": S.cube_sphere_obj(8), "synthetic/quad.obj": S.QUAD_OBJ},
+            "env": {"rgbe_b64": base64.b64encode(env.tobytes()).decode(), "width": w, "height": h}}
+
+
+def dec(b, dt):
+    return np.frombuffer(base64.b64decode(b), dtype=dt)
+
+
+def test_addon_exports():
+    out = run_node("exports", {})
+    assert out["abi"] == 1
+    for name in ("sceneCreate", "targetCreate", "camera", "trace", "render", "clear", "readRadiance", "setShard",
+                 "buildScene", "envBins", "counters"):
+        assert name in out["exports"]
+
+
+def test_js_build_scene_matches_python_host(small_scene):
+    """Same native pipeline through the JS host: arrays identical to the Python host's (which are
+    pinned to the reference JS output in test_goldens)."""
+    out = run_node("build", small_job())
+    for k in ("bvh", "tri", "mat", "norm", "uv"):
+        assert np.array_equal(dec(out[k], np.uint32), getattr(small_scene, k).view(np.uint32)), k
+    assert np.array_equal(dec(out["bins"], np.uint32), small_scene.bins)
+    assert np.array_equal(dec(out["atlas"], np.uint8), small_scene.atlas)
+    assert out["depth"] == small_scene.depth
+
+
+def test_js_host_fails_loudly_without_gpu():
+    from fspt_amd import _lib as L
+    if L.lib().fspt_device_count() > 0:
+        pytest.skip("GPU present")
+    out = run_node("nogpu", small_job())
+    assert out["error"] and "no CPU fallback" in out["error"]
+
+
+@pytest.mark.gpu
+def test_js_host_render_matches_oracle(small_scene, camera):
+    W, H = 80, 48
+    job = small_job()
+    job.update(W=W, H=H, bounces=4, seed=21, ticks_two_call=2, ticks_fused=3,
+               cam=dict(P=camera["P"], I=camera["I"], fov_scale=camera["fov_scale"], env_theta=camera["env_theta"],
+                        lens=camera["lens"]))
+    out = run_node("render", job)
+    got = dec(out["radiance"], np.float32).reshape(H, W, 4)
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
+             0, 5, 21, want)
+    assert np.array_equal(got, want)
