@@ -169,6 +169,16 @@ def main():
                     "avg_launch_ms": round(avg_launch_ms, 4), "bytes_per_sample": round(bps, 1),
                     "per_sample": per_sample}
         roofline.update(extra)
+        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot run the
+        # profiler on itself): only reported for the exact workload those passes measured
+        tpath = os.path.join(ROOT, "profiles", "r01", "final_hbm_traffic.json")
+        key = {76: "c2_70k", 289: "c3_1M"}.get(args.mesh_n)
+        if (stages is not None and key and os.path.exists(tpath) and n_gpus == 1 and args.batch == 32
+                and (args.width, args.height, args.bounces) == (1920, 1080, 8)):
+            tj = json.load(open(tpath)).get(key, {}).get("k_wf_trace<false>")
+            if tj:
+                roofline["traffic"] = round(tj["hbm_bytes_per_launch_corrected"])
+                roofline["traffic_source"] = "profiles/r01/final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
         out = {
             "metric": "Msamples/s at 1920x1080 depth 8 (bunny, 70k tri)",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
