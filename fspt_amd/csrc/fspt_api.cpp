@@ -60,7 +60,7 @@ struct fspt_target {
   // wavefront pipeline
   int pipeline = 1;           // 0 = megakernel, 1 = wavefront
   uint32_t batch_ticks = 32;  // ticks traced together by the wavefront pipeline
-  void *wf_mem[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void *wf_mem[13] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   fspt::WfCounts *wf_counts = nullptr;
   uint32_t wf_slots = 0;      // allocated path slots
   // per-launch stage timing (HIP events on the target's stream)
@@ -276,7 +276,7 @@ int fspt_scene_depth(const fspt_scene *s, uint32_t *depth) {
 static const uint32_t WORK_RING = 4096;
 static const uint32_t WF_ROUNDS_MAX = fspt::MAX_PATH_ITERS + 4;
 static const uint32_t EV_PAIRS = 4096;
-static const uint64_t WF_SLOT_BUDGET = 160ull << 20; // path slots, 124 B each (20 GB of the 288 GB HBM)
+static const uint64_t WF_SLOT_BUDGET = 160ull << 20; // path slots, 140 B each (22 GB of the 288 GB HBM)
 
 int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **out) {
   if (!scene || !out || W == 0 || H == 0) { fspt_set_error("fspt_target_create: bad argument"); return FSPT_E_INVALID; }
@@ -393,9 +393,9 @@ static int wf_ensure(fspt_target *t, uint32_t slots) {
   if (t->wf_slots >= slots && t->wf_counts) return FSPT_OK;
   HIP_TRY(hipStreamSynchronize(t->stream));
   for (void *&m : t->wf_mem) { if (m) { HIP_TRY(hipFree(m)); m = nullptr; } }
-  // ray_o ray_d thr col shd pend (float4) | hit (float2) | shadow_hit (int) | q_ext[2] q_shd[2] (u32)
-  const size_t sz[12] = {16, 16, 16, 16, 16, 16, 8, 4, 4, 4, 4, 4};
-  for (int i = 0; i < 12; ++i) {
+  // ray_o ray_d thr col shd pend (float4) | hit (float2) | shadow_hit (int) | q_ext[2] q_shd[2] (u32) | fin (float4)
+  const size_t sz[13] = {16, 16, 16, 16, 16, 16, 8, 4, 4, 4, 4, 4, 16};
+  for (int i = 0; i < 13; ++i) {
     HIP_TRY(hipMalloc(&t->wf_mem[i], (size_t)slots * sz[i]));
     HIP_TRY(hipMemsetAsync(t->wf_mem[i], 0, (size_t)slots * sz[i], t->stream)); // touch every page once, now
   }
@@ -446,6 +446,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
   p.hit = (float2 *)t->wf_mem[6]; p.shadow_hit = (int *)t->wf_mem[7];
   p.q_ext[0] = (uint32_t *)t->wf_mem[8]; p.q_ext[1] = (uint32_t *)t->wf_mem[9];
   p.q_shd[0] = (uint32_t *)t->wf_mem[10]; p.q_shd[1] = (uint32_t *)t->wf_mem[11];
+  p.fin = (float4 *)t->wf_mem[12];
   p.counts = t->wf_counts;
   p.W = t->W; p.H = t->H; p.work_total = work_total;
   p.env_theta = cam->env_theta; p.num_bounces = cam->num_bounces;

@@ -96,15 +96,16 @@ struct IntersectP {
 //   col    color.xyz, flags (bits: 0-7 bounce, 8-15 iters, 16 primary, 17 hasShadow)
 //   shd    envDir.xyz, weights.x     pend  reflectance*envThroughput.xyz, -
 //   hit    (t, index) of the extension/primary ray;  shadow_hit  index of the NEE ray
+//   fin    finished sample colour, indexed tick-major [j][w]
 // Queues hold slot ids; WF_DEAD marks a skipped entry (ragged tile edge).
 // ---------------------------------------------------------------------------
 constexpr uint32_t WF_DEAD = 0xFFFFFFFFu;
 constexpr int WF_MAX_BATCH = 64;
 constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17;
 
-struct WfCounts { // one per round, zeroed before the batch
-  uint32_t n_ext;  // entries of q_ext for this round
-  uint32_t n_shd;  // entries of q_shd for this round
+struct alignas(16) WfCounts { // one per round, zeroed before the batch
+  uint32_t n_ext;  // entries of q_ext for this round   } bumped together by one 64-bit atomic
+  uint32_t n_shd;  // entries of q_shd for this round   } (n_ext low word, n_shd high word)
   uint32_t head;   // trace kernel work-pool head (one head: XCD-segmented pools measured 50 % slower,
                    // static segments unbalance the XCDs and the L2 hit rate did not move - profiles/r01)
   uint32_t pad;
@@ -113,6 +114,7 @@ struct WfCounts { // one per round, zeroed before the batch
 struct WfP {
   DScene scene;
   float4 *ray_o, *ray_d, *thr, *col, *shd, *pend;
+  float4 *fin; // finished sample colours, tick-major [j][w] (resolve reads them coalesced)
   float2 *hit;
   int *shadow_hit;
   uint32_t *q_ext[2];

@@ -683,7 +683,70 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 // (layout and slot numbering: fspt_device.hpp)
 // ===========================================================================
 #define WF_TRACE_CHUNK 512u
+// measured on C2 (profiles/r01): 1 -> 0.462, 8 -> 0.348, 16 -> 0.338, 24 -> 0.336, 32 -> 0.343 ms per tick
+#ifndef WF_INTERIOR_MIN
+#define WF_INTERIOR_MIN 16
+#endif
+#ifndef WF_REFILL_MIN
+#define WF_REFILL_MIN 1
+#endif
+#ifndef WF_LOGIC_THREADS
 #define WF_LOGIC_THREADS 512
+#endif
+
+// Path state is streamed (touched once per round): non-temporal so it does not evict the BVH and
+// shading records from L2.  FSPT_NT=0 builds the plain variant for A/B.
+#ifndef FSPT_NT
+#define FSPT_NT 0 /* measured: logic kernel 5 % slower with nt, trace unchanged (profiles/r01) */
+#endif
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+FM_DEV float4 ld4(const float4 *p) {
+#if FSPT_NT
+  nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+FM_DEV void st4(float4 *p, float4 v) {
+#if FSPT_NT
+  nt_f4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<nt_f4 *>(p));
+#else
+  *p = v;
+#endif
+}
+FM_DEV float2 ld2(const float2 *p) {
+#if FSPT_NT
+  nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2 *>(p));
+  return make_float2(v.x, v.y);
+#else
+  return *p;
+#endif
+}
+FM_DEV void st2(float2 *p, float2 v) {
+#if FSPT_NT
+  nt_f2 w = {v.x, v.y};
+  __builtin_nontemporal_store(w, reinterpret_cast<nt_f2 *>(p));
+#else
+  *p = v;
+#endif
+}
+FM_DEV int ldi(const int *p) {
+#if FSPT_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+FM_DEV void sti(int *p, int v) {
+#if FSPT_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 
 FM_DEV uint32_t lane_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -707,10 +770,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_gen(const WfP p) {
         o = v3(po.x, po.y, po.z);
         d = v3(di.x, di.y, di.z);
       }
-      p.ray_o[s] = make_float4(o.x, o.y, o.z, 0.0f);
-      p.ray_d[s] = make_float4(d.x, d.y, d.z, 0.0f);
-      p.thr[s] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-      p.col[s] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(WF_FLAG_PRIMARY));
+      st4(p.ray_o + s, make_float4(o.x, o.y, o.z, 0.0f));
+      st4(p.ray_d + s, make_float4(d.x, d.y, d.z, 0.0f));
+      st4(p.thr + s, make_float4(1.0f, 1.0f, 1.0f, 0.0f));
+      st4(p.col + s, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(WF_FLAG_PRIMARY)));
       entry = s;
       nsamples++;
     }
@@ -770,6 +833,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     while (true) {
       unsigned long long need = __ballot(idle);
       if (need == 0ull) break;
+#if WF_REFILL_MIN > 1
+      // a refill stalls the whole wave on the new rays' loads: wait until several lanes are idle
+      if ((uint32_t)__popcll(need) < WF_REFILL_MIN && !exhausted) break;
+#endif
       uint32_t avail = pool_end - pool_next;
       if (avail == 0u) {
         if (exhausted) break;
@@ -789,8 +856,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
         bool sh = item < n_shd;
         uint32_t s = sh ? q_shd[item] : q_ext[item - n_shd];
         if (s != WF_DEAD) {
-          float4 ro = p.ray_o[s];
-          float4 rd = sh ? p.shd[s] : p.ray_d[s];
+          float4 ro = ld4(p.ray_o + s);
+          float4 rd = ld4(sh ? p.shd + s : p.ray_d + s);
           o = v3(ro.x, ro.y, ro.z);
           d = v3(rd.x, rd.y, rd.z);
           inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -809,7 +876,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     if (__ballot(!idle) == 0ull) break;
 
     // ---- interior nodes ----
-    while (cur >= 0) {
+    // Leave the loop once fewer than WF_INTERIOR_MIN lanes are still descending, so the lanes that
+    // already wait at a leaf (or for a refill) are not held up by a few long descents.
+    while (true) {
+      unsigned long long in = __ballot(cur >= 0);
+      if (in == 0ull) break;
+#if WF_INTERIOR_MIN > 1
+      if ((uint32_t)__popcll(in) < WF_INTERIOR_MIN && __popcll(__ballot(!idle)) > __popcll(in)) break;
+#endif
+      if (cur >= 0) {
       if (COUNT) c_steps++;
       const float4 *n = nodes + (size_t)cur * NODE_F4;
       float4 n0 = n[0], n1 = n[1], n2 = n[2];
@@ -834,9 +909,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
       } else {
         cur = REF_SENTINEL;
       }
+      }
     }
     // ---- leaf ----
-    if (!idle && cur != REF_SENTINEL) {
+    if (!idle && cur < 0 && cur != REF_SENTINEL) {
       if (COUNT) { c_steps++; c_leaves++; }
       int ts = ~cur;
       const float4 *tp = tris + (size_t)ts * TRI_F4;
@@ -861,8 +937,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     }
     // ---- finished rays: write the result, lane becomes idle ----
     if (!idle && cur == REF_SENTINEL) {
-      if (is_shadow) p.shadow_hit[slot] = hit;
-      else p.hit[slot] = make_float2(t, __int_as_float(hit));
+      if (is_shadow) sti(p.shadow_hit + slot, hit);
+      else st2(p.hit + slot, make_float2(t, __int_as_float(hit)));
       idle = true;
     }
   }
@@ -884,6 +960,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(const WfP p) {
+  static_assert(WF_LOGIC_THREADS % WAVE == 0, "whole waves");
   __shared__ uint32_t s_cnt[2][WF_LOGIC_THREADS / WAVE];
   __shared__ uint32_t s_base[2];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -902,8 +979,8 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
     uint32_t s = (i < n_in) ? q_in[i] : WF_DEAD;
     bool survive = false, shadow = false;
     if (s != WF_DEAD) {
-      float4 ro = p.ray_o[s], rd = p.ray_d[s], th = p.thr[s], co = p.col[s];
-      float2 h = p.hit[s];
+      float4 ro = ld4(p.ray_o + s), rd = ld4(p.ray_d + s), th = ld4(p.thr + s), co = ld4(p.col + s);
+      float2 h = ld2(p.hit + s);
       uint32_t flags = __float_as_uint(co.w);
       Path ps;
       ps.ro = v3(ro.x, ro.y, ro.z);
@@ -921,40 +998,51 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
       ps.pend = v3(0.0f, 0.0f, 0.0f);
       int hitA = -1;
       if (ps.hasShadow) {
-        float4 sd = p.shd[s], pe = p.pend[s];
+        float4 sd = ld4(p.shd + s), pe = ld4(p.pend + s);
         ps.envDir = v3(sd.x, sd.y, sd.z);
         ps.wx = sd.w;
         ps.pend = v3(pe.x, pe.y, pe.z);
-        hitA = p.shadow_hit[s];
+        hitA = ldi(p.shadow_hit + s);
       }
-      uint32_t j = s % p.n_batch;
+      const uint32_t j = s % p.n_batch;
       bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), p.rb_trace[j], p.env_theta,
                                           p.num_bounces, cnt);
       if (finished) {
-        p.col[s] = make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f);
+        // park the sample colour tick-major (fin[j][w]) so that resolve reads coalesced
+        uint32_t w = s / p.n_batch;
+        st4(p.fin + (size_t)j * p.work_total + w, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
       } else {
         uint32_t nf = ((uint32_t)ps.bounce & 255u) | (((uint32_t)ps.iters & 255u) << 8) |
                       (ps.hasShadow ? WF_FLAG_SHADOW : 0u);
-        p.ray_o[s] = make_float4(ps.ro.x, ps.ro.y, ps.ro.z, 0.0f);
-        p.ray_d[s] = make_float4(ps.rd.x, ps.rd.y, ps.rd.z, 0.0f);
-        p.thr[s] = make_float4(ps.thr.x, ps.thr.y, ps.thr.z, ps.wy);
-        p.col[s] = make_float4(ps.color.x, ps.color.y, ps.color.z, __uint_as_float(nf));
+        st4(p.ray_o + s, make_float4(ps.ro.x, ps.ro.y, ps.ro.z, 0.0f));
+        st4(p.ray_d + s, make_float4(ps.rd.x, ps.rd.y, ps.rd.z, 0.0f));
+        st4(p.thr + s, make_float4(ps.thr.x, ps.thr.y, ps.thr.z, ps.wy));
+        st4(p.col + s, make_float4(ps.color.x, ps.color.y, ps.color.z, __uint_as_float(nf)));
         if (ps.hasShadow) {
-          p.shd[s] = make_float4(ps.envDir.x, ps.envDir.y, ps.envDir.z, ps.wx);
-          p.pend[s] = make_float4(ps.pend.x, ps.pend.y, ps.pend.z, 0.0f);
+          st4(p.shd + s, make_float4(ps.envDir.x, ps.envDir.y, ps.envDir.z, ps.wx));
+          st4(p.pend + s, make_float4(ps.pend.x, ps.pend.y, ps.pend.z, 0.0f));
         }
         survive = true;
         shadow = ps.hasShadow;
       }
     }
-    // block-aggregated append of survivors (q_ext) and their shadow rays (q_shd): 2 atomics per block
+    // block-aggregated append of survivors (q_ext) and their shadow rays (q_shd): ONE 64-bit atomic per
+    // block iteration (n_ext in the low word, n_shd in the high word; neither can overflow 32 bits)
     unsigned long long m0 = __ballot(survive), m1 = __ballot(shadow);
     if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); }
     __syncthreads();
-    if (threadIdx.x < 2) {
-      uint32_t tot = 0;
-      for (int w2 = 0; w2 < WF_LOGIC_THREADS / WAVE; ++w2) { uint32_t c = s_cnt[threadIdx.x][w2]; s_cnt[threadIdx.x][w2] = tot; tot += c; }
-      s_base[threadIdx.x] = tot ? atomicAdd(threadIdx.x == 0 ? &cn->n_ext : &cn->n_shd, tot) : 0u;
+    if (threadIdx.x == 0) {
+      uint32_t tot0 = 0, tot1 = 0;
+      for (int w2 = 0; w2 < WF_LOGIC_THREADS / WAVE; ++w2) {
+        uint32_t c0 = s_cnt[0][w2], c1 = s_cnt[1][w2];
+        s_cnt[0][w2] = tot0; s_cnt[1][w2] = tot1;
+        tot0 += c0; tot1 += c1;
+      }
+      unsigned long long old = 0ull;
+      if (tot0 | tot1)
+        old = atomicAdd(reinterpret_cast<unsigned long long *>(&cn->n_ext), ((unsigned long long)tot1 << 32) | tot0);
+      s_base[0] = (uint32_t)old;
+      s_base[1] = (uint32_t)(old >> 32);
     }
     __syncthreads();
     if (survive) q_out[s_base[0] + s_cnt[0][wave] + lane_rank(m0)] = s;
@@ -980,7 +1068,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
     uint32_t pix = y * p.W + x;
     float4 acc = p.accum[pix];
     for (uint32_t j = 0; j < p.n_batch; ++j) {
-      float4 c = p.col[(size_t)w * p.n_batch + j];
+      float4 c = ld4(p.fin + (size_t)j * p.work_total + w);
       acc = accumulate_sample(acc, v3(c.x, c.y, c.z), p.first_tick + j);
     }
     p.accum[pix] = acc;
