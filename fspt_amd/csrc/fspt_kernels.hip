@@ -412,7 +412,25 @@ FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randB
   float tcy = fma_(w.z, uv2y, fma_(w.y, uv1y, w.x * uv0y));
   V3 texDiffuse, texEmissive, texNormal;
   float metallic, rough;
-  {
+  if (S.atlas_res == 1u) {
+    // flat-colour layers (texture_packer.js:36-42: colours only -> 1x1): the four bilinear taps are the same
+    // texel and lerp(x, x, a) = fma(a, 0, x) = x exactly, so the filter arithmetic is skipped (bit-identical)
+    const uint32_t nl = S.atlas_layers - 1u;
+    auto layer_of = [&](float layer) -> uint32_t {
+      int l = (int)floor_(layer + 0.5f);
+      return l < 0 ? 0u : ((uint32_t)l > nl ? nl : (uint32_t)l);
+    };
+    uint32_t q = S.atlas[layer_of(layDiffuse)];
+    texDiffuse = v3(unorm8(q & 255u), unorm8((q >> 8) & 255u), unorm8((q >> 16) & 255u));
+    q = S.atlas[layer_of(laySpec)];
+    texEmissive = v3(unorm8(q & 255u), unorm8((q >> 8) & 255u), unorm8((q >> 16) & 255u));
+    q = S.atlas[layer_of(layRough)];
+    metallic = unorm8(q & 255u);
+    rough = unorm8((q >> 8) & 255u);
+    q = S.atlas[layer_of(layNormal)];
+    texNormal = v3((unorm8(q & 255u) - 0.5f) * 2.0f, (unorm8((q >> 8) & 255u) - 0.5f) * 2.0f,
+                   (unorm8((q >> 16) & 255u) - 0.0f) * 1.0f);
+  } else {
     Tap4 q = atlas_taps(S, tcx, tcy, layDiffuse);
     texDiffuse = v3(tap_channel(q, 0), tap_channel(q, 1), tap_channel(q, 2));
     q = atlas_taps(S, tcx, tcy, laySpec);
@@ -693,6 +711,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 #ifndef WF_LOGIC_THREADS
 #define WF_LOGIC_THREADS 512
 #endif
+// (software-pipelining the path-state loads was measured 10 % slower: 12 spills - removed)
+// measured: U = 1 / 2 / 4 / 8 -> 0.327 / 0.320 / 0.331 / 0.357 ms per tick (spills grow with U)
+#ifndef WF_LOGIC_U
+#define WF_LOGIC_U 2
+#endif
 
 // Path state is streamed (touched once per round): non-temporal so it does not evict the BVH and
 // shading records from L2.  FSPT_NT=0 builds the plain variant for A/B.
@@ -770,10 +793,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_gen(const WfP p) {
         o = v3(po.x, po.y, po.z);
         d = v3(di.x, di.y, di.z);
       }
+      // thr = 1, colour = 0, flags = PRIMARY are implied in round 1 (k_wf_logic<.., true>): not stored
       st4(p.ray_o + s, make_float4(o.x, o.y, o.z, 0.0f));
       st4(p.ray_d + s, make_float4(d.x, d.y, d.z, 0.0f));
-      st4(p.thr + s, make_float4(1.0f, 1.0f, 1.0f, 0.0f));
-      st4(p.col + s, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(WF_FLAG_PRIMARY)));
       entry = s;
       nsamples++;
     }
@@ -958,10 +980,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 #ifndef WF_LOGIC_WAVES
 #define WF_LOGIC_WAVES 4
 #endif
-template <bool COUNT>
+// FIRST: round 1, where every path is a fresh primary: the queue is the identity (slot = index, validity
+// recomputed from the pixel mapping) and thr / colour / flags are constants, so neither is read - round 1
+// streams the whole batch's path state through HBM and is bandwidth-bound.
+template <bool COUNT, bool FIRST>
 __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(const WfP p) {
   static_assert(WF_LOGIC_THREADS % WAVE == 0, "whole waves");
-  __shared__ uint32_t s_cnt[2][WF_LOGIC_THREADS / WAVE];
+  constexpr int NW = WF_LOGIC_THREADS / WAVE;
+  constexpr int U = WF_LOGIC_U; // paths per thread between two compactions (amortises 2 barriers + 1 atomic)
+  __shared__ uint32_t s_cnt[2][U][NW];
   __shared__ uint32_t s_base[2];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
@@ -974,70 +1001,92 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
   WfCounts *cn = p.counts + p.round;
   Counters cnt = {0, 0, 0, 0, 0, 0};
 
-  for (uint32_t base = blockIdx.x * WF_LOGIC_THREADS; base < n_in; base += gridDim.x * WF_LOGIC_THREADS) {
-    uint32_t i = base + threadIdx.x;
-    uint32_t s = (i < n_in) ? q_in[i] : WF_DEAD;
-    bool survive = false, shadow = false;
-    if (s != WF_DEAD) {
-      float4 ro = ld4(p.ray_o + s), rd = ld4(p.ray_d + s), th = ld4(p.thr + s), co = ld4(p.col + s);
-      float2 h = ld2(p.hit + s);
-      uint32_t flags = __float_as_uint(co.w);
-      Path ps;
-      ps.ro = v3(ro.x, ro.y, ro.z);
-      ps.rd = v3(rd.x, rd.y, rd.z);
-      ps.thr = v3(th.x, th.y, th.z);
-      ps.wy = th.w;
-      ps.color = v3(co.x, co.y, co.z);
-      ps.bounce = (int)(flags & 255u);
-      ps.iters = (int)((flags >> 8) & 255u);
-      ps.primary = (flags & WF_FLAG_PRIMARY) != 0u;
-      ps.hasShadow = (flags & WF_FLAG_SHADOW) != 0u;
-      ps.pix = 0;
-      ps.wx = 0.0f;
-      ps.envDir = v3(0.0f, 0.0f, 0.0f);
-      ps.pend = v3(0.0f, 0.0f, 0.0f);
-      int hitA = -1;
-      if (ps.hasShadow) {
-        float4 sd = ld4(p.shd + s), pe = ld4(p.pend + s);
-        ps.envDir = v3(sd.x, sd.y, sd.z);
-        ps.wx = sd.w;
-        ps.pend = v3(pe.x, pe.y, pe.z);
-        hitA = ldi(p.shadow_hit + s);
-      }
-      const uint32_t j = s % p.n_batch;
-      bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), p.rb_trace[j], p.env_theta,
-                                          p.num_bounces, cnt);
-      if (finished) {
-        // park the sample colour tick-major (fin[j][w]) so that resolve reads coalesced
-        uint32_t w = s / p.n_batch;
-        st4(p.fin + (size_t)j * p.work_total + w, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
-      } else {
-        uint32_t nf = ((uint32_t)ps.bounce & 255u) | (((uint32_t)ps.iters & 255u) << 8) |
-                      (ps.hasShadow ? WF_FLAG_SHADOW : 0u);
-        st4(p.ray_o + s, make_float4(ps.ro.x, ps.ro.y, ps.ro.z, 0.0f));
-        st4(p.ray_d + s, make_float4(ps.rd.x, ps.rd.y, ps.rd.z, 0.0f));
-        st4(p.thr + s, make_float4(ps.thr.x, ps.thr.y, ps.thr.z, ps.wy));
-        st4(p.col + s, make_float4(ps.color.x, ps.color.y, ps.color.z, __uint_as_float(nf)));
-        if (ps.hasShadow) {
-          st4(p.shd + s, make_float4(ps.envDir.x, ps.envDir.y, ps.envDir.z, ps.wx));
-          st4(p.pend + s, make_float4(ps.pend.x, ps.pend.y, ps.pend.z, 0.0f));
+  const uint32_t span = (uint32_t)U * WF_LOGIC_THREADS;
+  for (uint32_t base = blockIdx.x * span; base < n_in; base += gridDim.x * span) {
+    uint32_t slot_u[U];
+    unsigned long long m_surv[U], m_shd[U];
+    bool surv_u[U], shd_u[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = base + (uint32_t)u * WF_LOGIC_THREADS + threadIdx.x;
+      uint32_t s = WF_DEAD;
+      if (i < n_in) {
+        if (FIRST) {
+          uint32_t px, py;
+          s = work_to_pixel(p, i / p.n_batch, px, py) ? i : WF_DEAD;
+        } else {
+          s = q_in[i];
         }
-        survive = true;
-        shadow = ps.hasShadow;
       }
+      bool survive = false, shadow = false;
+      if (s != WF_DEAD) {
+        float4 ro = ld4(p.ray_o + s), rd = ld4(p.ray_d + s);
+        float4 th = make_float4(1.0f, 1.0f, 1.0f, 0.0f), co = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(WF_FLAG_PRIMARY));
+        if (!FIRST) { th = ld4(p.thr + s); co = ld4(p.col + s); }
+        float2 h = ld2(p.hit + s);
+        uint32_t flags = __float_as_uint(co.w);
+        Path ps;
+        ps.ro = v3(ro.x, ro.y, ro.z);
+        ps.rd = v3(rd.x, rd.y, rd.z);
+        ps.thr = v3(th.x, th.y, th.z);
+        ps.wy = th.w;
+        ps.color = v3(co.x, co.y, co.z);
+        ps.bounce = (int)(flags & 255u);
+        ps.iters = (int)((flags >> 8) & 255u);
+        ps.primary = (flags & WF_FLAG_PRIMARY) != 0u;
+        ps.hasShadow = (flags & WF_FLAG_SHADOW) != 0u;
+        ps.pix = 0;
+        ps.wx = 0.0f;
+        ps.envDir = v3(0.0f, 0.0f, 0.0f);
+        ps.pend = v3(0.0f, 0.0f, 0.0f);
+        int hitA = -1;
+        if (ps.hasShadow) {
+          float4 sd = ld4(p.shd + s), pe = ld4(p.pend + s);
+          ps.envDir = v3(sd.x, sd.y, sd.z);
+          ps.wx = sd.w;
+          ps.pend = v3(pe.x, pe.y, pe.z);
+          hitA = ldi(p.shadow_hit + s);
+        }
+        const uint32_t j = s % p.n_batch;
+        bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), p.rb_trace[j], p.env_theta,
+                                            p.num_bounces, cnt);
+        if (finished) {
+          // park the sample colour tick-major (fin[j][w]) so that resolve reads coalesced
+          uint32_t w = s / p.n_batch;
+          st4(p.fin + (size_t)j * p.work_total + w, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
+        } else {
+          uint32_t nf = ((uint32_t)ps.bounce & 255u) | (((uint32_t)ps.iters & 255u) << 8) |
+                        (ps.hasShadow ? WF_FLAG_SHADOW : 0u);
+          st4(p.ray_o + s, make_float4(ps.ro.x, ps.ro.y, ps.ro.z, 0.0f));
+          st4(p.ray_d + s, make_float4(ps.rd.x, ps.rd.y, ps.rd.z, 0.0f));
+          st4(p.thr + s, make_float4(ps.thr.x, ps.thr.y, ps.thr.z, ps.wy));
+          st4(p.col + s, make_float4(ps.color.x, ps.color.y, ps.color.z, __uint_as_float(nf)));
+          if (ps.hasShadow) {
+            st4(p.shd + s, make_float4(ps.envDir.x, ps.envDir.y, ps.envDir.z, ps.wx));
+            st4(p.pend + s, make_float4(ps.pend.x, ps.pend.y, ps.pend.z, 0.0f));
+          }
+          survive = true;
+          shadow = ps.hasShadow;
+        }
+      }
+      slot_u[u] = s;
+      surv_u[u] = survive;
+      shd_u[u] = shadow;
+      m_surv[u] = __ballot(survive);
+      m_shd[u] = __ballot(shadow);
+      if (lane == 0) { s_cnt[0][u][wave] = (uint32_t)__popcll(m_surv[u]); s_cnt[1][u][wave] = (uint32_t)__popcll(m_shd[u]); }
     }
     // block-aggregated append of survivors (q_ext) and their shadow rays (q_shd): ONE 64-bit atomic per
-    // block iteration (n_ext in the low word, n_shd in the high word; neither can overflow 32 bits)
-    unsigned long long m0 = __ballot(survive), m1 = __ballot(shadow);
-    if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); }
+    // U*512 paths (n_ext in the low word, n_shd in the high word; neither can overflow 32 bits)
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t tot0 = 0, tot1 = 0;
-      for (int w2 = 0; w2 < WF_LOGIC_THREADS / WAVE; ++w2) {
-        uint32_t c0 = s_cnt[0][w2], c1 = s_cnt[1][w2];
-        s_cnt[0][w2] = tot0; s_cnt[1][w2] = tot1;
-        tot0 += c0; tot1 += c1;
-      }
+      for (int u = 0; u < U; ++u)
+        for (int w2 = 0; w2 < NW; ++w2) {
+          uint32_t c0 = s_cnt[0][u][w2], c1 = s_cnt[1][u][w2];
+          s_cnt[0][u][w2] = tot0; s_cnt[1][u][w2] = tot1;
+          tot0 += c0; tot1 += c1;
+        }
       unsigned long long old = 0ull;
       if (tot0 | tot1)
         old = atomicAdd(reinterpret_cast<unsigned long long *>(&cn->n_ext), ((unsigned long long)tot1 << 32) | tot0);
@@ -1045,8 +1094,11 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
       s_base[1] = (uint32_t)(old >> 32);
     }
     __syncthreads();
-    if (survive) q_out[s_base[0] + s_cnt[0][wave] + lane_rank(m0)] = s;
-    if (shadow) q_shd_out[s_base[1] + s_cnt[1][wave] + lane_rank(m1)] = s;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (surv_u[u]) q_out[s_base[0] + s_cnt[0][u][wave] + lane_rank(m_surv[u])] = slot_u[u];
+      if (shd_u[u]) q_shd_out[s_base[1] + s_cnt[1][u][wave] + lane_rank(m_shd[u])] = slot_u[u];
+    }
     __syncthreads();
   }
   if (COUNT) {
@@ -1171,8 +1223,14 @@ hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int nu
     else hipLaunchKernelGGL((k_wf_trace<false>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);
   } else if (kernel == WF_K_LOGIC) {
     uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * 4u);
-    if (count) hipLaunchKernelGGL((k_wf_logic<true>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
-    else hipLaunchKernelGGL((k_wf_logic<false>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
+    const bool first = (p.round == 1);
+    if (count) {
+      if (first) hipLaunchKernelGGL((k_wf_logic<true, true>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
+      else hipLaunchKernelGGL((k_wf_logic<true, false>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
+    } else {
+      if (first) hipLaunchKernelGGL((k_wf_logic<false, true>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
+      else hipLaunchKernelGGL((k_wf_logic<false, false>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
+    }
   } else {
     uint32_t grid = min((p.work_total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 16u);
     hipLaunchKernelGGL(k_wf_resolve, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
