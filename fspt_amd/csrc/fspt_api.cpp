@@ -185,26 +185,27 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   }
   // ---- pre-edged triangles, padded by leaf_size "-1" triangles (main.js:150-152) ----
   const uint32_t TP = T + desc->leaf_size;
-  std::vector<float> tris((size_t)TP * 12, 0.0f);
+  std::vector<float> tris((size_t)TP * 9 + 4, 0.0f); // +4: the last 16-byte load of a leaf may run 12 B past it
   for (uint32_t i = 0; i < TP; ++i) {
     float v[9];
     if (i < T) std::memcpy(v, desc->tri + (size_t)i * 9, 36);
     else for (int k = 0; k < 9; ++k) v[k] = -1.0f;
-    float *o = &tris[(size_t)i * 12];
+    float *o = &tris[(size_t)i * 9];
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
     o[3] = v[3] - v[0]; o[4] = v[4] - v[1]; o[5] = v[5] - v[2]; // e1 = v2 - v1 (tracer.fs:301)
     o[6] = v[6] - v[0]; o[7] = v[7] - v[1]; o[8] = v[8] - v[2]; // e2 = v3 - v1 (tracer.fs:302)
   }
-  // ---- shading records ---------------------------------------------------------
+  // ---- 192-byte hit records -----------------------------------------------------
   bool has_dielectric = false;
-  std::vector<float> shade((size_t)T * 40, 0.0f);
+  std::vector<float> shade((size_t)T * 48, 0.0f);
   for (uint32_t i = 0; i < T; ++i) {
-    float *o = &shade[(size_t)i * 40];
-    std::memcpy(o, desc->norm + (size_t)i * 27, 27 * 4);
-    std::memcpy(o + 27, desc->uv + (size_t)i * 6, 6 * 4);
+    float *o = &shade[(size_t)i * 48];
+    std::memcpy(o, &tris[(size_t)i * 9], 36);
+    std::memcpy(o + 9, desc->norm + (size_t)i * 27, 27 * 4);
+    std::memcpy(o + 36, desc->uv + (size_t)i * 6, 6 * 4);
     const float *m = desc->mat + (size_t)i * 12;
-    o[33] = m[0]; o[34] = m[1]; o[35] = m[2]; o[36] = m[3]; // diffuse, emissive("specular"), normal, mr layers
-    o[37] = m[9]; o[38] = m[10];                             // ior, dielectric
+    o[42] = m[0]; o[43] = m[1]; o[44] = m[2]; o[45] = m[3]; // diffuse, emissive("specular"), normal, mr layers
+    o[46] = m[9]; o[47] = m[10];                             // ior, dielectric
     if (m[10] >= 0.0f) has_dielectric = true;
   }
 
@@ -234,8 +235,8 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     return FSPT_E_HIP;
   }
   s->d.nodes = (const float4 *)s->nodes;
-  s->d.tris = (const float4 *)s->tris;
-  s->d.shade = (const float4 *)s->shade;
+  s->d.tris = (const float *)s->tris;
+  s->d.hitrec = (const float4 *)s->shade;
   s->d.atlas = (const uint32_t *)s->atlas;
   s->d.env = (const uint32_t *)s->env;
   s->d.bins = (const uint4 *)s->bins;

@@ -18,22 +18,24 @@ constexpr float INV_PI_F = 1.0f / M_PI_F;
 constexpr int MAX_PATH_ITERS = 64;       // cap on tracer.fs:488's unbounded i--
 
 constexpr int NODE_F4 = 4;   // 64-byte two-child node = 4 x float4
-constexpr int TRI_F4 = 3;    // 48-byte pre-edged triangle = 3 x float4
-constexpr int SHADE_F4 = 10; // 160-byte shading record = 10 x float4
+constexpr int TRI_FLOATS = 9;  // 36-byte packed pre-edged triangle (traversal)
+constexpr int HITREC_F4 = 12; // 192-byte hit record (shading) = 12 x float4 = exactly 3 cache lines
 
 // Node (64 B):   f4[0] = lmin.xyz lmax.x   f4[1] = lmax.yz rmin.xy
 //                f4[2] = rmin.z rmax.xyz   f4[3] = (int) left_ref right_ref 0 0
 //   (tracer.fs:374-378 fetches the header of `current` and then, dependently,
 //    the boxes of both children: 3 round trips; here one.)
-// Tri (48 B):    f4[0] = v1.xyz e1.x  f4[1] = e1.yz e2.xy  f4[2] = e2.z 0 0 0
-//   e1 = v2 - v1, e2 = v3 - v1 in binary32 = tracer.fs:301-302 precomputed.
-// Shade (160 B): floats 0..26 normTex record (n,t,bt per vertex, main.js:383-385)
-//                27..32 uv (main.js:386), 33..36 layers diffuse/emissive/normal/mr
-//                (main.js:377-379), 37 ior, 38 dielectric, 39 pad.
+// Tri (36 B, packed): v1.xyz e1.xyz e2.xyz; e1 = v2 - v1, e2 = v3 - v1 in binary32 =
+//   tracer.fs:301-302 precomputed.  A leaf visit reads LEAF_SIZE consecutive records
+//   (tracer.fs:355-364): 4 x 36 B = 144 contiguous bytes = 9 dword-aligned 16-byte loads.
+// HitRec (192 B, 64-byte aligned = exactly 3 cache lines per shaded hit):
+//   floats 0..8 the same v1,e1,e2; 9..35 normTex record (n,t,bt per vertex,
+//   main.js:383-385); 36..41 uv (main.js:386); 42..45 layers diffuse/emissive/normal/mr
+//   (main.js:377-379); 46 ior; 47 dielectric.
 struct DScene {
   const float4 *nodes;
-  const float4 *tris;
-  const float4 *shade;
+  const float *tris;    // packed 9-float triangles (+ LEAF_SIZE padding records)
+  const float4 *hitrec; // 12 x float4 per triangle
   const uint32_t *atlas; // RGBA8 texels, layer-major
   const uint32_t *env;   // RGBE texels (NULL = black default environment)
   const uint4 *bins;

@@ -52,6 +52,35 @@ FM_DEV float ray_tri(V3 o, V3 d, V3 v1, V3 e1, V3 e2) {
   return miss ? MAX_T : dist;
 }
 
+// ---------------------------------------------------------------------------
+// processLeaf (tracer.fs:355-364): always LEAF_SIZE triangles from `ts`, strict `<` update.
+// LEAF_SIZE = 4: the 4 packed 36-byte records are 144 contiguous bytes = 9 dword-aligned
+// 16-byte loads (gfx950 global loads only need dword alignment).
+// ---------------------------------------------------------------------------
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+FM_DEV void process_leaf(const float *__restrict__ tris, uint32_t leaf_size, int ts, V3 o, V3 d, float &t, int &hit) {
+  const float *tp = tris + (size_t)ts * TRI_FLOATS;
+  if (leaf_size == 4) {
+    const f4u *q = reinterpret_cast<const f4u *>(tp);
+    f4u r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5], r6 = q[6], r7 = q[7], r8 = q[8];
+    float res;
+    res = ray_tri(o, d, v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y), v3(r1.z, r1.w, r2.x));
+    if (res < t) { t = res; hit = ts; }
+    res = ray_tri(o, d, v3(r2.y, r2.z, r2.w), v3(r3.x, r3.y, r3.z), v3(r3.w, r4.x, r4.y));
+    if (res < t) { t = res; hit = ts + 1; }
+    res = ray_tri(o, d, v3(r4.z, r4.w, r5.x), v3(r5.y, r5.z, r5.w), v3(r6.x, r6.y, r6.z));
+    if (res < t) { t = res; hit = ts + 2; }
+    res = ray_tri(o, d, v3(r6.w, r7.x, r7.y), v3(r7.z, r7.w, r8.x), v3(r8.y, r8.z, r8.w));
+    if (res < t) { t = res; hit = ts + 3; }
+  } else {
+    for (uint32_t i = 0; i < leaf_size; ++i) {
+      const float *a = tp + (size_t)i * TRI_FLOATS;
+      float res = ray_tri(o, d, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]));
+      if (res < t) { t = res; hit = ts + (int)i; }
+    }
+  }
+}
+
 struct Counters {
   uint32_t samples, rays, steps, leaves, shades, envs;
 };
@@ -75,7 +104,7 @@ FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 d
   hitA = -1;
   if (COUNT) cnt.rays++;
   const float4 *__restrict__ nodes = S.nodes;
-  const float4 *__restrict__ tris = S.tris;
+  const float *__restrict__ tris = S.tris;
   const uint32_t leaf_size = S.leaf_size;
   while (true) {
     // ---- interior nodes ----------------------------------------------------
@@ -123,23 +152,7 @@ FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 d
     {
       if (COUNT) { cnt.steps++; cnt.leaves++; }
       int ts = ~cur;
-      const float4 *tp = tris + (size_t)ts * TRI_F4;
-      if (leaf_size == 4) {
-        float4 a[4], b[4], c[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = tp[i * 3]; b[i] = tp[i * 3 + 1]; c[i] = tp[i * 3 + 2]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float res = ray_tri(o, d, v3(a[i].x, a[i].y, a[i].z), v3(a[i].w, b[i].x, b[i].y), v3(b[i].z, b[i].w, c[i].x));
-          if (res < t) { t = res; hit = ts + i; }
-        }
-      } else {
-        for (uint32_t i = 0; i < leaf_size; ++i) {
-          float4 a = tp[i * 3], b = tp[i * 3 + 1], c = tp[i * 3 + 2];
-          float res = ray_tri(o, d, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x));
-          if (res < t) { t = res; hit = ts + (int)i; }
-        }
-      }
+      process_leaf(tris, leaf_size, ts, o, d, t, hit);
       if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
       else cur = REF_SENTINEL;
     }
@@ -382,18 +395,16 @@ struct Path {
 template <bool COUNT>
 FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randBase, float envTheta, Counters &cnt) {
   if (COUNT) cnt.shades++;
-  const float4 *tp = S.tris + (size_t)ti * TRI_F4;
-  float4 ta = tp[0], tb = tp[1], tc4 = tp[2];
-  V3 v1 = v3(ta.x, ta.y, ta.z), e1 = v3(ta.w, tb.x, tb.y), e2 = v3(tb.z, tb.w, tc4.x);
-  const float4 *sp = S.shade + (size_t)ti * SHADE_F4;
-  float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6], s7 = sp[7], s8 = sp[8],
-         s9 = sp[9];
-  V3 n1 = v3(s0.x, s0.y, s0.z), t1 = v3(s0.w, s1.x, s1.y), b1 = v3(s1.z, s1.w, s2.x);
-  V3 n2 = v3(s2.y, s2.z, s2.w), t2 = v3(s3.x, s3.y, s3.z), b2 = v3(s3.w, s4.x, s4.y);
-  V3 n3 = v3(s4.z, s4.w, s5.x), t3 = v3(s5.y, s5.z, s5.w), b3 = v3(s6.x, s6.y, s6.z);
-  float uv0x = s6.w, uv0y = s7.x, uv1x = s7.y, uv1y = s7.z, uv2x = s7.w, uv2y = s8.x;
-  float layDiffuse = s8.y, laySpec = s8.z, layNormal = s8.w, layRough = s9.x;
-  float ior = s9.y, dielectric = s9.z;
+  const float4 *hp = S.hitrec + (size_t)ti * HITREC_F4; // 192 B = 3 whole cache lines
+  const float4 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4], h5 = hp[5], h6 = hp[6], h7 = hp[7], h8 = hp[8],
+               h9 = hp[9], h10 = hp[10], h11 = hp[11];
+  V3 v1 = v3(h0.x, h0.y, h0.z), e1 = v3(h0.w, h1.x, h1.y), e2 = v3(h1.z, h1.w, h2.x);
+  V3 n1 = v3(h2.y, h2.z, h2.w), t1 = v3(h3.x, h3.y, h3.z), b1 = v3(h3.w, h4.x, h4.y);
+  V3 n2 = v3(h4.z, h4.w, h5.x), t2 = v3(h5.y, h5.z, h5.w), b2 = v3(h6.x, h6.y, h6.z);
+  V3 n3 = v3(h6.w, h7.x, h7.y), t3 = v3(h7.z, h7.w, h8.x), b3 = v3(h8.y, h8.z, h8.w);
+  float uv0x = h9.x, uv0y = h9.y, uv1x = h9.z, uv1y = h9.w, uv2x = h10.x, uv2y = h10.y;
+  float layDiffuse = h10.z, laySpec = h10.w, layNormal = h11.x, layRough = h11.y;
+  float ior = h11.z, dielectric = h11.w;
 
   V3 rd = ps.rd;
   V3 origin = vfma(rd, tHit, ps.ro);
@@ -825,7 +836,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   const DScene &S = p.scene;
   int *stack = lds_stack + (size_t)wave * S.stack_n * WAVE + lane;
   const float4 *__restrict__ nodes = S.nodes;
-  const float4 *__restrict__ tris = S.tris;
+  const float *__restrict__ tris = S.tris;
   const uint32_t leaf_size = S.leaf_size;
   const uint32_t *__restrict__ q_ext = p.q_ext[p.round & 1];
   const uint32_t *__restrict__ q_shd = p.q_shd[p.round & 1];
@@ -937,23 +948,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     if (!idle && cur < 0 && cur != REF_SENTINEL) {
       if (COUNT) { c_steps++; c_leaves++; }
       int ts = ~cur;
-      const float4 *tp = tris + (size_t)ts * TRI_F4;
-      if (leaf_size == 4) {
-        float4 a[4], b[4], c[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = tp[i * 3]; b[i] = tp[i * 3 + 1]; c[i] = tp[i * 3 + 2]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float res = ray_tri(o, d, v3(a[i].x, a[i].y, a[i].z), v3(a[i].w, b[i].x, b[i].y), v3(b[i].z, b[i].w, c[i].x));
-          if (res < t) { t = res; hit = ts + i; }
-        }
-      } else {
-        for (uint32_t i = 0; i < leaf_size; ++i) {
-          float4 a = tp[i * 3], b = tp[i * 3 + 1], c = tp[i * 3 + 2];
-          float res = ray_tri(o, d, v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x));
-          if (res < t) { t = res; hit = ts + (int)i; }
-        }
-      }
+      process_leaf(tris, leaf_size, ts, o, d, t, hit);
       if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
       else cur = REF_SENTINEL;
     }
