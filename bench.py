@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--aperture", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel"])
-    ap.add_argument("--batch", type=int, default=32, help="ticks per wavefront batch")
+    ap.add_argument("--batch", type=int, default=64, help="ticks per wavefront batch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,7 +173,7 @@ def main():
         # profiler on itself): only reported for the exact workload those passes measured
         tpath = os.path.join(ROOT, "profiles", "r01", "final_hbm_traffic.json")
         key = {76: "c2_70k", 289: "c3_1M"}.get(args.mesh_n)
-        if (stages is not None and key and os.path.exists(tpath) and n_gpus == 1 and args.batch == 32
+        if (stages is not None and key and os.path.exists(tpath) and n_gpus == 1
                 and (args.width, args.height, args.bounces) == (1920, 1080, 8)):
             tj = json.load(open(tpath)).get(key, {}).get("k_wf_trace<false>")
             if tj:

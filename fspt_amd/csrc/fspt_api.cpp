@@ -59,7 +59,7 @@ struct fspt_target {
   uint32_t last_launches = 0;
   // wavefront pipeline
   int pipeline = 1;           // 0 = megakernel, 1 = wavefront
-  uint32_t batch_ticks = 32;  // ticks traced together by the wavefront pipeline
+  uint32_t batch_ticks = 64;  // ticks traced together by the wavefront pipeline (18.8 GB of path state at 1080p)
   void *wf_mem[13] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   fspt::WfCounts *wf_counts = nullptr;
   uint32_t wf_slots = 0;      // allocated path slots

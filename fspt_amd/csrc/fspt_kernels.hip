@@ -716,6 +716,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 #ifndef WF_INTERIOR_MIN
 #define WF_INTERIOR_MIN 16
 #endif
+#ifndef WF_SHADOW_ANYHIT
+#define WF_SHADOW_ANYHIT 1
+#endif
 #ifndef WF_REFILL_MIN
 #define WF_REFILL_MIN 1
 #endif
@@ -951,6 +954,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
       process_leaf(tris, leaf_size, ts, o, d, t, hit);
       if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
       else cur = REF_SENTINEL;
+      // NEE shadow rays: only `shadow.index == -1` is consumed (tracer.fs:502), so the first hit settles
+      // the ray.  The counting variant keeps the reference's full closest-hit traversal, so the work
+      // counters stay equal to the oracle's (the algorithmic bytes of the reference algorithm).
+      if (WF_SHADOW_ANYHIT && !COUNT && is_shadow && hit != -1) cur = REF_SENTINEL;
     }
     // ---- finished rays: write the result, lane becomes idle ----
     if (!idle && cur == REF_SENTINEL) {
