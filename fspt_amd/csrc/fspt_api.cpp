@@ -597,6 +597,20 @@ int fspt_read_radiance(fspt_target *t, float *out) {
   return FSPT_OK;
 }
 
+int fspt_draw(fspt_target *t, float exposure, float saturation, int denoise, float max_sigma, uint8_t *out_rgba8) {
+  if (!t || !out_rgba8) { fspt_set_error("fspt_draw: NULL argument"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  size_t n = (size_t)t->W * t->H;
+  uint32_t *d = nullptr;
+  HIP_TRY(hipMalloc((void **)&d, n * 4));
+  hipError_t e = fspt::launch_draw(t->accum, t->W, t->H, exposure, saturation, denoise, max_sigma, d, t->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_rgba8, d, n * 4, hipMemcpyDeviceToHost, t->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  hipFree(d);
+  if (e != hipSuccess) { fspt_set_error("fspt_draw: %s", hipGetErrorString(e)); return FSPT_E_HIP; }
+  return FSPT_OK;
+}
+
 int fspt_last_kernel_ms(fspt_target *t, float *ms, uint32_t *launches) {
   if (!t || !ms) { fspt_set_error("fspt_last_kernel_ms: NULL argument"); return FSPT_E_INVALID; }
   if (!t->timed) { fspt_set_error("fspt_last_kernel_ms: nothing traced yet"); return FSPT_E_STATE; }

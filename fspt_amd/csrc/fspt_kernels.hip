@@ -1141,6 +1141,60 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_camera(uint32_t W, uint32_t H
   dir[i] = make_float4(d.x, d.y, d.z, 1.0f);
 }
 
+// draw.fs (1-93): exposure -> ACES fit -> saturation -> gamma (+ optional 5x5 firefly filter) -> RGBA8
+FM_DEV float draw_luma(V3 c) { return dot(c, v3(0.2126f, 0.7152f, 0.0722f)); }
+FM_DEV V3 draw_fetch(const float4 *acc, int W, int H, int x, int y) {
+  if (x < 0 || y < 0 || x >= W || y >= H) return v3(0.0f, 0.0f, 0.0f);
+  float4 p = acc[(size_t)y * W + x];
+  return v3(p.x, p.y, p.z);
+}
+FM_DEV float rrt_odt(float v) {
+  float a = fma_(v, v + 0.0245786f, -0.000090537f);
+  float b = fma_(v, fma_(0.983729f, v, 0.4329510f), 0.238081f);
+  return a / b;
+}
+__global__ __launch_bounds__(BLOCK_THREADS) void k_draw(const float4 *acc, uint32_t W, uint32_t H, float exposure,
+                                                       float saturation, int denoise, float maxSigma, uint32_t *out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W * H) return;
+  int x = (int)(i % W), y = (int)(i / W);
+  V3 c;
+  if (denoise) {
+    float sum = 0.0f, sq = 0.0f, middleLuma = 0.0f;
+    V3 middle = v3(0.0f, 0.0f, 0.0f);
+    for (int a = 0; a < 5; ++a)
+      for (int b = 0; b < 5; ++b) {
+        int ox = a - 2, oy = b - 2;
+        V3 col = draw_fetch(acc, (int)W, (int)H, x + ox, y + oy);
+        float l = draw_luma(col);
+        if (ox == 0 && oy == 0) { middle = col; middleLuma = l; continue; }
+        sum += l;
+        sq = fma_(l, l, sq);
+      }
+    float mean = sum / 24.0f;
+    float variance = fma_(-mean, mean, sq / 24.0f);
+    float sigma = sqrt_(variance);
+    if (abs_(middleLuma - mean) > maxSigma * sigma) middle = middle * (mean / middleLuma);
+    c = middle * exposure;
+  } else {
+    c = draw_fetch(acc, (int)W, (int)H, x, y) * exposure;
+  }
+  V3 a = v3(dot(c, v3(0.59719f, 0.35458f, 0.04823f)), dot(c, v3(0.07600f, 0.90834f, 0.01566f)),
+            dot(c, v3(0.02840f, 0.13383f, 0.83777f)));
+  a = v3(rrt_odt(a.x), rrt_odt(a.y), rrt_odt(a.z));
+  V3 m = v3(dot(a, v3(1.60475f, -0.53108f, -0.07367f)), dot(a, v3(-0.10208f, 1.10813f, -0.00605f)),
+            dot(a, v3(-0.00327f, -0.07276f, 1.07602f)));
+  m = v3(clamp_(m.x, 0.0f, 1.0f), clamp_(m.y, 0.0f, 1.0f), clamp_(m.z, 0.0f, 1.0f));
+  float l = draw_luma(m);
+  float os = 1.0f - saturation;
+  m = v3(fma_(m.x, saturation, l * os), fma_(m.y, saturation, l * os), fma_(m.z, saturation, l * os));
+  float g0 = pow_(m.x, 0.454545f), g1 = pow_(m.y, 0.454545f), g2 = pow_(m.z, 0.454545f);
+  uint32_t r8 = (uint32_t)floor_(fma_(clamp_(g0, 0.0f, 1.0f), 255.0f, 0.5f));
+  uint32_t g8 = (uint32_t)floor_(fma_(clamp_(g1, 0.0f, 1.0f), 255.0f, 0.5f));
+  uint32_t b8 = (uint32_t)floor_(fma_(clamp_(g2, 0.0f, 1.0f), 255.0f, 0.5f));
+  out[i] = r8 | (g8 << 8) | (b8 << 16) | 0xFF000000u;
+}
+
 // intersectScene as a stand-alone pass
 __global__ __launch_bounds__(BLOCK_THREADS) void k_intersect(const IntersectP p) {
   extern __shared__ int lds_stack[];
@@ -1175,6 +1229,8 @@ __global__ void k_math(int op, const float *a, const float *b, uint32_t n, float
     case 6: r = sqrt_(x); break;
     case 7: { float sd = x; r = rnd(sd); break; }
     case 8: r = fract_(x); break;
+    case 9: r = log2_(x); break;
+    case 10: r = pow_(x, y); break;
     default: r = 0.0f;
   }
   out[i] = r;
@@ -1245,6 +1301,14 @@ hipError_t launch_camera(uint32_t W, uint32_t H, const CameraP &cam, float rand_
   uint32_t n = W * H;
   hipLaunchKernelGGL(k_camera, dim3((n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS), 0, stream, W, H, cam,
                      rand_base, pos, dir);
+  return hipGetLastError();
+}
+
+hipError_t launch_draw(const float4 *acc, uint32_t W, uint32_t H, float exposure, float saturation, int denoise,
+                       float max_sigma, uint32_t *out, hipStream_t stream) {
+  uint32_t n = W * H;
+  hipLaunchKernelGGL(k_draw, dim3((n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS), 0, stream, acc, W, H,
+                     exposure, saturation, denoise, max_sigma, out);
   return hipGetLastError();
 }
 

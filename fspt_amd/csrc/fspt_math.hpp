@@ -141,6 +141,38 @@ FM_DEV float exp2_(float x) {
   return (p * s1) * s2;
 }
 
+// ---- log2 (Cephes log2f), pow(x,y) = exp2(y*log2(x)) (draw.fs:91 only) -----------
+FM_DEV float log2_(float x) {
+  if (!(x > 0.0f)) return (x == 0.0f) ? -__builtin_inff() : __builtin_nanf("");
+  uint32_t b = f2bits(x);
+  int e = 0;
+  if ((b >> 23) == 0u) { x = x * 8388608.0f; b = f2bits(x); e = -23; }
+  e += (int)(b >> 23) - 126;
+  float m = bits2f((b & 0x007fffffu) | 0x3f000000u);
+  if (m < 0.70710678118654752440f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+  float z = m * m;
+  float p = fma_(7.0376836292e-2f, m, -1.1514610310e-1f);
+  p = fma_(p, m, 1.1676998740e-1f);
+  p = fma_(p, m, -1.2420140846e-1f);
+  p = fma_(p, m, 1.4249322787e-1f);
+  p = fma_(p, m, -1.6668057665e-1f);
+  p = fma_(p, m, 2.0000714765e-1f);
+  p = fma_(p, m, -2.4999993993e-1f);
+  p = fma_(p, m, 3.3333331174e-1f);
+  float y = (p * m) * z;
+  y = fma_(-0.5f, z, y);
+  const float LOG2EA = 0.44269504088896340735992f;
+  float r = y * LOG2EA;
+  r = fma_(m, LOG2EA, r);
+  r = r + y;
+  r = r + m;
+  return r + (float)e;
+}
+FM_DEV float pow_(float x, float y) {
+  if (x == 0.0f) return 0.0f;
+  return exp2_(y * log2_(x));
+}
+
 // ---- vec3 helpers (explicit fma placement is part of the spec) ------------------
 FM_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 FM_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }

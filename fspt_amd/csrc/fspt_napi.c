@@ -15,6 +15,7 @@
  *   render(target, {P,I,fovScale,lens,envTheta,numBounces}, firstTick, nTicks, seed)
  *   clear(target) / sync(target)                                     (clear, main.js:826-836)
  *   readRadiance(target, Float32Array(W*H*4))                        (what draw.fs:87 reads)
+ *   draw(target, exposure, saturation, denoise, maxSigma, Uint8Array(W*H*4))   (drawQuad, main.js:809-824)
  *   setShard(target, shard, nShards, tile) / setPipeline(target, pipeline, batch)
  *   enableCounters(target, on) / counters(target) -> object
  *   buildScene(props[], leafSize) -> {bvh,tri,mat,norm,uv,depth}     (native obj_loader.js + bvh.js)
@@ -250,6 +251,16 @@ static napi_value ReadRadiance(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_read_radiance((fspt_target *)h, (float *)p));
   return a[1];
 }
+static napi_value Draw(napi_env env, napi_callback_info info) {
+  /* draw(target, exposure, saturation, denoise, maxSigma, Uint8Array(W*H*4)) : drawQuad (main.js:809-824) */
+  napi_value a[6]; void *h, *p; size_t n; double ex, sat, sig; bool den;
+  if (get_args(env, info, 6, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_f64(env, a[1], &ex) || get_f64(env, a[2], &sat)) return NULL;
+  NAPI_OK(napi_get_value_bool(env, a[3], &den));
+  if (get_f64(env, a[4], &sig) || typed(env, a[5], napi_uint8_array, 0, &p, &n)) return NULL;
+  FSPT_OK_OR_THROW(fspt_draw((fspt_target *)h, (float)ex, (float)sat, den ? 1 : 0, (float)sig, (uint8_t *)p));
+  return a[5];
+}
 static napi_value SetShard(napi_env env, napi_callback_info info) {
   napi_value a[4]; void *h; uint32_t s, n, tile;
   if (get_args(env, info, 4, a) || unwrap(env, a[0], &h)) return NULL;
@@ -416,7 +427,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   struct { const char *name; napi_callback fn; } fns[] = {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"render", Render}, {"clear", Clear},
-      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"setShard", SetShard}, {"setPipeline", SetPipeline},
+      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setPipeline", SetPipeline},
       {"enableCounters", EnableCounters}, {"counters", GetCounters}, {"buildScene", BuildScene}, {"envBins", EnvBins},
       {"randBaseNext", RandBaseNext}, {"deviceCount", DeviceCount}, {"abiVersion", AbiVersion}};
   for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {

@@ -170,6 +170,12 @@ int fspt_sync(fspt_target *target);
  * Blocking (syncs the stream first). */
 int fspt_read_radiance(fspt_target *target, float *out);
 
+/* drawQuad (main.js:809-824) -> draw.fs:82-93: exposure, ACES fit, saturation, gamma 1/2.2 and the
+ * optional 5x5 firefly filter (draw.fs:52-80, max_sigma = the `sigma` slider) on the current
+ * accumulator; writes what the canvas would hold: RGBA8, W*H*4 bytes, row 0 = bottom.  Blocking. */
+int fspt_draw(fspt_target *target, float exposure, float saturation, int denoise, float max_sigma,
+              uint8_t *out_rgba8);
+
 /* ------------------------------------------------------------------------
  * intersectScene (tracer.fs:366-404) as a stand-alone entry: n rays
  * (origin xyz, dir xyz: 6 floats each) -> closest hit t and triangle index
@@ -200,7 +206,7 @@ int fspt_counters_reset(fspt_target *target);
 enum {
   FSPT_MATH_SIN = 0, FSPT_MATH_COS = 1, FSPT_MATH_ATAN2 = 2, FSPT_MATH_ASIN = 3,
   FSPT_MATH_EXP2 = 4, FSPT_MATH_DIV = 5, FSPT_MATH_SQRT = 6, FSPT_MATH_RND = 7,
-  FSPT_MATH_FRACT = 8
+  FSPT_MATH_FRACT = 8, FSPT_MATH_LOG2 = 9, FSPT_MATH_POW = 10
 };
 int fspt_math_eval(int device, int op, const float *a, const float *b, uint32_t n,
                    float *out);

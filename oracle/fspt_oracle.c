@@ -669,6 +669,8 @@ void oracle_math_eval(int op, const float *a, const float *b, uint32_t n, float 
       case 6: out[i] = sqrtf(x); break;
       case 7: { float sd = x; out[i] = rnd(&sd); break; }
       case 8: out[i] = om_fract(x); break;
+      case 9: out[i] = om_log2(x); break;
+      case 10: out[i] = om_pow(x, y); break;
       default: out[i] = 0.0f;
     }
   }
@@ -716,4 +718,62 @@ void oracle_brdf_probe(const oracle_scene *s, int which, const float *in, uint32
       o[0] = r.x; o[1] = r.y; o[2] = r.z;
     }
   }
+}
+
+/* ---- draw.fs (1-93): exposure -> ACES fit -> saturation -> gamma, optional 5x5 firefly filter ----
+ * in: RGBA32F accumulator (W*H*4), out: RGBA8 (W*H*4) as the canvas would hold it
+ * (byte = floor(clamp(c,0,1)*255 + 0.5)).  Texel fetches outside the buffer return 0
+ * (robust-access texelFetch).  scale (main.js resScale) is 1. */
+static inline float draw_luma(vec3 c) { return v_dot(c, v3(0.2126f, 0.7152f, 0.0722f)); }
+static inline vec3 draw_fetch(const float *acc, int W, int H, int x, int y) {
+  if (x < 0 || y < 0 || x >= W || y >= H) return v3(0.0f, 0.0f, 0.0f);
+  const float *p = acc + ((size_t)y * W + x) * 4;
+  return v3(p[0], p[1], p[2]);
+}
+static inline float rrt_odt(float v) { /* draw.fs:32-37 */
+  float a = om_fma(v, v + 0.0245786f, -0.000090537f);
+  float b = om_fma(v, om_fma(0.983729f, v, 0.4329510f), 0.238081f);
+  return a / b;
+}
+void oracle_draw(const float *acc, uint32_t W, uint32_t H, float exposure, float saturation, int denoise,
+                 float maxSigma, uint8_t *out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t y = 0; y < (int64_t)H; ++y)
+    for (uint32_t x = 0; x < W; ++x) {
+      vec3 c;
+      if (denoise) { /* filterFireflies, draw.fs:52-80 */
+        float sum = 0.0f, sq = 0.0f, middleLuma = 0.0f;
+        vec3 middle = v3(0.0f, 0.0f, 0.0f);
+        for (int i = 0; i < 5; ++i)
+          for (int j = 0; j < 5; ++j) {
+            int ox = i - 2, oy = j - 2;
+            vec3 col = draw_fetch(acc, (int)W, (int)H, (int)x + ox, (int)y + oy);
+            float l = draw_luma(col);
+            if (ox == 0 && oy == 0) { middle = col; middleLuma = l; continue; }
+            sum += l;
+            sq = om_fma(l, l, sq);
+          }
+        float mean = sum / 24.0f;
+        float variance = om_fma(-mean, mean, sq / 24.0f);
+        float sigma = sqrtf(variance);
+        if (om_abs(middleLuma - mean) > maxSigma * sigma) middle = v_scale(middle, mean / middleLuma);
+        c = v_scale(middle, exposure);
+      } else {
+        c = v_scale(draw_fetch(acc, (int)W, (int)H, (int)x, (int)y), exposure);
+      }
+      /* ACESFitted (draw.fs:39-50): row vector times the column-major constant matrices */
+      vec3 a = v3(v_dot(c, v3(0.59719f, 0.35458f, 0.04823f)), v_dot(c, v3(0.07600f, 0.90834f, 0.01566f)),
+                  v_dot(c, v3(0.02840f, 0.13383f, 0.83777f)));
+      a = v3(rrt_odt(a.x), rrt_odt(a.y), rrt_odt(a.z));
+      vec3 m = v3(v_dot(a, v3(1.60475f, -0.53108f, -0.07367f)), v_dot(a, v3(-0.10208f, 1.10813f, -0.00605f)),
+                  v_dot(a, v3(-0.00327f, -0.07276f, 1.07602f)));
+      m = v3(om_clamp(m.x, 0.0f, 1.0f), om_clamp(m.y, 0.0f, 1.0f), om_clamp(m.z, 0.0f, 1.0f));
+      float l = draw_luma(m);
+      float os = 1.0f - saturation;
+      m = v3(om_fma(m.x, saturation, l * os), om_fma(m.y, saturation, l * os), om_fma(m.z, saturation, l * os));
+      float g[3] = {om_pow(m.x, 0.454545f), om_pow(m.y, 0.454545f), om_pow(m.z, 0.454545f)};
+      uint8_t *o = out + ((size_t)y * W + x) * 4;
+      for (int k = 0; k < 3; ++k) o[k] = (uint8_t)om_floor(om_fma(om_clamp(g[k], 0.0f, 1.0f), 255.0f, 0.5f));
+      o[3] = 255;
+    }
 }

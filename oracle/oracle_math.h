@@ -139,4 +139,36 @@ static inline float om_exp2(float x) {
   return (p * s1) * s2;
 }
 
+/* ---- log2 (Cephes log2f: frexp + degree-9 minimax), pow(x,y) = exp2(y*log2(x)) ---- */
+static inline float om_log2(float x) {
+  if (!(x > 0.0f)) return (x == 0.0f) ? -INFINITY : NAN;
+  uint32_t b = om_f2bits(x);
+  int e = 0;
+  if ((b >> 23) == 0u) { x = x * 8388608.0f; b = om_f2bits(x); e = -23; } /* denormal */
+  e += (int)(b >> 23) - 126;
+  float m = om_bits2f((b & 0x007fffffu) | 0x3f000000u); /* [0.5, 1) */
+  if (m < 0.70710678118654752440f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+  float z = m * m;
+  float p = om_fma(7.0376836292e-2f, m, -1.1514610310e-1f);
+  p = om_fma(p, m, 1.1676998740e-1f);
+  p = om_fma(p, m, -1.2420140846e-1f);
+  p = om_fma(p, m, 1.4249322787e-1f);
+  p = om_fma(p, m, -1.6668057665e-1f);
+  p = om_fma(p, m, 2.0000714765e-1f);
+  p = om_fma(p, m, -2.4999993993e-1f);
+  p = om_fma(p, m, 3.3333331174e-1f);
+  float y = (p * m) * z;
+  y = om_fma(-0.5f, z, y);
+  const float LOG2EA = 0.44269504088896340735992f; /* log2(e) - 1 */
+  float r = y * LOG2EA;
+  r = om_fma(m, LOG2EA, r);
+  r = r + y;
+  r = r + m;
+  return r + (float)e;
+}
+static inline float om_pow(float x, float y) {
+  if (x == 0.0f) return 0.0f; /* only y > 0 is used (draw.fs:91) */
+  return om_exp2(y * om_log2(x));
+}
+
 #endif

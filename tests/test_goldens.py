@@ -183,3 +183,21 @@ def test_d0_env_bins_odd_image():
     z = np.load(os.path.join(GOLD, "js_env_bins_odd.npz"))
     assert np.array_equal(S.env_bins(z["env"], int(z["env_w"]), int(z["env_h"])), z["bins"])
     assert z["bins"].size // 4 > 500  # the NaN path of biSplit really was exercised
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+def test_draw_fs_matches_glsl(i):
+    """draw.fs (tonemap; variants 2,3 with the 5x5 firefly filter) run on SwiftShader vs oracle_draw.
+    pow() precision differs by at most one 8-bit step.  Border pixels of the filtered variants are
+    excluded: out-of-range texelFetch is undefined in GLES 3.0 (SwiftShader clamps) while WebGL 2 - the
+    reference's platform - returns zero, which is what the oracle and the HIP kernel implement."""
+    z = np.load(os.path.join(GOLD, "glsl_draw.npz"))
+    e, s, d, g = [float(v) for v in z[f"params{i}"]]
+    o = O.draw(z["hdr"], e, s, bool(d), g).astype(int)
+    want = z[f"rgba{i}"].astype(int)
+    if d:
+        o, want = o[2:-2, 2:-2], want[2:-2, 2:-2]
+    diff = np.abs(o - want)
+    assert diff.max() <= 1
+    assert (diff == 0).mean() >= 0.99
+    assert (o[..., 3] == 255).all()

@@ -188,3 +188,29 @@ def test_stage_timing(small_scene, camera):
     st = pt.last_stage_ms()
     assert st["gen"][1] == 2 and st["resolve"][1] == 2 and st["trace"][1] == 2 * 5 and st["logic"][1] == 2 * 5
     assert all(v[0] > 0 for v in st.values())
+
+
+@pytest.mark.parametrize("params", [(1.0, 1.0, False, 3.0), (2.5, 0.6, False, 3.0), (1.0, 1.0, True, 3.0),
+                                    (0.7, 1.3, True, 1.5)])
+def test_draw_bitwise(small_scene, camera, params):
+    """fspt_draw (draw.fs as a HIP kernel) == oracle_draw byte for byte, on a real render with fireflies."""
+    W, H = 96, 64
+    pt = make_pt(small_scene, W, H, camera, 4)
+    pt.seed(8)
+    pt.render(3)
+    acc = pt.readRadiance()
+    got = pt.draw(*params)
+    want = O.draw(acc, *params)
+    assert np.array_equal(got, want)
+    assert got[..., :3].std() > 5
+
+
+def test_log2_pow_bitwise():
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(1e-6, 4, 30000), 10 ** rng.uniform(-38, 38, 2000), [0.0, 1.0, 0.5]]).astype(np.float32)
+    y = np.full_like(x, 0.454545)
+    for op, b in ((9, None), (10, y)):
+        out = np.zeros_like(x)
+        L.check(L.lib().fspt_math_eval(0, op, L.fptr(x), L.fptr(b) if b is not None else None, x.size, L.fptr(out)))
+        ref = O.math_eval(op, x, b)
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))

@@ -447,3 +447,38 @@ int gh_read_screen(int which, float *out /* W*H*4 */) {
   free(tmp);
   return mismatches;
 }
+
+/* drawQuad (main.js:809-824): draw.fs over an RGBA32F buffer into an RGBA8 target (the canvas) */
+static GLuint p_draw;
+int gh_draw_program(const char *vs, const char *fs) { return link_program(vs, fs, &p_draw); }
+int gh_draw(const float *acc, int W, int H, float exposure, float saturation, float scale, float maxSigma, int denoise,
+            unsigned char *out) {
+  GLuint src = data_texture(GL_RGBA32F, GL_RGBA, W, H, acc);
+  GLuint dst, fbo;
+  glGenTextures(1, &dst);
+  glBindTexture(GL_TEXTURE_2D, dst);
+  glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+  glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+  glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA, W, H, 0, GL_RGBA, GL_UNSIGNED_BYTE, NULL);
+  glGenFramebuffers(1, &fbo);
+  glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+  glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, dst, 0);
+  if (glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) FAIL("draw FBO incomplete");
+  glUseProgram(p_draw);
+  glViewport(0, 0, W, H);
+  bind_corner(p_draw);
+  GLint loc;
+  if ((loc = glGetUniformLocation(p_draw, "maxSigma")) >= 0) glUniform1f(loc, maxSigma);
+  if ((loc = glGetUniformLocation(p_draw, "saturation")) >= 0) glUniform1f(loc, saturation);
+  if ((loc = glGetUniformLocation(p_draw, "exposure")) >= 0) glUniform1f(loc, exposure);
+  if ((loc = glGetUniformLocation(p_draw, "denoise")) >= 0) glUniform1i(loc, denoise);
+  if ((loc = glGetUniformLocation(p_draw, "scale")) >= 0) glUniform1f(loc, scale);
+  if ((loc = glGetUniformLocation(p_draw, "fbTex")) >= 0) glUniform1i(loc, 0);
+  glActiveTexture(GL_TEXTURE0);
+  glBindTexture(GL_TEXTURE_2D, src);
+  glDrawArrays(GL_TRIANGLES, 0, 3);
+  glFinish();
+  glReadPixels(0, 0, W, H, GL_RGBA, GL_UNSIGNED_BYTE, out);
+  GLCHK("draw");
+  return 0;
+}

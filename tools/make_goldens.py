@@ -283,6 +283,25 @@ def make_converged(name):
                         streams=np.int32([11, 12]))
 
 
+def make_draw():
+    """draw.fs (tonemap + firefly filter) on SwiftShader: HDR input = a converged golden image, with a few
+    injected fireflies so the 5x5 filter has something to do."""
+    import glsl_ref as G
+    z = np.load(os.path.join(GOLD, "glsl_converged_small.npz"))
+    hdr = z["a"].copy()
+    rng = np.random.default_rng(3)
+    ys, xs = rng.integers(3, hdr.shape[0] - 3, 12), rng.integers(3, hdr.shape[1] - 3, 12)
+    hdr[ys, xs, :3] *= rng.uniform(20, 200, size=(12, 1)).astype(np.float32)
+    g = G.GlslRef()
+    out = {"hdr": hdr}
+    for i, (exp, sat, den, sig) in enumerate([(1.0, 1.0, False, 3.0), (2.5, 0.6, False, 3.0), (1.0, 1.0, True, 3.0),
+                                              (0.7, 1.3, True, 1.5)]):
+        out[f"rgba{i}"] = g.draw(hdr, exp, sat, den, sig)
+        out[f"params{i}"] = np.float32([exp, sat, float(den), sig])
+    np.savez_compressed(os.path.join(GOLD, "glsl_draw.npz"), renderer=g.renderer, **out)
+    print("draw goldens", out["rgba0"].shape, out["rgba0"][..., :3].mean())
+
+
 if __name__ == "__main__":
     import subprocess
     what = sys.argv[1:] or ["js", "glsl", "converged"]
@@ -295,5 +314,7 @@ if __name__ == "__main__":
         elif w == "converged":
             for name in CONVERGED:
                 subprocess.check_call([sys.executable, "-u", os.path.abspath(__file__), "converged:" + name])
+        elif w == "draw":
+            make_draw()
         elif w.startswith("converged:"):
             make_converged(w.split(":", 1)[1])
