@@ -106,6 +106,7 @@ def main():
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     pt.bind_accumulator(accum.data_ptr(), keep=accum)
     pt.seed(1)
+    pt.prepare()  # path-state allocation happens here, never inside the timed region (even with --warmup 0)
 
     def barrier():
         pt.sync()

@@ -88,6 +88,7 @@ SIGNATURES = {
     "fspt_last_kernel_ms": (C.c_int, [_VP, _F, _U32]),
     "fspt_target_set_pipeline": (C.c_int, [_VP, C.c_int, C.c_uint32]),
     "fspt_last_stage_ms": (C.c_int, [_VP, _F, _U32]),
+    "fspt_target_prepare": (C.c_int, [_VP]),
     "fspt_builder_create": (C.c_int, [C.POINTER(_VP)]),
     "fspt_builder_destroy": (C.c_int, [_VP]),
     "fspt_builder_add_obj": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(PropDesc)]),

@@ -630,6 +630,25 @@ int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks)
   return FSPT_OK;
 }
 
+int fspt_target_prepare(fspt_target *t) {
+  if (!t) { fspt_set_error("fspt_target_prepare: NULL target"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  if (t->pipeline != 1) return FSPT_OK;
+  fspt::TraceP tp{};
+  fill_trace_params(t, tp);
+  const uint64_t work_total = (uint64_t)tp.n_owned_tiles * tp.tile * tp.tile;
+  if (work_total == 0) return FSPT_OK;
+  uint64_t batch = t->batch_ticks;
+  uint64_t fit = WF_SLOT_BUDGET / work_total;
+  if (fit < 1) fit = 1;
+  if (batch > fit) batch = fit;
+  if (batch * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
+  int rc = wf_ensure(t, (uint32_t)(batch * work_total));
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return FSPT_OK;
+}
+
 int fspt_last_stage_ms(fspt_target *t, float ms[4], uint32_t launches[4]) {
   if (!t || !ms || !launches) { fspt_set_error("fspt_last_stage_ms: NULL argument"); return FSPT_E_INVALID; }
   HIP_TRY(hipSetDevice(t->scene->device));

@@ -106,6 +106,10 @@ class PathTracer:
         code = {"megakernel": 0, "wavefront": 1}.get(pipeline, pipeline)
         L.check(L.lib().fspt_target_set_pipeline(self._t, int(code), int(batch_ticks)))
 
+    def prepare(self):
+        """Allocate the pipeline's path-state buffers now (not lazily inside the first render)."""
+        L.check(L.lib().fspt_target_prepare(self._t))
+
     def last_stage_ms(self):
         ms = (C.c_float * 4)(); n = (C.c_uint32 * 4)()
         L.check(L.lib().fspt_last_stage_ms(self._t, ms, n))

@@ -159,6 +159,9 @@ float fspt_rand_base_next(uint64_t *state);
  *              kernels over batch_ticks ticks at a time (0 keeps the current batch size, max 64);
  *   pipeline 0 "megakernel": one persistent kernel per tick (path regeneration). */
 int fspt_target_set_pipeline(fspt_target *target, int pipeline, uint32_t batch_ticks);
+/* Allocate (and touch) the pipeline's path-state buffers for the current resolution / shard / batch now,
+ * instead of lazily inside the first fspt_trace / fspt_render.  Blocking. */
+int fspt_target_prepare(fspt_target *target);
 /* Per-kernel-class timing of the most recent fspt_trace / fspt_render (wavefront pipeline):
  * summed HIP-event durations and launch counts for {gen, trace, logic, resolve}. Blocking. */
 int fspt_last_stage_ms(fspt_target *target, float ms[4], uint32_t launches[4]);

@@ -74,3 +74,19 @@ def test_shards_partition_frame(small_scene, camera):
         O.render(*args, part, shard=s, n_shards=3, tile=16)
         total += part
     assert np.array_equal(total, full)
+
+
+def test_oracle_root_leaf_and_black_env():
+    """2-triangle scene: root is a leaf; rays that miss see the black default environment."""
+    from fspt_amd import scene as S
+    props = [{"path": "q.obj", "scale": 3, "rotate": [], "translate": [0, -0.5, 0], "emittance": [0, 0, 0],
+              "diffuse": [0.8, 0.7, 0.6], "emission": [0.5, 0.5, 0.5], "normals": "flat"}]
+    arrays = S.build_scene(props, {"q.obj": S.QUAD_OBJ})
+    assert arrays.n_nodes == 1
+    rays = np.array([[0, 1, 0, 0, -1, 0], [0, 1, 0, 0, 1, 0], [10, 1, 0, 0, -1, 0]], np.float32)
+    t, idx, steps, leaves = O.intersect(arrays, rays)
+    assert idx[0] >= 0 and abs(t[0] - 1.5) < 1e-5 and idx[1] == -1 and idx[2] == -1
+    assert (steps == 1).all() and (leaves == 1).all()
+    acc = np.zeros((8, 8, 4), np.float32)
+    O.render(arrays, 8, 8, [0.2, 1.0, 2.5], [0.0, 0.45, 0.9], 0.5, [0.5, 0.02], 0.0, 4, 0, 1, 3, acc)
+    assert not acc[..., :3].any() and (acc[..., 3] == 1).all()  # looking away: only black environment

@@ -214,3 +214,31 @@ def test_log2_pow_bitwise():
         L.check(L.lib().fspt_math_eval(0, op, L.fptr(x), L.fptr(b) if b is not None else None, x.size, L.fptr(out)))
         ref = O.math_eval(op, x, b)
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_root_leaf_scene_and_tiny_frames(camera, pipeline):
+    """Edge cases: a 2-triangle scene whose BVH root is itself a leaf (bvh.js:22: n <= 4), the 4-triangle leaf
+    over-read running into the padding (tracer.fs:356), a black default environment (main.js:303-307), and
+    1-pixel-wide / 1-pixel-high frames."""
+    from fspt_amd import scene as S
+    props = [{"path": "q.obj", "scale": 3, "rotate": [], "translate": [0, -0.5, 0], "emittance": [0, 0, 0],
+              "diffuse": [0.8, 0.7, 0.6], "emission": [0.5, 0.5, 0.5], "normals": "flat"}]
+    arrays = S.build_scene(props, {"q.obj": S.QUAD_OBJ})  # no environment
+    assert arrays.n_nodes == 1 and arrays.n_tris == 2 and arrays.env is None
+    rays = random_rays(arrays, 2000, seed=2)
+    sc = Scene(arrays)
+    t, idx, steps, leaves = sc.intersect(rays)
+    rt, ridx, rsteps, rleaves = O.intersect(arrays, rays)
+    assert np.array_equal(idx, ridx) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+    assert (steps == 1).all() and (leaves == 1).all() and np.array_equal(steps, rsteps)
+    cam = dict(P=[0.2, 1.0, 2.5], I=[0.0, -0.45, -0.9], fov_scale=0.5, env_theta=0.0, focal_depth=2.0, aperture=0.02)
+    cam["lens"] = [0.5, 0.02]
+    for (W, H) in ((1, 37), (53, 1), (40, 24)):
+        pt = make_pt(sc, W, H, cam, 4, pipeline)
+        pt.seed(4)
+        pt.render(3)
+        want = np.zeros((H, W, 4), np.float32)
+        O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 4, 0, 3, 4, want)
+        assert np.array_equal(pt.readRadiance(), want), (W, H)
+    assert want[..., :3].max() > 0  # the emissive quad is visible (tracer.fs:467)
