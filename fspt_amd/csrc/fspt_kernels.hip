@@ -1,19 +1,24 @@
 // fspt_kernels.hip — gfx950 kernels of libfspt.
 //
 // The reference's hot path is one fragment-shader invocation per pixel
-// (shader/tracer.fs:436-518).  Here it is a persistent-threads wavefront
-// kernel: every 64-lane wave pulls pixels from a global work counter, and a
-// lane whose path has terminated is refilled with a fresh pixel in place
-// ("path regeneration"), so the wave stays full until the frame is done.  The
-// wave alternates two phases that every live lane takes part in:
-//   S  consume traversal results (tracer.fs:501-512), finish/regenerate
-//      (camera.fs:37-46, tracer.fs:515-517) or shade (tracer.fs:447-499);
-//   T  trace the lane's one or two pending rays (shadow, then extension)
-//      through the BVH (tracer.fs:366-404) in a while-while loop whose
-//      deferred-child stack lives in LDS.
-// Arithmetic is "fspt-math" (fspt_math.hpp); traversal order, pruning rule and
-// the 4-triangle leaf over-read are the reference's, so results are identical
-// to the CPU restatement bit for bit.
+// (shader/tracer.fs:436-518).  Two execution strategies run the same per-path
+// arithmetic (advance_path / shade_hit / trace loops below) and give
+// bit-identical results:
+//
+//  * wavefront pipeline (default; k_wf_gen / k_wf_trace / k_wf_logic / k_wf_resolve):
+//    path state in HBM, slot queues, one kernel per kind of work.  k_wf_trace is a
+//    persistent while-while traversal with per-lane dynamic refill from the ray queue,
+//    its deferred-child stack in LDS; k_wf_logic does one S step per live path and
+//    compacts the survivors (one 64-bit atomic per 1024 paths).
+//  * megakernel (k_trace): one persistent kernel per tick; a lane whose path has
+//    terminated pulls the next pixel in place (path regeneration); the wave alternates
+//      S  consume traversal results (tracer.fs:501-512), finish / regenerate
+//         (camera.fs:37-46, tracer.fs:515-517) or shade (tracer.fs:447-499),
+//      T  trace the lane's one or two pending rays (shadow, then extension).
+//
+// Arithmetic is "fspt-math" (fspt_math.hpp); traversal order, pruning rule and the
+// 4-triangle leaf over-read are the reference's, so results equal the CPU restatement
+// (oracle/) bit for bit.
 #include "fspt_device.hpp"
 #include "fspt_math.hpp"
 
