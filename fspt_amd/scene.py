@@ -102,6 +102,16 @@ class TexturePacker:
         self.max_res = max(self.max_res, rgba.shape[0])
         return self._add(key, ("pixels", rgba))
 
+    def add_texture(self, key, rgba, corrected=False, swizzle=None):
+        """addTexture (texture_packer.js:13-24): a decoded image, uint8 [h, w, 4] with row 0 = top as an
+        HTMLImageElement uploads; key plays the role of image.currentSrc.  corrected = sRGB-decode (diffuse
+        maps, main.js:214-219); swizzle = mrSwizzle / pmr_swizzle (main.js:226-236)."""
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        if self.image_keys.get(key):
+            return self.image_keys[key]
+        self.max_res = max(self.max_res, rgba.shape[0])
+        return self._add(key, ("image", (rgba, bool(corrected), tuple(swizzle) if swizzle else (0, 1, 2, 3))))
+
     def get_resolution(self):
         if self.max_res < self.res:
             self.res = self.max_res
@@ -115,6 +125,8 @@ class TexturePacker:
                 # gl.clearColor(c) + readPixels RGBA8 (texture_packer.js:152-157)
                 px = [int(math.floor(min(max(c, 0.0), 1.0) * 255.0 + 0.5)) for c in item[:3]] + [255]
                 out[i, :, :, :] = np.array(px, dtype=np.uint8)
+            elif kind == "image":
+                out[i] = resample_image(item[0], res, item[1], item[2])
             else:
                 if item.shape[0] != res or item.shape[1] != res:
                     raise ValueError("pre-resampled image must be res x res")
@@ -122,14 +134,53 @@ class TexturePacker:
         return out.reshape(-1)
 
 
-def get_material(prop, packer):
-    """getMaterial (main.js:206-270) for props whose maps are colours."""
-    def colour(v, default):
-        return v if isinstance(v, (list, tuple)) else default
-    diffuse = packer.add_color(colour(prop.get("diffuse"), [0.5, 0.5, 0.5]))
-    rough = packer.add_color(colour(prop.get("metallicRoughness"), [0.0, 0.3, 0]))
-    spec = packer.add_color(colour(prop.get("emission"), [0, 0, 0]))
-    normal = packer.add_color([0.5, 0.5, 1])
+def resample_image(rgba, res, corrected=False, swizzle=(0, 1, 2, 3)):
+    """WebGLTextureWriter.setAndDrawTexture + the writer shader (texture_packer.js:103-121,159-175):
+    bilinear (S = REPEAT, T = CLAMP_TO_EDGE) resample to res x res at uv = (x+.5, res-(y+.5))/res,
+    sRGB -> linear before filtering when `corrected` (SRGB8_ALPHA8 upload), channel swizzle,
+    rgb premultiplied by alpha, alpha forced to 1, quantised to RGBA8.  Output row 0 = bottom (readPixels)."""
+    src = np.asarray(rgba, dtype=np.float32) / np.float32(255.0)
+    h, w = src.shape[:2]
+    if corrected:  # sRGB EOTF on rgb, alpha linear
+        c = src[..., :3]
+        src = src.copy()
+        src[..., :3] = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4).astype(np.float32)
+    px = (np.arange(res, dtype=np.float32) + 0.5) / np.float32(res)
+    u = px * w - 0.5
+    v = (1.0 - px) * h - 0.5
+    i0 = np.floor(u).astype(np.int64); a = (u - np.floor(u)).astype(np.float32)
+    j0 = np.floor(v).astype(np.int64); b = (v - np.floor(v)).astype(np.float32)
+    i1 = (i0 + 1) % w; i0 = i0 % w
+    j1 = np.clip(j0 + 1, 0, h - 1); j0 = np.clip(j0, 0, h - 1)
+    top = src[j0][:, i0] * (1 - a)[None, :, None] + src[j0][:, i1] * a[None, :, None]
+    bot = src[j1][:, i0] * (1 - a)[None, :, None] + src[j1][:, i1] * a[None, :, None]
+    c = top * (1 - b)[:, None, None] + bot * b[:, None, None]
+    c = c[..., list(swizzle)]
+    out = np.empty((res, res, 4), np.float32)
+    out[..., :3] = c[..., :3] * c[..., 3:4]
+    out[..., 3] = 1.0
+    return np.clip(np.floor(out * 255.0 + 0.5), 0, 255).astype(np.uint8)
+
+
+def get_material(prop, packer, images=None):
+    """getMaterial (main.js:206-270).  Colour-valued maps become flat layers; string-valued maps name an
+    entry of `images` ({path: uint8 [h, w, 4], row 0 = top}) and become resampled image layers (diffuse maps
+    sRGB-decoded, main.js:214-219; metallicRoughness honours mrSwizzle, main.js:232-236)."""
+    images = images or {}
+
+    def layer(value, default, corrected=False, swizzle=None):
+        if isinstance(value, str):
+            return packer.add_texture(value, images[value], corrected, swizzle)
+        if isinstance(value, (list, tuple)):
+            return packer.add_color(value)
+        return packer.add_color(default)
+    diffuse = layer(prop.get("diffuse"), [0.5, 0.5, 0.5], corrected=True)
+    rough = layer(prop.get("metallicRoughness"), [0.0, 0.3, 0], swizzle=prop.get("mrSwizzle"))
+    em = prop.get("emission")
+    spec = packer.add_texture(em, images[em]) if isinstance(em, str) else packer.add_color(
+        em if isinstance(em, (list, tuple)) else [0, 0, 0])
+    nm = prop.get("normal")
+    normal = packer.add_texture(nm, images[nm]) if isinstance(nm, str) else packer.add_color([0.5, 0.5, 1])
     ior = prop.get("ior") or 1.4
     dielectric = prop.get("dielectric") or -1
     return dict(diffuseIndex=diffuse, roughnessIndex=rough, specularIndex=spec, normalIndex=normal,
@@ -150,7 +201,7 @@ def env_bins(env_rgbe, w, h):
     return bins
 
 
-def build_scene(props, obj_texts, env=None, env_w=0, env_h=0, leaf_size=4, atlas_res=2048):
+def build_scene(props, obj_texts, env=None, env_w=0, env_h=0, leaf_size=4, atlas_res=2048, images=None):
     """initBVH (main.js:284-445) for props = list of scene-JSON prop dicts and
     obj_texts = {path: OBJ text}.  env = RGBE uint8 [h*w*4] or None."""
     lib = L.lib()
@@ -159,7 +210,7 @@ def build_scene(props, obj_texts, env=None, env_w=0, env_h=0, leaf_size=4, atlas
     L.check(lib.fspt_builder_create(C.byref(b)))
     try:
         for prop in props:
-            m = get_material(prop, packer)
+            m = get_material(prop, packer, images)
             pd = L.PropDesc()
             rot = prop.get("rotate", [])
             flat = []
@@ -275,6 +326,34 @@ def synthetic_env(w=2048, h=1024, sun_deg=1.5, sun_gain=60.0, sun_dir=(0.35, 0.5
     rgb = np.clip(np.floor(img / scale[..., None] * 255.0 + 0.5), 0, 255)
     out = np.concatenate([rgb, (e + 128)[..., None]], -1).astype(np.uint8)
     return out.reshape(-1), w, h
+
+
+def textured_test_scene(res=16):
+    """Two image-mapped quads + a flat-colour sphere: exercises the bilinear RGBA8 atlas path (atlas res > 1),
+    tangent-space normal mapping and emissive maps with procedurally generated images."""
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:res, 0:res]
+    checker = (((xx // 2) + (yy // 2)) % 2).astype(np.uint8)
+    diffuse = np.stack([40 + 180 * checker, 200 - 120 * checker, 90 + xx * 8, np.full_like(checker, 255)], -1).astype(np.uint8)
+    mr = np.stack([(xx > res // 2) * 255, 30 + yy * 10, np.zeros_like(xx), np.full_like(xx, 255)], -1).astype(np.uint8)
+    nrm = np.stack([128 + (rng.integers(-40, 41, (res, res))), 128 + (rng.integers(-40, 41, (res, res))),
+                    np.full((res, res), 230), np.full((res, res), 255)], -1).astype(np.uint8)
+    emis = np.zeros((res, res, 4), np.uint8); emis[..., 3] = 255; emis[res // 4: res // 2, res // 4: res // 2, :3] = (255, 160, 40)
+    images = {"tex/diffuse.png": diffuse, "tex/mr.png": mr, "tex/normal.png": nrm, "tex/emissive.png": emis}
+    props = [
+        {"path": "synthetic/quad.obj", "scale": 4, "rotate": [], "translate": [0, -0.75, 0], "emittance": [0, 0, 0],
+         "diffuse": "tex/diffuse.png", "metallicRoughness": "tex/mr.png", "normal": "tex/normal.png", "normals": "flat"},
+        {"path": "synthetic/quad.obj", "scale": 4, "rotate": [{"angle": -1.57, "axis": [1, 0, 0]}], "translate": [0, 0.25, -1],
+         "emittance": [0, 0, 0], "diffuse": "tex/diffuse.png", "emission": "tex/emissive.png",
+         "metallicRoughness": [0, 0.4, 0], "normal": "tex/normal.png", "normals": "flat", "ior": 10},
+        {"path": "synthetic/cube_sphere.obj", "scale": 0.35, "rotate": [], "translate": [0.1, -0.4, 0],
+         "diffuse": [0.9, 0.9, 0.9], "emittance": [0, 0, 0], "metallicRoughness": [0, 0.2, 0], "normals": "smooth"},
+    ]
+    texts = {"synthetic/cube_sphere.obj": cube_sphere_obj(6), "synthetic/quad.obj": QUAD_OBJ}
+    env, w, h = synthetic_env(64, 32)
+    s = build_scene(props, texts, env=env, env_w=w, env_h=h, images=images)
+    s.meta = dict(kind="textured-test")
+    return s
 
 
 def bunny_props():

@@ -201,3 +201,35 @@ def test_draw_fs_matches_glsl(i):
     assert diff.max() <= 1
     assert (diff == 0).mean() >= 0.99
     assert (o[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+def test_atlas_writer_matches_reference_shader(i):
+    """resample_image vs the reference's WebGLTextureWriter shader (texture_packer.js:103-121) on SwiftShader:
+    bilinear resample, y-flip, swizzle, sRGB decode, premultiply -> within one 8-bit step."""
+    z = np.load(os.path.join(GOLD, "glsl_atlas_writer.npz"))
+    res, cor, *swz = [int(v) for v in z[f"params{i}"]]
+    o = S.resample_image(z[f"src{i}"], res, bool(cor), tuple(swz)).astype(int)
+    d = np.abs(o - z[f"dst{i}"].astype(int))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.9
+    assert (o[..., 3] == 255).all()
+
+
+def test_d3_textured_scene_bilinear_atlas():
+    """Scene with 16x16 image maps: GLSL texture() (bilinear, REPEAT) vs the oracle's hand filter."""
+    z = np.load(os.path.join(GOLD, "glsl_stages_textured.npz"))
+    a = S.textured_test_scene()
+    assert (a.atlas_res, a.atlas_layers) == (int(z["atlas_res"]), int(z["atlas_layers"])) and a.atlas_res == 16
+    W, H = int(z["W"]), int(z["H"])
+    acc = np.zeros((H, W, 4), np.float32)
+    fh = O.trace(a, W, H, z["rays_pos"], z["rays_dir"], 0, 1.0, float(z["env_theta"]), 4, acc, first_hits=True).reshape(H, W)
+    assert (fh["index"] == z["hit_index"]).mean() >= 0.9999
+    hit = (z["hit_index"] >= 0) & (fh["index"] == z["hit_index"])
+    assert hit.sum() > 1000
+    for field, key, cols, tol in (("uv", "shade2", slice(0, 2), 1e-5), ("mr", "shade2", slice(2, 4), 1e-3),
+                                  ("diffuse", "shade3", slice(0, 3), 1e-3), ("tex_normal", "shade4", slice(0, 3), 1e-3),
+                                  ("macro_normal", "shade5", slice(0, 3), 1e-3), ("emissive", "shade7", slice(0, 3), 1e-3)):
+        d = np.abs(z[key][..., cols] - fh[field])[hit]
+        assert d.max() <= tol, (field, d.max())
+    # the maps really vary across the image (not a flat-colour scene in disguise)
+    assert fh["diffuse"][hit].std() > 0.1 and fh["tex_normal"][hit][:, 0].std() > 0.05

@@ -242,3 +242,24 @@ def test_root_leaf_scene_and_tiny_frames(camera, pipeline):
         O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 4, 0, 3, 4, want)
         assert np.array_equal(pt.readRadiance(), want), (W, H)
     assert want[..., :3].max() > 0  # the emissive quad is visible (tracer.fs:467)
+
+
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_textured_scene_bitwise(camera, pipeline):
+    """Image-mapped materials (atlas res 16): the bilinear REPEAT atlas fetch, normal mapping and emissive maps
+    on the device equal the oracle bit for bit."""
+    from fspt_amd import scene as S
+    arrays = S.textured_test_scene()
+    assert arrays.atlas_res == 16
+    W, H = 96, 64
+    pt = make_pt(arrays, W, H, camera, 4, pipeline)
+    pt.enable_counters(True)
+    pt.clear()
+    pt.seed(6)
+    pt.render(3)
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(arrays, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4, 0, 3, 6,
+             want, counters=oc)
+    assert np.array_equal(pt.readRadiance(), want)
+    assert pt.counters() == oc.as_dict()

@@ -172,3 +172,20 @@ class GlslRef:
         self._ck(self.lib.gh_draw(acc.ctypes.data_as(_F), W, H, C.c_float(exposure), C.c_float(saturation), C.c_float(1.0),
                                   C.c_float(max_sigma), 1 if denoise else 0, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
+
+    def write_texture(self, rgba, res, corrected=False, swizzle=(0, 1, 2, 3)):
+        """WebGLTextureWriter (texture_packer.js:66-185): the writer's shader strings are taken from the
+        reference file at run time."""
+        if not getattr(self, "_writer_ready", False):
+            js = open(os.path.join(REF, "texture_packer.js")).read()
+            vs = re.search(r"let vsStr = `(.*?)`;", js, re.S).group(1)
+            fs = re.search(r"let fsStr = `(.*?)`;", js, re.S).group(1)
+            self._ck(self.lib.gh_writer_program(vs.encode(), fs.encode()))
+            self._writer_ready = True
+        rgba = np.ascontiguousarray(rgba, np.uint8)
+        h, w = rgba.shape[:2]
+        out = np.zeros((res, res, 4), np.uint8)
+        sw = (C.c_uint * 4)(*swizzle)
+        self._ck(self.lib.gh_write_texture(rgba.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, 1 if corrected else 0, sw, res,
+                                           out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out

@@ -482,3 +482,46 @@ int gh_draw(const float *acc, int W, int H, float exposure, float saturation, fl
   GLCHK("draw");
   return 0;
 }
+
+/* WebGLTextureWriter.setAndDrawTexture + getPixels (texture_packer.js:159-185): resample one source image to
+ * res x res through the writer's own shader. */
+#define GL_SRGB8_ALPHA8 0x8C43
+static GLuint p_writer;
+int gh_writer_program(const char *vs, const char *fs) { return link_program(vs, fs, &p_writer); }
+int gh_write_texture(const unsigned char *src, int w, int h, int corrected, const unsigned int swizzle[4], int res,
+                     unsigned char *out) {
+  GLuint tex, dst, fbo;
+  glGenTextures(1, &tex);
+  glBindTexture(GL_TEXTURE_2D, tex);
+  glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_REPEAT);          /* texture_packer.js:91-94 */
+  glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+  glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
+  glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+  glTexImage2D(GL_TEXTURE_2D, 0, corrected ? GL_SRGB8_ALPHA8 : GL_RGBA, w, h, 0, GL_RGBA, GL_UNSIGNED_BYTE, src);
+  glGenTextures(1, &dst);
+  glBindTexture(GL_TEXTURE_2D, dst);
+  glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+  glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+  glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA, res, res, 0, GL_RGBA, GL_UNSIGNED_BYTE, NULL);
+  glGenFramebuffers(1, &fbo);
+  glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+  glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, dst, 0);
+  if (glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) FAIL("writer FBO incomplete");
+  glUseProgram(p_writer);
+  glClearColor(0.0f, 0.0f, 0.0f, 1.0f);
+  glClear(GL_COLOR_BUFFER_BIT);
+  glViewport(0, 0, res, res);
+  bind_corner(p_writer);
+  GLint loc;
+  if ((loc = glGetUniformLocation(p_writer, "tex")) >= 0) glUniform1i(loc, 0);
+  float dims[2] = {(float)res, (float)res};
+  if ((loc = glGetUniformLocation(p_writer, "dims")) >= 0) glUniform2fv(loc, 1, dims);
+  if ((loc = glGetUniformLocation(p_writer, "swizzle")) >= 0) glUniform4uiv(loc, 1, swizzle);
+  glActiveTexture(GL_TEXTURE0);
+  glBindTexture(GL_TEXTURE_2D, tex);
+  glDrawArrays(GL_TRIANGLES, 0, 3);
+  glFinish();
+  glReadPixels(0, 0, res, res, GL_RGBA, GL_UNSIGNED_BYTE, out);
+  GLCHK("write_texture");
+  return 0;
+}

@@ -302,6 +302,49 @@ def make_draw():
     print("draw goldens", out["rgba0"].shape, out["rgba0"][..., :3].mean())
 
 
+def make_textured():
+    """D3 on a scene with image maps (atlas res 16): the GLSL's bilinear RGBA8 texture() against the oracle's."""
+    import glsl_ref as G
+    import oracle as O
+    arrays = S.textured_test_scene()
+    cam = dict(S.BUNNY_CAMERA)
+    lens = S.lens_features(cam["focal_depth"], cam["aperture"])
+    g = G.GlslRef()
+    g.scene(arrays)
+    g._env_theta = cam["env_theta"]
+    W, H = 64, 40
+    g.target(W, H, replicate=True)
+    pos, d = O.camera(W, H, cam["P"], cam["I"], cam["fov_scale"], lens, 4321.0)
+    g.set_camera(pos, d)
+    out = dict(W=W, H=H, rays_pos=pos, rays_dir=d, env_theta=np.float32(cam["env_theta"]), atlas_res=arrays.atlas_res,
+               atlas_layers=arrays.atlas_layers)
+    hit = probe(g, HIT)
+    out["hit_t"], out["hit_index"] = hit[..., 0], hit[..., 1].astype(np.int32)
+    for sel in (2, 3, 4, 5, 7):
+        out[f"shade{sel}"] = probe(g, sel)
+    np.savez_compressed(os.path.join(GOLD, "glsl_stages_textured.npz"), **out)
+    print("textured stages", arrays.atlas_res, arrays.atlas_layers, (out["hit_index"] >= 0).mean())
+
+
+def make_atlas():
+    """Reference atlas writer (texture_packer.js WebGLTextureWriter) on synthetic source images."""
+    import glsl_ref as G
+    g = G.GlslRef()
+    rng = np.random.default_rng(11)
+    out = {}
+    cases = [(37, 23, 16, False, (0, 1, 2, 3)), (64, 64, 32, True, (0, 1, 2, 3)), (20, 48, 32, False, (2, 1, 0, 3)),
+             (33, 17, 8, True, (1, 0, 2, 3))]
+    for i, (w, h, res, corrected, swz) in enumerate(cases):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([(xx * 255 // max(1, w - 1)), (yy * 255 // max(1, h - 1)), rng.integers(0, 256, (h, w)),
+                        np.where((xx + yy) % 5 == 0, 128, 255)], -1).astype(np.uint8)
+        out[f"src{i}"] = img
+        out[f"params{i}"] = np.int32([res, int(corrected), *swz])
+        out[f"dst{i}"] = g.write_texture(img, res, corrected, swz)
+    np.savez_compressed(os.path.join(GOLD, "glsl_atlas_writer.npz"), renderer=g.renderer, **out)
+    print("atlas goldens", [out[f"dst{i}"].shape for i in range(len(cases))])
+
+
 if __name__ == "__main__":
     import subprocess
     what = sys.argv[1:] or ["js", "glsl", "converged"]
@@ -314,6 +357,10 @@ if __name__ == "__main__":
         elif w == "converged":
             for name in CONVERGED:
                 subprocess.check_call([sys.executable, "-u", os.path.abspath(__file__), "converged:" + name])
+        elif w == "textured":
+            make_textured()
+        elif w == "atlas":
+            make_atlas()
         elif w == "draw":
             make_draw()
         elif w.startswith("converged:"):
