@@ -263,3 +263,78 @@ def test_textured_scene_bitwise(camera, pipeline):
              want, counters=oc)
     assert np.array_equal(pt.readRadiance(), want)
     assert pt.counters() == oc.as_dict()
+
+
+def test_full_size_baseline_config_properties():
+    """BASELINE configs[1] at full size (69 316 triangles, 1920x1080, depth 8):
+      * the two independent schedulers (wavefront / megakernel) agree on every pixel, bit for bit;
+      * every 64th 32x32 tile (oracle tile shard 0 of 64) equals the CPU oracle exactly, counters included;
+      * re-rendering with the same seed is idempotent; alpha is 1 everywhere; radiance is finite and clamped."""
+    from fspt_amd import scene as S
+    arrays = S.bunny_scene(n=76)
+    cam = dict(S.BUNNY_CAMERA)
+    cam["lens"] = S.lens_features(cam["focal_depth"], cam["aperture"])
+    W, H, ticks, seed = 1920, 1080, 2, 12345
+    sc = Scene(arrays)
+    pt = make_pt(sc, W, H, cam, 8, "wavefront")
+    pt.seed(seed)
+    pt.render(ticks)
+    wf = pt.readRadiance()
+    pt.clear(); pt.seed(seed); pt.render(ticks)
+    assert np.array_equal(pt.readRadiance(), wf)  # idempotent
+    pt.close()
+    mk = make_pt(sc, W, H, cam, 8, "megakernel")
+    mk.seed(seed)
+    mk.render(ticks)
+    assert np.array_equal(mk.readRadiance(), wf)
+    mk.close()
+    assert np.isfinite(wf).all() and (wf[..., 3] == 1).all() and wf[..., :3].min() >= 0 and wf[..., :3].max() <= 1024
+    # oracle on a uniform 1/64 sample of the tiles
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 8, 0, ticks, seed, want,
+             counters=oc, shard=0, n_shards=64, tile=32)
+    from fspt_amd import distributed as D
+    mask = D.owner_mask(0, 64, W, H)
+    assert mask.sum() > 30000
+    assert np.array_equal(wf[mask], want[mask])
+    # the same shard traced on the GPU gives the oracle's work counters (reference-algorithm steps/leaves/...)
+    sh = make_pt(sc, W, H, cam, 8, "wavefront")
+    sh.set_shard(0, 64, 32)
+    sh.enable_counters(True)
+    sh.clear(); sh.seed(seed); sh.render(ticks)
+    assert sh.counters() == oc.as_dict()
+    sh.close()
+
+
+def test_bvh_deeper_than_the_reference_stack_is_rejected():
+    """tracer.fs:368 `int stack[64]`: a (degenerate, chain-shaped) tree deeper than 63 levels is refused."""
+    import ctypes as C
+    n_leaves = 70
+    nodes = []
+    # pre-order chain: interior i has a leaf as left child and the next interior as right child
+    for i in range(n_leaves - 1):
+        nodes.append(("interior", i))
+        nodes.append(("leaf", i))
+    nodes.append(("leaf", n_leaves - 1))
+    bvh = np.zeros((len(nodes), 9), np.float32)
+    iv = bvh.view(np.int32)
+    tri = np.zeros((n_leaves, 9), np.float32)
+    for k in range(n_leaves):
+        tri[k] = [k, 0, 0, k + 0.5, 0, 0, k, 0.5, 0]
+    idx = 0
+    for kind, i in nodes:
+        if kind == "interior":
+            iv[idx, 0] = idx + 1; iv[idx, 1] = idx + 2; iv[idx, 2] = -1
+        else:
+            iv[idx, 0] = 0; iv[idx, 1] = 0; iv[idx, 2] = i
+        bvh[idx, 3:6] = [0, 0, 0]; bvh[idx, 6:9] = [n_leaves, 1, 1]
+        idx += 1
+    from fspt_amd import scene as S
+    arr = S.SceneArrays(bvh=bvh.reshape(-1), tri=tri.reshape(-1), mat=np.zeros(n_leaves * 12, np.float32),
+                        norm=np.zeros(n_leaves * 27, np.float32), uv=np.zeros(n_leaves * 6, np.float32),
+                        atlas=np.full(4, 255, np.uint8), atlas_res=1, atlas_layers=1, env=None, env_w=0, env_h=0,
+                        bins=np.array([0, 0, 1, 2048], np.uint32))
+    with pytest.raises(L.FsptError) as e:
+        Scene(arr)
+    assert e.value.code == -1 and "depth" in str(e.value)
