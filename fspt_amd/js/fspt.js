@@ -87,6 +87,43 @@ function buildScene(props, objTexts, env, leafSize) {
   return s;
 }
 
+/** `.fspt` scene blob (layout: fspt_amd/blob.py). */
+const fs = require('fs');
+const DT = [Float32Array, Uint8Array, Uint32Array];
+function saveBlob(path, s) {
+  const secs = [['bvh', s.bvh], ['tri', s.tri], ['mat', s.mat], ['norm', s.norm], ['uv', s.uv], ['atlas', s.atlas],
+    ['bins', s.bins], ['meta', new Uint32Array([s.atlasRes, s.atlasLayers, s.env ? s.envW : 0, s.env ? s.envH : 0, s.leafSize, s.depth || 0])]];
+  if (s.env) secs.push(['env', s.env]);
+  const parts = [Buffer.from('FSPT'), Buffer.alloc(8)];
+  parts[1].writeUInt32LE(1, 0); parts[1].writeUInt32LE(secs.length, 4);
+  for (const [name, arr] of secs) {
+    const h = Buffer.alloc(24);
+    h.write(name, 0, 'ascii');
+    h.writeUInt32LE(DT.findIndex((T) => arr instanceof T), 8);
+    h.writeBigUInt64LE(BigInt(arr.length), 16);
+    const raw = Buffer.from(arr.buffer, arr.byteOffset, arr.byteLength);
+    parts.push(h, raw, Buffer.alloc((16 - (raw.length % 16)) % 16));
+  }
+  fs.writeFileSync(path, Buffer.concat(parts));
+}
+function loadBlob(path) {
+  const buf = fs.readFileSync(path);
+  if (buf.toString('ascii', 0, 4) !== 'FSPT' || buf.readUInt32LE(4) !== 1) throw new Error('not a version-1 .fspt blob');
+  const n = buf.readUInt32LE(8), secs = {};
+  let off = 12;
+  for (let i = 0; i < n; i++) {
+    const name = buf.toString('ascii', off, off + 8).replace(/\0+$/, '');
+    const T = DT[buf.readUInt32LE(off + 8)], count = Number(buf.readBigUInt64LE(off + 16));
+    off += 24;
+    const nbytes = count * T.BYTES_PER_ELEMENT;
+    secs[name] = new T(buf.buffer.slice(buf.byteOffset + off, buf.byteOffset + off + nbytes));
+    off += nbytes + ((16 - (nbytes % 16)) % 16);
+  }
+  const m = secs.meta;
+  return { bvh: secs.bvh, tri: secs.tri, mat: secs.mat, norm: secs.norm, uv: secs.uv, atlas: secs.atlas, atlasRes: m[0],
+    atlasLayers: m[1], env: secs.env || null, envW: m[2], envH: m[3], bins: secs.bins, leafSize: m[4], depth: m[5] };
+}
+
 class PathTracer {
   /** scene: {bvh,tri,mat,norm,uv,atlas,atlasRes,atlasLayers,env,envW,envH,bins,leafSize} */
   constructor(scene, width, height, device) {
@@ -131,4 +168,4 @@ class PathTracer {
   close() { if (this._target) { addon.targetDestroy(this._target); addon.sceneDestroy(this._scene); this._target = null; } }
 }
 
-module.exports = { addon, TexturePacker, getMaterial, packReferenceScene, buildScene, PathTracer };
+module.exports = { addon, TexturePacker, getMaterial, packReferenceScene, buildScene, PathTracer, saveBlob, loadBlob };

@@ -16,6 +16,11 @@ if (mode === 'exports') {
   const s = F.buildScene(job.props, job.objs, env, 4);
   for (const k of ['bvh', 'tri', 'mat', 'norm', 'uv', 'bins', 'atlas']) out[k] = b64(s[k]);
   out.depth = s.depth; out.atlasLayers = s.atlasLayers;
+} else if (mode === 'blob') {
+  // read a blob written by Python, write it back from JS
+  const s = F.loadBlob(job.blob_in);
+  F.saveBlob(job.blob_out, s);
+  out.n_tris = s.tri.length / 9; out.leafSize = s.leafSize; out.atlasLayers = s.atlasLayers;
 } else if (mode === 'nogpu') {
   const s = F.buildScene(job.props, job.objs, env, 4);
   try { new F.PathTracer(s, 16, 16, 0); out.error = null; } catch (e) { out.error = String(e.message); }

@@ -77,3 +77,18 @@ def test_js_host_render_matches_oracle(small_scene, camera):
     O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
              0, 5, 21, want)
     assert np.array_equal(got, want)
+
+
+def test_blob_roundtrip_python_and_js(small_scene, tmp_path):
+    """.fspt scene blob: Python -> file -> JS -> file -> Python is the identity."""
+    from fspt_amd import blob
+    p1, p2 = str(tmp_path / "a.fspt"), str(tmp_path / "b.fspt")
+    blob.save(p1, small_scene)
+    out = run_node("blob", {"blob_in": p1, "blob_out": p2})
+    assert out["n_tris"] == small_scene.n_tris and out["leafSize"] == 4
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    b = blob.load(p2)
+    for k in ("bvh", "tri", "mat", "norm", "uv", "atlas", "env", "bins"):
+        assert np.array_equal(getattr(b, k), getattr(small_scene, k)), k
+    assert (b.atlas_res, b.atlas_layers, b.env_w, b.env_h, b.leaf_size, b.depth) == (
+        small_scene.atlas_res, small_scene.atlas_layers, small_scene.env_w, small_scene.env_h, 4, small_scene.depth)
