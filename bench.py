@@ -9,8 +9,9 @@ accumulated into the running-mean radiance buffer.  N=1 workload = BASELINE
 configs[1]: synthetic 'bunny' scene (69 316 triangles), 1920x1080, depth 8.
 For N>1 (launched by torch.distributed.run, one rank per GPU) the frame grows
 with N (weak scaling: 1920*a x 1080*b, a*b = N), is cut into 32x32 tiles dealt
-round-robin to the ranks (no data-path collective), and ONE RCCL sum-reduce of
-the RGBA32F radiance buffer to rank 0 closes the timed region.
+round-robin to the ranks (no data-path collective), and ONE RCCL exchange of the
+RGBA32F radiance buffer to rank 0 closes the timed region: a gather of
+each rank's own tiles (default) or a sum-reduce of the full frame (--exchange reduce).
 
 Rank 0 prints ONE JSON line.
 """
@@ -69,6 +70,8 @@ def main():
     ap.add_argument("--aperture", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
+                    help="multi-GPU read-out: gather each rank's own tiles to rank 0 (default) or sum-reduce the full frame")
     ap.add_argument("--batch", type=int, default=64, help="ticks per wavefront batch")
     args = ap.parse_args()
 
@@ -106,6 +109,7 @@ def main():
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     pt.bind_accumulator(accum.data_ptr(), keep=accum)
     pt.seed(1)
+    exch = D.TileGather(rank, n_gpus, W, H, accum.device) if (n_gpus > 1 and args.exchange == "gather") else None
     pt.prepare()  # path-state allocation happens here, never inside the timed region (even with --warmup 0)
 
     def barrier():
@@ -123,7 +127,11 @@ def main():
     t_start = time.perf_counter()
     pt.render(args.steps)
     pt.sync()
-    D.reduce_radiance(accum, dst=0)  # the one exchange step (RCCL sum-reduce to rank 0)
+    # the one exchange step of the path (RCCL over xGMI): rank 0 ends up with the whole frame
+    if exch is not None:
+        exch.exchange(accum)
+    else:
+        D.reduce_radiance(accum, dst=0)
     barrier()
     elapsed = time.perf_counter() - t_start
     kernel_ms, launches = pt.last_kernel_ms()
@@ -188,7 +196,7 @@ def main():
             "config": {"workload": f"bunny-synthetic {arrays.n_tris} tri, {W}x{H}, depth {args.bounces}, "
                                    f"1 spp/step, aperture {cam['aperture']}",
                        "scene_bytes": arrays.nbytes(), "bvh_nodes": arrays.n_nodes, "bvh_depth": arrays.depth,
-                       "env_bins": int(arrays.bins.size // 4), "sharding": f"32x32 tiles round-robin over {n_gpus}", "pipeline": args.pipeline, "batch_ticks": args.batch,
+                       "env_bins": int(arrays.bins.size // 4), "sharding": f"32x32 tiles round-robin over {n_gpus}", "exchange": (args.exchange if n_gpus > 1 else "none"), "pipeline": args.pipeline, "batch_ticks": args.batch,
                        "scene_build_s": round(build_s, 2)},
             "roofline": roofline,
         }

@@ -53,6 +53,45 @@ def owner_mask(rank, world, width, height, tile=TILE):
     return ((ys // tile) * tiles_x + xs // tile) % world == rank
 
 
+def owned_pixel_index(rank, world, width, height, tile=TILE, device=None):
+    """Linear pixel indices (row-major, int64 tensor) of the pixels `rank` traces, in a fixed order."""
+    import numpy as np
+    import torch
+    idx = np.flatnonzero(owner_mask(rank, world, width, height, tile).reshape(-1))
+    return torch.from_numpy(idx).to(device) if device is not None else torch.from_numpy(idx)
+
+
+class TileGather:
+    """Read-out exchange that moves only what each rank owns (the cheaper alternative to reducing
+    the whole frame): every rank packs its own pixels (1/world of the frame), one gather to `dst`, `dst`
+    scatters the pieces into its full-size buffer.  Index tensors are built once, outside any timed region."""
+
+    def __init__(self, rank, world, width, height, device, tile=TILE, dst=0):
+        import torch
+        self.rank, self.world, self.dst = rank, world, dst
+        self.idx = owned_pixel_index(rank, world, width, height, tile, device)
+        counts = [int(owner_mask(r, world, width, height, tile).sum()) for r in range(world)]
+        self.n_max = max(counts)
+        self.send = torch.zeros((self.n_max, 4), dtype=torch.float32, device=device)
+        self.recv, self.all_idx = None, None
+        if rank == dst:
+            self.recv = [torch.zeros((self.n_max, 4), dtype=torch.float32, device=device) for _ in range(world)]
+            self.all_idx = [owned_pixel_index(r, world, width, height, tile, device) for r in range(world)]
+
+    def exchange(self, accum):
+        """accum: float32 [H, W, 4] on every rank (only own pixels non-zero); complete on `dst` afterwards."""
+        import torch.distributed as dist
+        flat = accum.view(-1, 4)
+        self.send[: self.idx.numel()] = flat.index_select(0, self.idx)
+        if self.world > 1:
+            dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst)
+            if self.rank == self.dst:
+                for r in range(self.world):
+                    if r != self.dst:
+                        flat.index_copy_(0, self.all_idx[r], self.recv[r][: self.all_idx[r].numel()])
+        return accum
+
+
 def reduce_radiance(accum, dst=0):
     """The one exchange step: sum the ranks' full-size buffers onto `dst` in place."""
     import torch.distributed as dist

@@ -40,10 +40,13 @@ def _worker(rank, world, port, tmp):
     # a rank only ever touches its own tiles
     mask = D.owner_mask(rank, world, W, H)
     assert not acc[~mask].any() and (acc[..., 3][mask] == 1).all()
-    t = torch.from_numpy(acc)
+    t = torch.from_numpy(acc.copy())
     D.reduce_radiance(t, dst=0)
+    t2 = torch.from_numpy(acc.copy())
+    D.TileGather(rank, world, W, H, torch.device("cpu")).exchange(t2)
     if rank == 0:
         np.save(os.path.join(tmp, "reduced.npy"), t.numpy())
+        np.save(os.path.join(tmp, "gathered.npy"), t2.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,6 +63,7 @@ def test_two_rank_tile_shard_and_reduce(tmp_path):
     want = np.zeros((H, W, 4), np.float32)
     O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], lens, cam["env_theta"], 4, 0, TICKS, SEED, want)
     assert np.array_equal(got, want)
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "gathered.npy")), want)  # tile-gather exchange
 
 
 def test_tile_ownership_partitions_frame():

@@ -338,3 +338,32 @@ def test_bvh_deeper_than_the_reference_stack_is_rejected():
     with pytest.raises(L.FsptError) as e:
         Scene(arr)
     assert e.value.code == -1 and "depth" in str(e.value)
+
+
+def test_bound_torch_accumulator_and_tile_gather_on_gpu(small_scene, camera):
+    """bench.py's multi-GPU plumbing on one GPU: the library accumulates into a torch tensor
+    (fspt_target_bind_accumulator), two tile shards rendered by two targets, exchanged with TileGather's
+    pack / scatter (world 1: no collective) -> equals the oracle's full frame."""
+    import torch
+    from fspt_amd import distributed as D
+    W, H = 100, 70
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
+             0, 2, 17, want)
+    sc = Scene(small_scene)
+    full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for r in range(2):
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+        pt = make_pt(sc, W, H, camera, 4)
+        pt.set_shard(r, 2, D.TILE)
+        pt.bind_accumulator(acc.data_ptr(), keep=acc)
+        pt.seed(17)
+        pt.render(2)
+        pt.sync()
+        idx = D.owned_pixel_index(r, 2, W, H, device=acc.device)
+        assert not acc.view(-1, 4)[torch.ones(W * H, dtype=torch.bool, device=acc.device).index_fill_(0, idx, False)].any()
+        full.view(-1, 4).index_copy_(0, idx, acc.view(-1, 4).index_select(0, idx))
+        pt.close()
+    assert np.array_equal(full.cpu().numpy(), want)
+    g = D.TileGather(0, 1, W, H, full.device)
+    assert np.array_equal(g.exchange(full.clone()).cpu().numpy(), want)
