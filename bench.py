@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--mesh-n", type=int, default=76, help="cube-sphere resolution: 12*n^2 triangles (289 -> 1M)")
     ap.add_argument("--aperture", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "wavefront2"])
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="multi-GPU read-out: gather each rank's own tiles to rank 0 (default) or sum-reduce the full frame")
     ap.add_argument("--batch", type=int, default=64, help="ticks per wavefront batch")
@@ -146,7 +146,7 @@ def main():
     # ---- stage timing of the TIMED region (HIP events recorded on the target's stream around
     #      every kernel launch) + algorithmic work (counting variant, outside the timed region) ----
     if rank == 0:
-        stages = pt.last_stage_ms() if args.pipeline == "wavefront" else None
+        stages = pt.last_stage_ms() if args.pipeline.startswith("wavefront") else None
         pt.enable_counters(True)
         L = fspt_amd._lib
         L.check(L.lib().fspt_counters_reset(pt._t))
@@ -188,6 +188,16 @@ def main():
             if tj:
                 roofline["traffic"] = round(tj["hbm_bytes_per_launch_corrected"])
                 roofline["traffic_source"] = "profiles/r01/final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
+            # what actually bounds the kernel on this cache-resident scene: the CU's vector-memory pipeline
+            # (TA address / TD data-return units of the L1), DESIGN.md 4.3
+            lpath = os.path.join(ROOT, "profiles", "r01", "l1_pipe.json")
+            if key == "c2_70k" and os.path.exists(lpath):
+                lj = json.load(open(lpath))
+                kj = lj["kernels"].get("k_wf_trace<false>")
+                if kj:
+                    roofline["vmem_pipe"] = {"TA_busy": kj["TA_busy"], "TD_busy": kj["TD_busy"],
+                                             "l1_gather_peak_GBps": lj["l1_gather_GBps"]["divergent_64B_records"],
+                                             "source": "profiles/r01/l1_pipe.json (rocprofv3 --pmc TA_TA_BUSY / TD_TD_BUSY; tools/microbench/gather2)"}
         out = {
             "metric": "Msamples/s at 1920x1080 depth 8 (bunny, 70k tri)",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,

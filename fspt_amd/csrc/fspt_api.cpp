@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -58,11 +59,19 @@ struct fspt_target {
   bool timed = false;
   uint32_t last_launches = 0;
   // wavefront pipeline
-  int pipeline = 1;           // 0 = megakernel, 1 = wavefront
+  int pipeline = 1;           // 0 = megakernel, 1 = wavefront (2 = wavefront with two overlapped lanes sets n_lanes)
   uint32_t batch_ticks = 64;  // ticks traced together by the wavefront pipeline (18.8 GB of path state at 1080p)
-  void *wf_mem[13] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  fspt::WfCounts *wf_counts = nullptr;
-  uint32_t wf_slots = 0;      // allocated path slots
+  // Two lanes = two independent batches in flight on two HIP streams: while one batch sits in a latency-bound
+  // kernel or in the tail of a late round, the other batch's kernels fill the idle SIMDs.
+  struct WfLane {
+    void *mem[13] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    fspt::WfCounts *counts = nullptr;
+    uint32_t slots = 0;        // allocated path slots
+    hipStream_t stream = nullptr;
+    hipEvent_t resolved = nullptr; // this lane's most recent resolve has finished
+  } lanes[2];
+  uint32_t n_lanes = 1; // 2 = pipeline code 2: measured +3 % at 64+ ticks, -17 % at 8 ticks (profiles/r01)
+  hipEvent_t ev_start = nullptr;
   // per-launch stage timing (HIP events on the target's stream)
   std::vector<hipEvent_t> ev_pool;
   std::vector<int> ev_kind;   // kernel class of pair i
@@ -296,6 +305,11 @@ int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **
   if (e == hipSuccess) e = hipStreamCreate(&t->stream);
   if (e == hipSuccess) e = hipEventCreate(&t->ev0);
   if (e == hipSuccess) e = hipEventCreate(&t->ev1);
+  if (e == hipSuccess) e = hipEventCreate(&t->ev_start);
+  for (auto &ln : t->lanes) {
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.resolved, hipEventDisableTiming);
+  }
   if (e == hipSuccess) e = hipMemsetAsync(t->accum_own, 0, px * 16, t->stream);
   if (e == hipSuccess) e = hipMemsetAsync(t->counters, 0, 48, t->stream);
   if (e != hipSuccess) {
@@ -313,8 +327,13 @@ int fspt_target_destroy(fspt_target *t) {
   hipSetDevice(t->scene->device);
   if (t->stream) hipStreamSynchronize(t->stream);
   hipFree(t->accum_own); hipFree(t->ray_pos); hipFree(t->ray_dir); hipFree(t->work_counters); hipFree(t->counters);
-  for (void *m : t->wf_mem) hipFree(m);
-  hipFree(t->wf_counts);
+  for (auto &ln : t->lanes) {
+    for (void *m : ln.mem) hipFree(m);
+    hipFree(ln.counts);
+    if (ln.resolved) hipEventDestroy(ln.resolved);
+    if (ln.stream) hipStreamDestroy(ln.stream);
+  }
+  if (t->ev_start) hipEventDestroy(t->ev_start);
   for (hipEvent_t e : t->ev_pool) hipEventDestroy(e);
   if (t->ev0) hipEventDestroy(t->ev0);
   if (t->ev1) hipEventDestroy(t->ev1);
@@ -390,22 +409,36 @@ static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
   p.n_owned_tiles = (n_tiles > t->shard) ? (n_tiles - t->shard + t->n_shards - 1) / t->n_shards : 0;
 }
 
-static int wf_ensure(fspt_target *t, uint32_t slots) {
-  if (t->wf_slots >= slots && t->wf_counts) return FSPT_OK;
-  HIP_TRY(hipStreamSynchronize(t->stream));
-  for (void *&m : t->wf_mem) { if (m) { HIP_TRY(hipFree(m)); m = nullptr; } }
+static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots) {
+  if (ln.slots >= slots && ln.counts) return FSPT_OK;
+  HIP_TRY(hipStreamSynchronize(ln.stream));
+  for (void *&m : ln.mem) { if (m) { HIP_TRY(hipFree(m)); m = nullptr; } }
   // ray_o ray_d thr col shd pend (float4) | hit (float2) | shadow_hit (int) | q_ext[2] q_shd[2] (u32) | fin (float4)
   const size_t sz[13] = {16, 16, 16, 16, 16, 16, 8, 4, 4, 4, 4, 4, 16};
   for (int i = 0; i < 13; ++i) {
-    HIP_TRY(hipMalloc(&t->wf_mem[i], (size_t)slots * sz[i]));
-    HIP_TRY(hipMemsetAsync(t->wf_mem[i], 0, (size_t)slots * sz[i], t->stream)); // touch every page once, now
+    HIP_TRY(hipMalloc(&ln.mem[i], (size_t)slots * sz[i]));
+    HIP_TRY(hipMemsetAsync(ln.mem[i], 0, (size_t)slots * sz[i], ln.stream)); // touch every page once, now
   }
-  if (!t->wf_counts) HIP_TRY(hipMalloc((void **)&t->wf_counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2)));
-  t->wf_slots = slots;
+  if (!ln.counts) HIP_TRY(hipMalloc((void **)&ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2)));
+  HIP_TRY(hipStreamSynchronize(ln.stream));
+  ln.slots = slots;
   return FSPT_OK;
 }
 
-static int ev_begin(fspt_target *t, int kind) {
+// ticks per lane and number of lanes for a call of n_ticks (0 = the configured steady state)
+static void wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &lanes, uint32_t &per_lane) {
+  uint32_t batch = t->batch_ticks;
+  if (batch > (uint32_t)fspt::WF_MAX_BATCH) batch = fspt::WF_MAX_BATCH;
+  uint64_t fit = WF_SLOT_BUDGET / work_total;
+  if (fit < 1) fit = 1;
+  if (batch > fit) batch = (uint32_t)fit;
+  if (batch < 1) batch = 1;
+  lanes = (t->n_lanes >= 2 && batch >= 2) ? 2u : 1u;
+  per_lane = batch / lanes; // the configured batch is the number of ticks in flight over all lanes
+  (void)n_ticks;
+}
+
+static int ev_begin(fspt_target *t, int kind, hipStream_t stream) {
   if (t->ev_used >= EV_PAIRS) { t->ev_overflow = true; return -1; }
   if (t->ev_pool.size() < (size_t)(t->ev_used + 1) * 2) {
     hipEvent_t a, b;
@@ -415,10 +448,10 @@ static int ev_begin(fspt_target *t, int kind) {
   }
   int i = (int)t->ev_used++;
   t->ev_kind[i] = kind;
-  hipEventRecord(t->ev_pool[2 * i], t->stream);
+  hipEventRecord(t->ev_pool[2 * i], stream);
   return i;
 }
-static void ev_end(fspt_target *t, int i) { if (i >= 0) hipEventRecord(t->ev_pool[2 * i + 1], t->stream); }
+static void ev_end(fspt_target *t, int i, hipStream_t stream) { if (i >= 0) hipEventRecord(t->ev_pool[2 * i + 1], stream); }
 
 // n_ticks ticks through the wavefront pipeline.  rays_from_buffers: two-call form (n_ticks == 1).
 static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
@@ -427,28 +460,21 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
   fill_trace_params(t, tp);
   const uint32_t work_total = tp.n_owned_tiles * tp.tile * tp.tile;
   if (work_total == 0) return FSPT_OK;
-  uint32_t batch = t->batch_ticks;
-  if (batch > (uint32_t)fspt::WF_MAX_BATCH) batch = fspt::WF_MAX_BATCH;
-  uint64_t fit = WF_SLOT_BUDGET / work_total;
-  if (fit < 1) fit = 1;
-  if (batch > fit) batch = (uint32_t)fit;
-  if (batch < 1) batch = 1;
-  if ((uint64_t)batch * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
+  uint32_t n_lanes, per_lane;
+  wf_plan(t, work_total, n_ticks, n_lanes, per_lane);
+  if ((uint64_t)per_lane * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
   // path-state buffers are sized for the CONFIGURED batch at first use (not for this call's tick count):
   // a short warm-up call must not cause a reallocation inside a later, longer call
-  int rc = wf_ensure(t, batch * work_total);
-  if (batch > n_ticks) batch = n_ticks;
-  if (rc) return rc;
+  int rc = FSPT_OK;
+  for (uint32_t l = 0; l < n_lanes; ++l)
+    if ((rc = wf_ensure(t, t->lanes[l], per_lane * work_total))) return rc;
+  // a short call is still split over both lanes so that its two halves overlap
+  uint32_t batch = per_lane;
+  if (n_lanes == 2 && n_ticks < 2 * per_lane) batch = (n_ticks + 1) / 2;
+  if (batch < 1) batch = 1;
 
   fspt::WfP p{};
   p.scene = t->scene->d;
-  p.ray_o = (float4 *)t->wf_mem[0]; p.ray_d = (float4 *)t->wf_mem[1]; p.thr = (float4 *)t->wf_mem[2];
-  p.col = (float4 *)t->wf_mem[3]; p.shd = (float4 *)t->wf_mem[4]; p.pend = (float4 *)t->wf_mem[5];
-  p.hit = (float2 *)t->wf_mem[6]; p.shadow_hit = (int *)t->wf_mem[7];
-  p.q_ext[0] = (uint32_t *)t->wf_mem[8]; p.q_ext[1] = (uint32_t *)t->wf_mem[9];
-  p.q_shd[0] = (uint32_t *)t->wf_mem[10]; p.q_shd[1] = (uint32_t *)t->wf_mem[11];
-  p.fin = (float4 *)t->wf_mem[12];
-  p.counts = t->wf_counts;
   p.W = t->W; p.H = t->H; p.work_total = work_total;
   p.env_theta = cam->env_theta; p.num_bounces = cam->num_bounces;
   std::memcpy(p.cam.P, cam->P, 12); std::memcpy(p.cam.I, cam->I, 12);
@@ -462,21 +488,34 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
   const bool gen = !rays_from_buffers;
   const uint32_t nb = cam->num_bounces;
 
-  auto launch = [&](int kind) -> int {
-    int e = ev_begin(t, kind);
-    hipError_t err = fspt::launch_wf(kind, p, gen, t->count, cus, t->stream);
-    ev_end(t, e);
-    if (err != hipSuccess) { fspt_set_error("wavefront launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
-    return FSPT_OK;
-  };
+  // everything already queued on the target's stream (clear, ray upload, earlier renders) comes first
+  HIP_TRY(hipEventRecord(t->ev_start, t->stream));
+  for (uint32_t l = 0; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(t->lanes[l].stream, t->ev_start, 0));
 
-  uint32_t done = 0;
+  uint32_t done = 0, bi = 0;
+  fspt_target::WfLane *prev = nullptr;
   while (done < n_ticks) {
+    fspt_target::WfLane &ln = t->lanes[bi % n_lanes];
+    hipStream_t st = ln.stream;
+    auto launch = [&](int kind) -> int {
+      int e = ev_begin(t, kind, st);
+      hipError_t err = fspt::launch_wf(kind, p, gen, t->count, cus, st);
+      ev_end(t, e, st);
+      if (err != hipSuccess) { fspt_set_error("wavefront launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
+      return FSPT_OK;
+    };
+    p.ray_o = (float4 *)ln.mem[0]; p.ray_d = (float4 *)ln.mem[1]; p.thr = (float4 *)ln.mem[2];
+    p.col = (float4 *)ln.mem[3]; p.shd = (float4 *)ln.mem[4]; p.pend = (float4 *)ln.mem[5];
+    p.hit = (float2 *)ln.mem[6]; p.shadow_hit = (int *)ln.mem[7];
+    p.q_ext[0] = (uint32_t *)ln.mem[8]; p.q_ext[1] = (uint32_t *)ln.mem[9];
+    p.q_shd[0] = (uint32_t *)ln.mem[10]; p.q_shd[1] = (uint32_t *)ln.mem[11];
+    p.fin = (float4 *)ln.mem[12];
+    p.counts = ln.counts;
     uint32_t nbt = n_ticks - done < batch ? n_ticks - done : batch;
     p.n_batch = nbt;
     p.first_tick = first_tick + done;
     for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
-    HIP_TRY(hipMemsetAsync(t->wf_counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), t->stream));
+    HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
     p.round = 0;
     if ((rc = launch(fspt::WF_K_GEN))) return rc;
     if ((rc = launch(fspt::WF_K_TRACE))) return rc;
@@ -491,17 +530,23 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     if (t->scene->has_dielectric) {
       for (; r < WF_ROUNDS_MAX; ++r) {
         fspt::WfCounts c;
-        HIP_TRY(hipMemcpyAsync(&c, t->wf_counts + (r - 1), sizeof(c), hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
+        HIP_TRY(hipMemcpyAsync(&c, ln.counts + (r - 1), sizeof(c), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
         if (c.n_ext == 0) break;
         p.round = r;
         if ((rc = launch(fspt::WF_K_LOGIC))) return rc;
         if ((rc = launch(fspt::WF_K_TRACE))) return rc;
       }
     }
+    // the running mean is order-dependent (tracer.fs:517): resolves run in tick order across the lanes
+    if (prev) HIP_TRY(hipStreamWaitEvent(st, prev->resolved, 0));
     if ((rc = launch(fspt::WF_K_RESOLVE))) return rc;
+    HIP_TRY(hipEventRecord(ln.resolved, st));
+    prev = &ln;
     done += nbt;
+    ++bi;
   }
+  if (prev) HIP_TRY(hipStreamWaitEvent(t->stream, prev->resolved, 0)); // the resolves are chained: the last one ends it all
   return FSPT_OK;
 }
 
@@ -623,9 +668,10 @@ int fspt_last_kernel_ms(fspt_target *t, float *ms, uint32_t *launches) {
 
 int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks) {
   if (!t) { fspt_set_error("fspt_target_set_pipeline: NULL target"); return FSPT_E_INVALID; }
-  if (pipeline != 0 && pipeline != 1) { fspt_set_error("pipeline must be 0 (megakernel) or 1 (wavefront)"); return FSPT_E_INVALID; }
+  if (pipeline < 0 || pipeline > 2) { fspt_set_error("pipeline must be 0 (megakernel), 1 (wavefront) or 2 (wavefront, two lanes)"); return FSPT_E_INVALID; }
   if (batch_ticks > (uint32_t)fspt::WF_MAX_BATCH) { fspt_set_error("batch_ticks must be <= %d", fspt::WF_MAX_BATCH); return FSPT_E_INVALID; }
-  t->pipeline = pipeline;
+  t->pipeline = pipeline == 2 ? 1 : pipeline;
+  t->n_lanes = pipeline == 2 ? 2u : 1u;
   if (batch_ticks) t->batch_ticks = batch_ticks;
   return FSPT_OK;
 }
@@ -638,14 +684,13 @@ int fspt_target_prepare(fspt_target *t) {
   fill_trace_params(t, tp);
   const uint64_t work_total = (uint64_t)tp.n_owned_tiles * tp.tile * tp.tile;
   if (work_total == 0) return FSPT_OK;
-  uint64_t batch = t->batch_ticks;
-  uint64_t fit = WF_SLOT_BUDGET / work_total;
-  if (fit < 1) fit = 1;
-  if (batch > fit) batch = fit;
-  if (batch * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
-  int rc = wf_ensure(t, (uint32_t)(batch * work_total));
-  if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(t->stream));
+  uint32_t n_lanes, per_lane;
+  wf_plan(t, work_total, 0, n_lanes, per_lane);
+  if ((uint64_t)per_lane * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
+  for (uint32_t l = 0; l < n_lanes; ++l) {
+    int rc = wf_ensure(t, t->lanes[l], (uint32_t)(per_lane * work_total));
+    if (rc) return rc;
+  }
   return FSPT_OK;
 }
 

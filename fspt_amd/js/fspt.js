@@ -162,7 +162,7 @@ class PathTracer {
       !!denoise, maxSigma === undefined ? 3 : maxSigma, out);
   }
   setShard(shard, nShards, tile) { addon.setShard(this._target, shard, nShards, tile || 32); }
-  setPipeline(name, batch) { addon.setPipeline(this._target, name === 'megakernel' ? 0 : 1, batch || 0); }
+  setPipeline(name, batch) { addon.setPipeline(this._target, name === 'megakernel' ? 0 : (name === 'wavefront2' ? 2 : 1), batch || 0); }
   enableCounters(on) { addon.enableCounters(this._target, !!on); }
   counters() { return addon.counters(this._target); }
   close() { if (this._target) { addon.targetDestroy(this._target); addon.sceneDestroy(this._scene); this._target = null; } }

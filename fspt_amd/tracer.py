@@ -102,8 +102,9 @@ class PathTracer:
         L.check(L.lib().fspt_target_bind_accumulator(self._t, C.c_void_p(device_ptr)))
 
     def set_pipeline(self, pipeline, batch_ticks=0):
-        """'wavefront' (default) or 'megakernel'; results are bit-identical."""
-        code = {"megakernel": 0, "wavefront": 1}.get(pipeline, pipeline)
+        """'wavefront' (default), 'megakernel' or 'wavefront2' (two overlapped half-batches);
+        results are bit-identical."""
+        code = {"megakernel": 0, "wavefront": 1, "wavefront2": 2}.get(pipeline, pipeline)
         L.check(L.lib().fspt_target_set_pipeline(self._t, int(code), int(batch_ticks)))
 
     def prepare(self):

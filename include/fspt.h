@@ -157,7 +157,9 @@ float fspt_rand_base_next(uint64_t *state);
 /* Execution strategy of fspt_trace / fspt_render (results are bit-identical):
  *   pipeline 1 (default) "wavefront": gen -> [trace <-> logic] x rounds -> resolve, queue-driven
  *              kernels over batch_ticks ticks at a time (0 keeps the current batch size, max 64);
- *   pipeline 0 "megakernel": one persistent kernel per tick (path regeneration). */
+ *   pipeline 0 "megakernel": one persistent kernel per tick (path regeneration);
+ *   pipeline 2 "wavefront, two lanes": pipeline 1 with the batch split in two halves that run
+ *              concurrently on two HIP streams (separate path state, resolves chained in tick order). */
 int fspt_target_set_pipeline(fspt_target *target, int pipeline, uint32_t batch_ticks);
 /* Allocate (and touch) the pipeline's path-state buffers for the current resolution / shard / batch now,
  * instead of lazily inside the first fspt_trace / fspt_render.  Blocking. */

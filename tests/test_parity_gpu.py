@@ -92,7 +92,8 @@ def test_trace_two_call_bitwise(small_scene, camera, bounces, pipeline):
     assert pt.counters() == oc.as_dict()
 
 
-@pytest.mark.parametrize("pipeline,batch", [("wavefront", 0), ("wavefront", 2), ("wavefront", 64), ("megakernel", 0)])
+@pytest.mark.parametrize("pipeline,batch", [("wavefront", 0), ("wavefront", 2), ("wavefront", 64), ("megakernel", 0),
+                                            ("wavefront2", 0), ("wavefront2", 2), ("wavefront2", 3)])
 def test_render_fused_bitwise(medium_scene, camera, pipeline, batch):
     """fspt_render (ray generation fused into the path kernels) == oracle tick loop, for both
     execution strategies and for batches smaller / larger than the tick count."""
@@ -158,7 +159,7 @@ def test_trace_before_rays_is_state_error(small_scene):
     assert e.value.code == -6
 
 
-@pytest.mark.parametrize("pipeline", PIPELINES)
+@pytest.mark.parametrize("pipeline", PIPELINES + ["wavefront2"])
 def test_refractive_scene_bitwise(pipeline):
     """Dielectric material (tracer.fs:481-488: refraction does `i--`, so paths outlive NUM_BOUNCES
     rounds) + mesh normals + metallic: the reference-JS-built 'variant' golden scene."""
