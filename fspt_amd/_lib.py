@@ -57,6 +57,22 @@ class PropDesc(C.Structure):
     ]
 
 
+class WorldTransform(C.Structure):
+    _fields_ = [
+        ("rotate", C.POINTER(C.c_double)), ("n_rotate", C.c_uint32), ("has_rotate", C.c_uint32),
+        ("translate", C.c_double * 3), ("has_translate", C.c_uint32),
+    ]
+
+
+class GroupMaterial(C.Structure):
+    _fields_ = [
+        ("diffuse_layer", C.c_double), ("emissive_layer", C.c_double),
+        ("normal_layer", C.c_double), ("mr_layer", C.c_double),
+        ("emittance", C.c_double * 3),
+        ("ior", C.c_double), ("dielectric", C.c_double),
+    ]
+
+
 # every symbol include/fspt.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 _F = C.POINTER(C.c_float)
@@ -92,8 +108,15 @@ SIGNATURES = {
     "fspt_builder_create": (C.c_int, [C.POINTER(_VP)]),
     "fspt_builder_destroy": (C.c_int, [_VP]),
     "fspt_builder_add_obj": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(PropDesc)]),
+    "fspt_builder_parse_obj": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(PropDesc), C.POINTER(WorldTransform),
+                                         C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _U32]),
+    "fspt_builder_group_info": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_char_p), _U32, C.POINTER(C.c_int32)]),
+    "fspt_builder_mtllib_name": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_char_p)]),
+    "fspt_builder_commit_obj": (C.c_int, [_VP, C.POINTER(GroupMaterial), C.c_uint32]),
+    "fspt_builder_normalize": (C.c_int, [_VP, C.c_double]),
     "fspt_builder_build": (C.c_int, [_VP, C.c_uint32]),
     "fspt_builder_counts": (C.c_int, [_VP, _U32, _U32, _U32]),
+    "fspt_builder_autofocus": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fspt_builder_get": (C.c_int, [_VP, _F, _F, _F, _F, _F]),
     "fspt_env_bins": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, _U32, C.c_uint32, _U32]),
     "fspt_last_error": (C.c_char_p, []),

@@ -134,24 +134,60 @@ std::vector<std::string> split_spaces(const std::string &line) {
 
 }  // namespace
 
+struct PendingGroup {
+  std::string name;
+  std::vector<Tri> tris;
+  int32_t mtllib = -1;  // ordinal of the latest `mtllib` line seen when the group was created (-1: none)
+};
+
 struct fspt_builder {
   std::vector<Tri> geometry;
+  // groups of the OBJ parsed last, waiting for their materials (fspt_builder_commit_obj)
+  std::vector<PendingGroup> pending;
+  std::vector<std::string> mtllibs;
+  // scene bounds (main.js:310,317-318), for scene.normalize
+  Box bounds;
   // packed output
   std::vector<float> bvh, tri, mat, norm, uv;
   uint32_t n_nodes = 0, n_tris = 0, depth = 0;
   bool built = false;
+  // the built tree in float64 (for fspt_builder_autofocus): per node box, children, leaf triangle range in tri_order
+  struct HostNode { Box box; int left, right; uint32_t lo, hi; bool leaf; };
+  std::vector<HostNode> host_nodes;
+  std::vector<uint32_t> tri_order;
 };
 
 namespace {
 
 // ---- obj_loader.js parseMesh ------------------------------------------------
-int parse_obj(fspt_builder *B, const char *text, size_t len, const fspt_prop_desc *prop) {
+// An own property key that JS orders first, numerically (array index: canonical uint32 < 2^32 - 1)
+bool js_array_index(const std::string &k, uint64_t &val) {
+  if (k.empty() || k.size() > 10) return false;
+  if (k.size() > 1 && k[0] == '0') return false;
+  uint64_t v = 0;
+  for (char c : k) { if (c < '0' || c > '9') return false; v = v * 10 + (uint64_t)(c - '0'); }
+  if (v > 4294967294ull) return false;
+  val = v;
+  return true;
+}
+
+int parse_obj(fspt_builder *B, const char *text, size_t len, const fspt_prop_desc *prop,
+              const fspt_world_transform *world, uint32_t n_world, const char *const *skips, uint32_t n_skips) {
   std::vector<D3> vertices, mesh_normals;
   std::vector<std::pair<bool, std::pair<double, double>>> uvs;  // (defined, (u,v))
   std::vector<std::vector<D3>> vert_normals;
   std::vector<std::string> group_order;
   std::map<std::string, std::vector<Tri>> groups;
+  std::map<std::string, int32_t> group_mtllib;
   std::string current_group = "FSPT_DEFAULT_GROUP";
+  int32_t cur_mtllib = -1;
+  B->pending.clear();
+  B->mtllibs.clear();
+  auto skipped = [&](const std::string &g) {
+    for (uint32_t i = 0; i < n_skips; ++i) if (g == skips[i]) return true;
+    return false;
+  };
+  Box prop_bounds;  // parsed.bounds (obj_loader.js:17,137-142)
 
   auto apply_rotations = [&](D3 v) {
     for (uint32_t r = 0; r < prop->n_rotate; ++r) {
@@ -160,12 +196,24 @@ int parse_obj(fspt_builder *B, const char *text, size_t len, const fspt_prop_des
     }
     return v;
   };
-  // obj_loader.js:24-38 (worldTransforms not supported: none of the scenes use it)
+  // obj_loader.js:24-38
   auto apply_transforms = [&](D3 v, bool rotation_only) {
     D3 r = apply_rotations(v);
     D3 s = scale(r, rotation_only ? 1.0 : prop->scale);
     D3 t = rotation_only ? d3(0, 0, 0) : d3(prop->translate[0], prop->translate[1], prop->translate[2]);
-    return add(s, t);
+    D3 m = add(s, t);
+    for (uint32_t w = 0; w < n_world; ++w) {  // scene.worldTransforms: `if (rotate) ... else if (translate && !rotationOnly)`
+      const fspt_world_transform &wt = world[w];
+      if (wt.has_rotate) {
+        for (uint32_t r2 = 0; r2 < wt.n_rotate; ++r2) {
+          const double *q = wt.rotate + 4 * r2;
+          m = rotate_arbitrary(m, d3(q[0], q[1], q[2]), q[3]);
+        }
+      } else if (wt.has_translate && !rotation_only) {
+        m = add(m, d3(wt.translate[0], wt.translate[1], wt.translate[2]));
+      }
+    }
+    return m;
   };
 
   struct Idx { double v, t, n; };
@@ -191,6 +239,10 @@ int parse_obj(fspt_builder *B, const char *text, size_t len, const fspt_prop_des
       tri.uv[i][1] = ok ? uvs[(size_t)ti].second.second : std::numeric_limits<double>::quiet_NaN();
     }
     for (int i = 0; i < 3; ++i) tri.box.add_vertex(tri.v[i]);
+    for (int i = 0; i < 3; ++i) {  // Vec3.max(bounds.max, vert) / Vec3.min(bounds.min, vert)
+      prop_bounds.mx = d3(jsmax(prop_bounds.mx.x, tri.v[i].x), jsmax(prop_bounds.mx.y, tri.v[i].y), jsmax(prop_bounds.mx.z, tri.v[i].z));
+      prop_bounds.mn = d3(jsmin(prop_bounds.mn.x, tri.v[i].x), jsmin(prop_bounds.mn.y, tri.v[i].y), jsmin(prop_bounds.mn.z, tri.v[i].z));
+    }
     if (prop->normals_mode == 2) {  // "mesh", obj_loader.js:144-149
       for (int i = 0; i < 3; ++i) {
         double ni = ind[i]->n - 1;
@@ -210,7 +262,6 @@ int parse_obj(fspt_builder *B, const char *text, size_t len, const fspt_prop_des
         vert_normals[vi].push_back(nrm);
       }
     }
-    if (!groups.count(current_group)) { groups[current_group]; group_order.push_back(current_group); }
     groups[current_group].push_back(std::move(tri));
     return 0;
   };
@@ -229,7 +280,13 @@ int parse_obj(fspt_builder *B, const char *text, size_t len, const fspt_prop_des
       for (int i = 0; i < 3; ++i)
         c[i] = (a.size() > (size_t)(1 + i)) ? js_parse_float(a[1 + i]) : std::numeric_limits<double>::quiet_NaN();
       vertices.push_back(d3(c[0], c[1], c[2]));
-    } else if (key == "f") {
+    } else if (key == "f" && !skipped(current_group)) {
+      // obj_loader.js:170-172: the group (and its material, from the mtllib seen so far) is created by its first face
+      if (!groups.count(current_group)) {
+        groups[current_group];
+        group_order.push_back(current_group);
+        group_mtllib[current_group] = cur_mtllib;
+      }
       std::vector<Idx> fi;
       for (size_t k = 1; k < a.size(); ++k) {
         const std::string &s = a[k];
@@ -272,8 +329,28 @@ int parse_obj(fspt_builder *B, const char *text, size_t len, const fspt_prop_des
       std::string name;
       for (size_t k = 1; k < a.size(); ++k) { if (k > 1) name += ' '; name += a[k]; }
       current_group = name;
+    } else if (key == "mtllib") {
+      // the library's text is read and resolved by the host (mtl_loader.js, getMaterial main.js:206-270);
+      // the builder reports which library was current when each group was created
+      std::string name;
+      for (size_t k = 1; k < a.size(); ++k) { if (k > 1) name += ' '; name += a[k]; }
+      B->mtllibs.push_back(name);
+      cur_mtllib = (int32_t)B->mtllibs.size() - 1;
     }
-    // mtllib: material libraries are resolved by the host (getMaterial, main.js:206-270)
+  }
+
+  // Object.entries(groups) order: array-index keys ascending, then the rest in insertion order
+  {
+    std::vector<std::pair<uint64_t, std::string>> numeric;
+    std::vector<std::string> rest;
+    for (auto &g : group_order) {
+      uint64_t v;
+      if (js_array_index(g, v)) numeric.push_back({v, g}); else rest.push_back(g);
+    }
+    std::sort(numeric.begin(), numeric.end());
+    group_order.clear();
+    for (auto &pr : numeric) group_order.push_back(pr.second);
+    for (auto &g : rest) group_order.push_back(g);
   }
 
   // smooth normals, obj_loader.js:194-203 (average is NOT re-normalised)
@@ -325,15 +402,33 @@ int parse_obj(fspt_builder *B, const char *text, size_t len, const fspt_prop_des
         t.tangents.push_back(tangent);
         t.bitangents.push_back(bitangent);
       }
-      // material record, main.js:376-382
-      double m[12] = {prop->diffuse_layer, prop->emissive_layer, prop->normal_layer, prop->mr_layer, 0, 0,
-                      prop->emittance[0], prop->emittance[1], prop->emittance[2], prop->ior, prop->dielectric, 0};
-      std::memcpy(t.mat, m, sizeof(m));
     }
 
-  for (auto &gname : group_order)
-    for (auto &t : groups[gname]) B->geometry.push_back(std::move(t));
+  for (auto &gname : group_order) {
+    PendingGroup pg;
+    pg.name = gname;
+    pg.tris = std::move(groups[gname]);
+    pg.mtllib = group_mtllib[gname];
+    B->pending.push_back(std::move(pg));
+  }
+  // main.js:317-318: bounds.addVertex(parsed.bounds.max); bounds.addVertex(parsed.bounds.min)
+  B->bounds.add_vertex(prop_bounds.mx);
+  B->bounds.add_vertex(prop_bounds.mn);
   return 0;
+}
+
+// main.js:326-334 + 376-382: every triangle of a group gets the group's material record
+void commit_groups(fspt_builder *B, const fspt_group_material *mats) {
+  for (size_t g = 0; g < B->pending.size(); ++g) {
+    const fspt_group_material &gm = mats[g];
+    double m[12] = {gm.diffuse_layer, gm.emissive_layer, gm.normal_layer, gm.mr_layer, 0, 0,
+                    gm.emittance[0], gm.emittance[1], gm.emittance[2], gm.ior, gm.dielectric, 0};
+    for (auto &t : B->pending[g].tris) {
+      std::memcpy(t.mat, m, sizeof(m));
+      B->geometry.push_back(std::move(t));
+    }
+  }
+  B->pending.clear();
 }
 
 // ---- bvh.js --------------------------------------------------------------
@@ -455,16 +550,76 @@ int fspt_builder_destroy(fspt_builder *b) {
   return FSPT_OK;
 }
 
-int fspt_builder_add_obj(fspt_builder *b, const char *obj_text, size_t len, const fspt_prop_desc *prop) {
-  if (!b || !obj_text || !prop) { fspt_set_error("fspt_builder_add_obj: NULL argument"); return FSPT_E_INVALID; }
-  if (prop->n_rotate && !prop->rotate) { fspt_set_error("fspt_builder_add_obj: rotate is NULL"); return FSPT_E_INVALID; }
+int fspt_builder_parse_obj(fspt_builder *b, const char *obj_text, size_t len, const fspt_prop_desc *prop,
+                           const fspt_world_transform *world, uint32_t n_world, const char *const *skips,
+                           uint32_t n_skips, uint32_t *n_groups) {
+  if (!b || !obj_text || !prop) { fspt_set_error("fspt_builder_parse_obj: NULL argument"); return FSPT_E_INVALID; }
+  if (prop->n_rotate && !prop->rotate) { fspt_set_error("fspt_builder_parse_obj: rotate is NULL"); return FSPT_E_INVALID; }
+  if ((n_world && !world) || (n_skips && !skips)) { fspt_set_error("fspt_builder_parse_obj: NULL world / skips"); return FSPT_E_INVALID; }
+  for (uint32_t w = 0; w < n_world; ++w)
+    if (world[w].has_rotate && world[w].n_rotate && !world[w].rotate) { fspt_set_error("fspt_builder_parse_obj: world rotate is NULL"); return FSPT_E_INVALID; }
+  if (!b->pending.empty()) { fspt_set_error("fspt_builder_parse_obj: the previous OBJ was not committed"); return FSPT_E_STATE; }
   b->built = false;
-  return parse_obj(b, obj_text, len, prop);
+  int rc = parse_obj(b, obj_text, len, prop, world, n_world, skips, n_skips);
+  if (rc) { b->pending.clear(); return rc; }
+  if (n_groups) *n_groups = (uint32_t)b->pending.size();
+  return FSPT_OK;
+}
+
+int fspt_builder_group_info(const fspt_builder *b, uint32_t group, const char **name, uint32_t *n_tris, int32_t *mtllib) {
+  if (!b || group >= b->pending.size()) { fspt_set_error("fspt_builder_group_info: no such pending group"); return FSPT_E_INVALID; }
+  if (name) *name = b->pending[group].name.c_str();
+  if (n_tris) *n_tris = (uint32_t)b->pending[group].tris.size();
+  if (mtllib) *mtllib = b->pending[group].mtllib;
+  return FSPT_OK;
+}
+
+int fspt_builder_mtllib_name(const fspt_builder *b, uint32_t index, const char **name) {
+  if (!b || !name || index >= b->mtllibs.size()) { fspt_set_error("fspt_builder_mtllib_name: no such mtllib"); return FSPT_E_INVALID; }
+  *name = b->mtllibs[index].c_str();
+  return FSPT_OK;
+}
+
+int fspt_builder_commit_obj(fspt_builder *b, const fspt_group_material *mats, uint32_t n_groups) {
+  if (!b) { fspt_set_error("fspt_builder_commit_obj: NULL builder"); return FSPT_E_INVALID; }
+  if (n_groups != b->pending.size()) { fspt_set_error("fspt_builder_commit_obj: %u materials for %zu pending groups", n_groups, b->pending.size()); return FSPT_E_INVALID; }
+  if (n_groups && !mats) { fspt_set_error("fspt_builder_commit_obj: mats is NULL"); return FSPT_E_INVALID; }
+  commit_groups(b, mats);
+  return FSPT_OK;
+}
+
+int fspt_builder_add_obj(fspt_builder *b, const char *obj_text, size_t len, const fspt_prop_desc *prop) {
+  uint32_t ng = 0;
+  int rc = fspt_builder_parse_obj(b, obj_text, len, prop, nullptr, 0, nullptr, 0, &ng);
+  if (rc) return rc;
+  fspt_group_material gm;
+  gm.diffuse_layer = prop->diffuse_layer; gm.emissive_layer = prop->emissive_layer;
+  gm.normal_layer = prop->normal_layer; gm.mr_layer = prop->mr_layer;
+  gm.emittance[0] = prop->emittance[0]; gm.emittance[1] = prop->emittance[1]; gm.emittance[2] = prop->emittance[2];
+  gm.ior = prop->ior; gm.dielectric = prop->dielectric;
+  std::vector<fspt_group_material> mats(ng, gm);
+  return fspt_builder_commit_obj(b, mats.data(), ng);
+}
+
+// main.js:337-348: `scene.normalize`: centre the scene and scale its longest side to 2 * size.  Only the vertices
+// move; the per-triangle boxes the SAH sweeps and the centroid sort use stay as built (bvh.js:204), as in the reference.
+int fspt_builder_normalize(fspt_builder *b, double size) {
+  if (!b) { fspt_set_error("fspt_builder_normalize: NULL builder"); return FSPT_E_INVALID; }
+  if (!b->pending.empty()) { fspt_set_error("fspt_builder_normalize: an OBJ is waiting for fspt_builder_commit_obj"); return FSPT_E_STATE; }
+  D3 diff = sub(b->bounds.mx, b->bounds.mn);
+  double longest = jsmax(jsmax(diff.x, diff.y), diff.z);
+  D3 centroid = b->bounds.centroid();
+  double sc = 2 * size / longest;
+  for (auto &t : b->geometry)
+    for (int j = 0; j < 3; ++j) t.v[j] = scale(sub(t.v[j], centroid), sc);
+  b->built = false;
+  return FSPT_OK;
 }
 
 int fspt_builder_build(fspt_builder *b, uint32_t leaf_size) {
   if (!b) { fspt_set_error("fspt_builder_build: NULL builder"); return FSPT_E_INVALID; }
   if (leaf_size == 0) { fspt_set_error("fspt_builder_build: leaf_size must be >= 1"); return FSPT_E_INVALID; }
+  if (!b->pending.empty()) { fspt_set_error("fspt_builder_build: an OBJ is waiting for fspt_builder_commit_obj"); return FSPT_E_STATE; }
   if (b->geometry.empty()) { fspt_set_error("fspt_builder_build: no triangles"); return FSPT_E_INVALID; }
   BvhBuilder bb(b->geometry, leaf_size);
   bb.build();
@@ -508,7 +663,84 @@ int fspt_builder_build(fspt_builder *b, uint32_t leaf_size) {
   b->n_nodes = (uint32_t)nn;
   b->n_tris = (uint32_t)nt;
   b->depth = bb.depth;
+  b->host_nodes.resize(nn);
+  for (size_t i = 0; i < nn; ++i) {
+    const BuildNode &nd = bb.nodes[i];
+    b->host_nodes[i] = fspt_builder::HostNode{nd.box, nd.left, nd.right, nd.lo, nd.hi, nd.leaf};
+  }
+  b->tri_order = bb.idx[0];
   b->built = true;
+  return FSPT_OK;
+}
+
+// shootAutoFocusRay (main.js:447-546): the distance along (eye, dir) to the first triangle, found on the host
+// BVH in float64; main.js then sets lensFeatures[0] = 1 - 1 / dist.  1e6 (maxT) when nothing is hit.
+int fspt_builder_autofocus(const fspt_builder *b, const double eye_[3], const double dir_[3], double *dist) {
+  if (!b || !b->built) { fspt_set_error("fspt_builder_autofocus: builder not built"); return FSPT_E_STATE; }
+  if (!eye_ || !dir_ || !dist) { fspt_set_error("fspt_builder_autofocus: NULL argument"); return FSPT_E_INVALID; }
+  const double maxT = 1e6;
+  const D3 eye = d3(eye_[0], eye_[1], eye_[2]), dir = d3(dir_[0], dir_[1], dir_[2]);
+  auto ray_tri = [&](const Tri &tri) -> double {  // main.js:448-473
+    const double epsilon = 0.000000000001;
+    D3 e1 = sub(tri.v[1], tri.v[0]), e2 = sub(tri.v[2], tri.v[0]);
+    D3 p = cross(dir, e2);
+    double det = dot(e1, p);
+    if (det > -epsilon && det < epsilon) return maxT;
+    double invDet = 1.0 / det;
+    D3 t = sub(eye, tri.v[0]);
+    double u = dot(t, p) * invDet;
+    if (u < 0 || u > 1) return maxT;
+    D3 q = cross(t, e1);
+    double v = dot(dir, q) * invDet;
+    if (v < 0 || u + v > 1) return maxT;
+    double tt = dot(e2, q) * invDet;
+    if (tt > epsilon) return tt;
+    return maxT;
+  };
+  auto ray_box = [&](const Box &bx) -> double {  // main.js:487-504
+    D3 inv = d3(1 / dir.x, 1 / dir.y, 1 / dir.z);  // Vec3.inverse
+    double tx1 = (bx.mn.x - eye.x) * inv.x, tx2 = (bx.mx.x - eye.x) * inv.x;
+    double ty1 = (bx.mn.y - eye.y) * inv.y, ty2 = (bx.mx.y - eye.y) * inv.y;
+    double tz1 = (bx.mn.z - eye.z) * inv.z, tz2 = (bx.mx.z - eye.z) * inv.z;
+    double tmin = jsmin(tx1, tx2), tmax = jsmax(tx1, tx2);
+    tmin = jsmax(tmin, jsmin(ty1, ty2)); tmax = jsmin(tmax, jsmax(ty1, ty2));
+    tmin = jsmax(tmin, jsmin(tz1, tz2)); tmax = jsmin(tmax, jsmax(tz1, tz2));
+    return (tmax >= tmin && tmax >= 0) ? tmin : maxT;
+  };
+  // findTriangles (main.js:531-542), explicit stack instead of recursion; `closest` is threaded through
+  struct Frame { int node; int stage; int ord[2]; double t[2]; };
+  std::vector<Frame> st;
+  double closest = maxT;
+  // recursion returns a value that is min-ed into the caller's `closest`; since every callee starts from the
+  // caller's current `closest` and only lowers it, one running minimum is equivalent
+  st.push_back(Frame{0, 0, {-1, -1}, {0, 0}});
+  while (!st.empty()) {
+    Frame &f = st.back();
+    const fspt_builder::HostNode &nd = b->host_nodes[(size_t)f.node];
+    if (nd.leaf) {
+      double res = maxT;  // processLeaf: the leaf's closest hit, then Math.min(res, closest)
+      for (uint32_t k = nd.lo; k < nd.hi; ++k) {
+        double tmp = ray_tri(b->geometry[b->tri_order[k]]);
+        if (tmp < res) res = tmp;
+      }
+      closest = jsmin(res, closest);
+      st.pop_back();
+      continue;
+    }
+    if (f.stage == 0) {  // closestNode (main.js:506-529)
+      double tl = ray_box(b->host_nodes[(size_t)nd.left].box), tr = ray_box(b->host_nodes[(size_t)nd.right].box);
+      int left = tl < maxT ? nd.left : -1, right = tr < maxT ? nd.right : -1;
+      if (tl < tr) { f.ord[0] = left; f.t[0] = tl; f.ord[1] = right; f.t[1] = tr; }
+      else { f.ord[0] = right; f.t[0] = tr; f.ord[1] = left; f.t[1] = tl; }
+    }
+    if (f.stage >= 2) { st.pop_back(); continue; }
+    int i = f.stage++;
+    if (f.ord[i] >= 0 && f.t[i] < closest) {
+      int child = f.ord[i];
+      st.push_back(Frame{child, 0, {-1, -1}, {0, 0}});  // invalidates f; not used after this point
+    }
+  }
+  *dist = closest;
   return FSPT_OK;
 }
 

@@ -83,6 +83,7 @@ class TexturePacker:
         self.res = atlas_res
         self.image_set = []
         self.image_keys = {}
+        self.images = {}
         self.max_res = 1
 
     def _add(self, key, item):
@@ -102,15 +103,39 @@ class TexturePacker:
         self.max_res = max(self.max_res, rgba.shape[0])
         return self._add(key, ("pixels", rgba))
 
-    def add_texture(self, key, rgba, corrected=False, swizzle=None):
+    _KEEP = object()
+
+    def add_texture(self, key, rgba, corrected=False, swizzle=_KEEP):
         """addTexture (texture_packer.js:13-24): a decoded image, uint8 [h, w, 4] with row 0 = top as an
         HTMLImageElement uploads; key plays the role of image.currentSrc.  corrected = sRGB-decode (diffuse
-        maps, main.js:214-219); swizzle = mrSwizzle / pmr_swizzle (main.js:226-236)."""
-        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        maps, main.js:214-219), fixed by the FIRST add of the image.  swizzle = mrSwizzle / pmr_swizzle: the
+        reference stores it on the shared image object BEFORE de-duplicating (main.js:226-236) and reads it
+        when the atlas is written, so the LAST metallic-roughness use of an image decides (None = identity);
+        other uses leave it alone."""
+        ent = self.images.get(key)
+        if ent is None:
+            ent = self.images[key] = {"rgba": np.ascontiguousarray(rgba, dtype=np.uint8), "corrected": None, "swizzle": None}
+        if swizzle is not TexturePacker._KEEP:
+            ent["swizzle"] = None if swizzle is None else tuple(int(x) for x in swizzle)
         if self.image_keys.get(key):
             return self.image_keys[key]
-        self.max_res = max(self.max_res, rgba.shape[0])
-        return self._add(key, ("image", (rgba, bool(corrected), tuple(swizzle) if swizzle else (0, 1, 2, 3))))
+        self.max_res = max(self.max_res, ent["rgba"].shape[0])
+        ent["corrected"] = bool(corrected)  # `image.corrected = corrected` on every real insertion (layer 0 re-adds)
+        return self._add(key, ("image", ent))
+
+    def describe(self):
+        """Layer list in the form tools/js_ref dumps the reference's imageSet."""
+        out = []
+        for kind, item in self.image_set:
+            if kind == "color":
+                out.append({"color": list(item)})
+            elif kind == "image":
+                key = [k for k, v in self.images.items() if v is item][0]
+                out.append({"src": key, "corrected": bool(item["corrected"]),
+                            "swizzle": list(item["swizzle"]) if item["swizzle"] else None})
+            else:
+                out.append({"pixels": True})
+        return out
 
     def get_resolution(self):
         if self.max_res < self.res:
@@ -126,7 +151,7 @@ class TexturePacker:
                 px = [int(math.floor(min(max(c, 0.0), 1.0) * 255.0 + 0.5)) for c in item[:3]] + [255]
                 out[i, :, :, :] = np.array(px, dtype=np.uint8)
             elif kind == "image":
-                out[i] = resample_image(item[0], res, item[1], item[2])
+                out[i] = resample_image(item["rgba"], res, item["corrected"], item["swizzle"] or (0, 1, 2, 3))
             else:
                 if item.shape[0] != res or item.shape[1] != res:
                     raise ValueError("pre-resampled image must be res x res")
@@ -162,27 +187,113 @@ def resample_image(rgba, res, corrected=False, swizzle=(0, 1, 2, 3)):
     return np.clip(np.floor(out * 255.0 + 0.5), 0, 255).astype(np.uint8)
 
 
-def get_material(prop, packer, images=None):
-    """getMaterial (main.js:206-270).  Colour-valued maps become flat layers; string-valued maps name an
-    entry of `images` ({path: uint8 [h, w, 4], row 0 = top}) and become resampled image layers (diffuse maps
-    sRGB-decoded, main.js:214-219; metallicRoughness honours mrSwizzle, main.js:232-236)."""
-    images = images or {}
+def _js_parse_float(tok):
+    """parseFloat: longest numeric prefix, NaN when none."""
+    import re
+    m = re.match(r"\s*[+-]?(Infinity|(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?))", tok or "")
+    if not m:
+        return float("nan")
+    try:
+        return float(m.group(0))
+    except ValueError:  # "1e" style prefixes: parseFloat backs off to the mantissa
+        m2 = re.match(r"\s*[+-]?(\d+\.?\d*|\.\d+)", tok)
+        return float(m2.group(0)) if m2 else float("nan")
 
-    def layer(value, default, corrected=False, swizzle=None):
-        if isinstance(value, str):
-            return packer.add_texture(value, images[value], corrected, swizzle)
-        if isinstance(value, (list, tuple)):
-            return packer.add_color(value)
-        return packer.add_color(default)
-    diffuse = layer(prop.get("diffuse"), [0.5, 0.5, 0.5], corrected=True)
-    rough = layer(prop.get("metallicRoughness"), [0.0, 0.3, 0], swizzle=prop.get("mrSwizzle"))
-    em = prop.get("emission")
-    spec = packer.add_texture(em, images[em]) if isinstance(em, str) else packer.add_color(
-        em if isinstance(em, (list, tuple)) else [0, 0, 0])
-    nm = prop.get("normal")
-    normal = packer.add_texture(nm, images[nm]) if isinstance(nm, str) else packer.add_color([0.5, 0.5, 1])
-    ior = prop.get("ior") or 1.4
-    dielectric = prop.get("dielectric") or -1
+
+def parse_materials(mtl_text, base_path):
+    """ParseMaterials (mtl_loader.js:3-43): {name: {key: value}} and the set of texture urls.
+    Values that are falsy in JS (0, NaN, empty) are dropped, as `if (value)` does."""
+    materials, urls = {}, []
+    scalar = {"ns", "ni", "d", "illum", "dielectric", "ior"}
+    vector = {"ka", "kd", "kem", "ks", "ke", "pr", "pm", "pmr", "pmr_swizzle"}
+    string = {"map_bump", "map_kd", "map_kem", "map_ks", "map_d", "map_ns", "map_pmr"}
+    name = None
+    for line in mtl_text.split("\n"):
+        tokens = _js_split_spaces(line)
+        key = tokens[0].lower()
+        if key == "newmtl":
+            name = tokens[1] if len(tokens) > 1 else None
+            if name is not None:
+                materials[name] = {}
+        if name:
+            value, is_url = None, False
+            if key in scalar:
+                value = _js_parse_float(tokens[1]) if len(tokens) > 1 else float("nan")
+                if value != value or value == 0:
+                    value = None
+            elif key in vector:
+                value = [_js_parse_float(t) for t in tokens[1:]]  # an array is always truthy
+            elif key in string:
+                value = tokens[1] if len(tokens) > 1 else None
+                is_url = True
+                if value == "":
+                    value = None
+            if value is not None:
+                if is_url and (base_path + "/" + value) not in urls:
+                    urls.append(base_path + "/" + value)
+                materials[name][key] = value
+    return materials, urls
+
+
+def _js_split_spaces(line):
+    """line.trim().split(/[ ]+/)"""
+    import re
+    return re.split(r"[ ]+", line.strip(" \t\r\n\f\v\ufeff\xa0"))
+
+
+def get_material(prop, packer, images=None, group_material=None, base_path=""):
+    """getMaterial (main.js:206-270) for one OBJ group: the group's MTL entry (map_kd / kd, map_pmr / pmr,
+    map_kem / kem, map_bump, ior, dielectric) wins over the prop's scene-JSON fields.  Colour-valued maps
+    become flat layers; string-valued maps name an entry of `images` ({path: uint8 [h, w, 4], row 0 = top})
+    and become resampled image layers (diffuse maps sRGB-decoded, main.js:214-219; metallicRoughness honours
+    pmr_swizzle / mrSwizzle, main.js:226-236)."""
+    images = images or {}
+    gm = group_material or {}
+
+    def tex(url, corrected=False, **kw):
+        if url not in images:
+            raise KeyError(f"texture {url!r} is not in `images`")
+        return packer.add_texture(url, images[url], corrected, **kw)
+
+    if gm.get("map_kd"):
+        diffuse = tex(base_path + "/" + gm["map_kd"], True)
+    elif gm.get("kd"):
+        diffuse = packer.add_color(gm["kd"])
+    elif isinstance(prop.get("diffuse"), str):
+        diffuse = tex(prop["diffuse"], True)
+    elif isinstance(prop.get("diffuse"), (list, tuple, dict)):
+        diffuse = packer.add_color(prop["diffuse"])
+    else:
+        diffuse = packer.add_color([0.5, 0.5, 0.5])
+
+    if gm.get("map_pmr"):
+        rough = tex(base_path + "/" + gm["map_pmr"], False, swizzle=gm.get("pmr_swizzle"))
+    elif gm.get("pmr"):
+        rough = packer.add_color(gm["pmr"])
+    elif isinstance(prop.get("metallicRoughness"), str):
+        rough = tex(prop["metallicRoughness"], False, swizzle=prop.get("mrSwizzle"))
+    elif isinstance(prop.get("metallicRoughness"), (list, tuple, dict)):
+        rough = packer.add_color(prop["metallicRoughness"])
+    else:
+        rough = packer.add_color([0.0, 0.3, 0])
+
+    if gm.get("map_kem"):
+        spec = tex(base_path + "/" + gm["map_kem"])
+    elif gm.get("kem"):
+        spec = packer.add_color(gm["kem"])
+    elif isinstance(prop.get("emission"), str):
+        spec = tex(prop["emission"])
+    else:  # an array-valued `emission` is ignored by the reference (main.js:249-253)
+        spec = packer.add_color([0, 0, 0])
+
+    if gm.get("map_bump"):
+        normal = tex(base_path + "/" + gm["map_bump"])
+    elif prop.get("normal"):
+        normal = tex(prop["normal"])
+    else:
+        normal = packer.add_color([0.5, 0.5, 1])
+    ior = gm.get("ior") or prop.get("ior") or 1.4
+    dielectric = gm.get("dielectric") or prop.get("dielectric") or -1
     return dict(diffuseIndex=diffuse, roughnessIndex=rough, specularIndex=spec, normalIndex=normal,
                 ior=float(ior), dielectric=float(dielectric), emittance=prop.get("emittance", [0, 0, 0]))
 
@@ -201,34 +312,77 @@ def env_bins(env_rgbe, w, h):
     return bins
 
 
-def build_scene(props, obj_texts, env=None, env_w=0, env_h=0, leaf_size=4, atlas_res=2048, images=None):
-    """initBVH (main.js:284-445) for props = list of scene-JSON prop dicts and
-    obj_texts = {path: OBJ text}.  env = RGBE uint8 [h*w*4] or None."""
+def _rot_array(rot):
+    flat = []
+    for r in rot:
+        flat += [float(r["axis"][0]), float(r["axis"][1]), float(r["axis"][2]), float(r["angle"])]
+    arr = (C.c_double * max(len(flat), 1))(*flat)
+    return arr, len(rot)
+
+
+def build_scene(props, obj_texts, env=None, env_w=0, env_h=0, leaf_size=4, atlas_res=2048, images=None,
+                world_transforms=None, normalize=None, mtl_texts=None, focus_rays=None):
+    """initBVH (main.js:284-445) for props = list of scene-JSON prop dicts and obj_texts = {path: OBJ text}.
+    env = RGBE uint8 [h*w*4] or None; world_transforms = scene.worldTransforms; normalize = scene.normalize;
+    mtl_texts = {url: MTL text} for `mtllib` lines (url = <dir of the OBJ>/<name>, obj_loader.js:186);
+    images = {url: decoded RGBA8 [h, w, 4], row 0 = top} for texture maps; focus_rays = [(eye, dir), ...] ->
+    meta["focus"] = shootAutoFocusRay's lensFeatures[0] = 1 - 1/dist for each (main.js:447-546)."""
     lib = L.lib()
     packer = TexturePacker(atlas_res)
+    focus = []
+    mtl_texts = mtl_texts or {}
     b = C.c_void_p()
     L.check(lib.fspt_builder_create(C.byref(b)))
+    keep = []
     try:
+        world = world_transforms or []
+        wt = (L.WorldTransform * max(len(world), 1))()
+        for i, t in enumerate(world):
+            if "rotate" in t and t["rotate"] is not None:  # `if (transform.rotate)`: an empty list is truthy
+                arr, n = _rot_array(t["rotate"])
+                keep.append(arr)
+                wt[i].rotate = C.cast(arr, C.POINTER(C.c_double)); wt[i].n_rotate = n; wt[i].has_rotate = 1
+            elif t.get("translate"):
+                wt[i].translate = (C.c_double * 3)(*[float(x) for x in t["translate"]]); wt[i].has_translate = 1
         for prop in props:
-            m = get_material(prop, packer, images)
             pd = L.PropDesc()
-            rot = prop.get("rotate", [])
-            flat = []
-            for r in rot:
-                flat += [float(r["axis"][0]), float(r["axis"][1]), float(r["axis"][2]), float(r["angle"])]
-            rot_arr = (C.c_double * max(len(flat), 1))(*flat)
+            rot_arr, n_rot = _rot_array(prop.get("rotate", []))
             pd.rotate = C.cast(rot_arr, C.POINTER(C.c_double))
-            pd.n_rotate = len(rot)
+            pd.n_rotate = n_rot
             pd.scale = float(prop.get("scale", 1.0))
             tr = prop.get("translate", [0, 0, 0])
             pd.translate = (C.c_double * 3)(*[float(x) for x in tr])
             pd.normals_mode = _NORMALS_MODE[prop.get("normals")]
-            pd.diffuse_layer = m["diffuseIndex"]; pd.emissive_layer = m["specularIndex"]
-            pd.normal_layer = m["normalIndex"]; pd.mr_layer = m["roughnessIndex"]
-            pd.emittance = (C.c_double * 3)(*[float(x) for x in m["emittance"]])
-            pd.ior = m["ior"]; pd.dielectric = m["dielectric"]
             text = obj_texts[prop["path"]].encode("utf-8")
-            L.check(lib.fspt_builder_add_obj(b, text, len(text), C.byref(pd)))
+            skips = [str(x).encode("utf-8") for x in (prop.get("skips") or [])]
+            skip_arr = (C.c_char_p * max(len(skips), 1))(*skips)
+            ng = C.c_uint32()
+            L.check(lib.fspt_builder_parse_obj(b, text, len(text), C.byref(pd), wt, len(world), skip_arr, len(skips),
+                                               C.byref(ng)))
+            base_path = "/".join(prop["path"].split("/")[:-1])
+            libs = {}
+            mats = (L.GroupMaterial * max(ng.value, 1))()
+            for g in range(ng.value):
+                name, nt, mi = C.c_char_p(), C.c_uint32(), C.c_int32()
+                L.check(lib.fspt_builder_group_info(b, g, C.byref(name), C.byref(nt), C.byref(mi)))
+                gm = {}
+                if mi.value >= 0:
+                    if mi.value not in libs:
+                        ln = C.c_char_p()
+                        L.check(lib.fspt_builder_mtllib_name(b, mi.value, C.byref(ln)))
+                        url = base_path + "/" + ln.value.decode("utf-8")
+                        if url not in mtl_texts:
+                            raise KeyError(f"mtllib {url!r} is not in `mtl_texts`")
+                        libs[mi.value] = parse_materials(mtl_texts[url], base_path)[0]
+                    gm = libs[mi.value].get(name.value.decode("utf-8"), {})
+                m = get_material(prop, packer, images, gm, base_path)
+                mats[g].diffuse_layer = m["diffuseIndex"]; mats[g].emissive_layer = m["specularIndex"]
+                mats[g].normal_layer = m["normalIndex"]; mats[g].mr_layer = m["roughnessIndex"]
+                mats[g].emittance = (C.c_double * 3)(*[float(x) for x in m["emittance"]])
+                mats[g].ior = m["ior"]; mats[g].dielectric = m["dielectric"]
+            L.check(lib.fspt_builder_commit_obj(b, mats, ng.value))
+        if normalize:
+            L.check(lib.fspt_builder_normalize(b, float(normalize)))
         L.check(lib.fspt_builder_build(b, leaf_size))
         nn, nt, dp = C.c_uint32(), C.c_uint32(), C.c_uint32()
         L.check(lib.fspt_builder_counts(b, C.byref(nn), C.byref(nt), C.byref(dp)))
@@ -236,6 +390,11 @@ def build_scene(props, obj_texts, env=None, env_w=0, env_h=0, leaf_size=4, atlas
         mat = np.zeros(nt.value * 12, np.float32); norm = np.zeros(nt.value * 27, np.float32)
         uv = np.zeros(nt.value * 6, np.float32)
         L.check(lib.fspt_builder_get(b, L.fptr(bvh), L.fptr(tri), L.fptr(mat), L.fptr(norm), L.fptr(uv)))
+        for eye, d in (focus_rays or []):
+            dist = C.c_double()
+            L.check(lib.fspt_builder_autofocus(b, (C.c_double * 3)(*[float(x) for x in eye]),
+                                               (C.c_double * 3)(*[float(x) for x in d]), C.byref(dist)))
+            focus.append(1 - 1 / dist.value)
     finally:
         lib.fspt_builder_destroy(b)
     atlas = packer.get_pixels()
@@ -246,7 +405,24 @@ def build_scene(props, obj_texts, env=None, env_w=0, env_h=0, leaf_size=4, atlas
         bins = np.array([0, 0, 1, 2048], dtype=np.uint32)  # main.js:292
     return SceneArrays(bvh=bvh, tri=tri, mat=mat, norm=norm, uv=uv, atlas=atlas, atlas_res=packer.res,
                        atlas_layers=len(packer.image_set), env=env, env_w=env_w, env_h=env_h, bins=bins,
-                       leaf_size=leaf_size, depth=dp.value)
+                       leaf_size=leaf_size, depth=dp.value, meta={"layers": packer.describe(), "focus": focus})
+
+
+def build_scene_json(scene, obj_texts, mtl_texts=None, images=None, env=None, env_w=0, env_h=0, leaf_size=4,
+                     focus_rays=None):
+    """build_scene for a whole scene JSON (props / static_props / animated_props, worldTransforms, normalize,
+    atlasRes: main.js:284-445,869-871,944)."""
+    return build_scene(merge_scene_props(scene), obj_texts, env=env, env_w=env_w, env_h=env_h, leaf_size=leaf_size,
+                       atlas_res=scene.get("atlasRes") or 2048, images=images,
+                       world_transforms=scene.get("worldTransforms"), normalize=scene.get("normalize"),
+                       mtl_texts=mtl_texts, focus_rays=focus_rays)
+
+
+def merge_scene_props(scene):
+    """mergeSceneProps (main.js:869-871): props + static_props + the values of animated_props."""
+    anim = scene.get("animated_props") or []
+    anim = list(anim.values()) if isinstance(anim, dict) else list(anim)
+    return list(scene.get("props") or []) + list(scene.get("static_props") or []) + anim
 
 
 # ---------------------------------------------------------------------------

@@ -242,17 +242,51 @@ typedef struct fspt_prop_desc {
   double ior, dielectric;
 } fspt_prop_desc;
 
+/* one element of scene.worldTransforms (obj_loader.js:26-36): `if (t.rotate) rotations (positions and
+ * normals) else if (t.translate) translation (positions only)`; has_rotate = the key is present. */
+typedef struct fspt_world_transform {
+  const double *rotate; /* n_rotate x 4: axis.x axis.y axis.z angle */
+  uint32_t n_rotate;
+  uint32_t has_rotate;
+  double translate[3];
+  uint32_t has_translate;
+} fspt_world_transform;
+
+/* getMaterial's result for one OBJ group (main.js:206-270, packed by main.js:376-382) */
+typedef struct fspt_group_material {
+  double diffuse_layer, emissive_layer, normal_layer, mr_layer;
+  double emittance[3];
+  double ior, dielectric;
+} fspt_group_material;
+
 int fspt_builder_create(fspt_builder **out);
 int fspt_builder_destroy(fspt_builder *b);
 /* parseMesh (obj_loader.js:6-215) for one prop: v / vt / vn / f lines, fan
  * triangulation, negative indices, per-prop transforms, normals, tangents. */
 int fspt_builder_add_obj(fspt_builder *b, const char *obj_text, size_t len,
                          const fspt_prop_desc *prop);
+/* The same in two steps, for OBJs whose groups (`usemtl`) carry their own materials (mtl_loader.js,
+ * getMaterial main.js:206-270): parse (scene.worldTransforms, prop.skips; the material fields of `prop` are
+ * ignored), list the groups in the reference's iteration order (Object.entries: array-index names first),
+ * let the host resolve one material per group, commit.  mtllib = ordinal of the `mtllib` line that was
+ * current when the group's first face was read (-1: none; the group's material is then `{}`). */
+int fspt_builder_parse_obj(fspt_builder *b, const char *obj_text, size_t len, const fspt_prop_desc *prop,
+                           const fspt_world_transform *world, uint32_t n_world,
+                           const char *const *skips, uint32_t n_skips, uint32_t *n_groups);
+int fspt_builder_group_info(const fspt_builder *b, uint32_t group, const char **name,
+                            uint32_t *n_tris, int32_t *mtllib);
+int fspt_builder_mtllib_name(const fspt_builder *b, uint32_t index, const char **name);
+int fspt_builder_commit_obj(fspt_builder *b, const fspt_group_material *mats, uint32_t n_groups);
+/* scene.normalize (main.js:337-348): centre on the scene bounds and scale the longest side to 2*size. */
+int fspt_builder_normalize(fspt_builder *b, double size);
 /* new BVH(geometry, leaf_size) + serializeTree + packing loops
  * (bvh.js:5-91, main.js:355-392). */
 int fspt_builder_build(fspt_builder *b, uint32_t leaf_size);
 int fspt_builder_counts(const fspt_builder *b, uint32_t *n_nodes, uint32_t *n_tris,
                         uint32_t *depth);
+/* shootAutoFocusRay (main.js:447-546) on the built tree, in float64: distance along (eye, dir) to the first
+ * triangle, 1e6 when there is none; the reference then sets lensFeatures[0] = 1 - 1/dist. */
+int fspt_builder_autofocus(const fspt_builder *b, const double eye[3], const double dir[3], double *dist);
 /* Copies the packed reference-layout arrays (sizes from fspt_builder_counts:
  * bvh 9*n_nodes, tri 9*n_tris, mat 12*n_tris, norm 27*n_tris, uv 6*n_tris). */
 int fspt_builder_get(const fspt_builder *b, float *bvh, float *tri, float *mat,

@@ -25,31 +25,59 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def load_js(name):
     z = np.load(os.path.join(GOLD, f"js_scene_{name}.npz"))
-    return z, json.loads(str(z["props"])), json.loads(str(z["texts"]))
+    return z, json.loads(str(z["scene"])), json.loads(str(z["texts"])), json.loads(str(z["files"]))
+
+
+def stand_in_images(z):
+    """Decoded-image stand-ins with the heights the golden was generated with (the reference's getMaterial /
+    TexturePacker only look at currentSrc and height; tools/make_goldens.py stand_in_images)."""
+    rng = np.random.default_rng(5)
+    return {u: rng.integers(0, 256, size=(h, h, 4), dtype=np.uint8) for u, h in sorted(json.loads(str(z["heights"])).items())}
+
+
+def native_build(name):
+    z, scene, texts, files = load_js(name)
+    return z, S.build_scene_json(scene, texts, files, stand_in_images(z), env=z["env"], env_w=int(z["env_w"]),
+                                 env_h=int(z["env_h"]), focus_rays=z["focus_rays"].tolist())
 
 
 def scene_from_golden(name):
-    """SceneArrays made of the REFERENCE JS pipeline's arrays (+ the flat-colour atlas)."""
-    z, props, _ = load_js(name)
-    pk = S.TexturePacker()
-    for p in props:
-        S.get_material(p, pk)
+    """SceneArrays made of the REFERENCE JS pipeline's arrays (+ the atlas of the same scene)."""
+    z, nat = native_build(name)
     return S.SceneArrays(bvh=z["bvh"].copy(), tri=z["tri"].copy(), mat=z["mat"].copy(), norm=z["norm"].copy(),
-                         uv=z["uv"].copy(), atlas=pk.get_pixels(), atlas_res=pk.res, atlas_layers=len(pk.image_set),
+                         uv=z["uv"].copy(), atlas=nat.atlas, atlas_res=nat.atlas_res, atlas_layers=nat.atlas_layers,
                          env=z["env"].copy(), env_w=int(z["env_w"]), env_h=int(z["env_h"]), bins=z["bins"].copy(),
                          leaf_size=4, depth=int(z["depth"]))
 
 
-@pytest.mark.parametrize("name", ["small", "variant"])
+@pytest.mark.parametrize("name", ["small", "variant", "mtl"])
 def test_d0_native_pipeline_matches_reference_js(name):
-    z, props, texts = load_js(name)
-    a = S.build_scene(props, texts, env=z["env"], env_w=int(z["env_w"]), env_h=int(z["env_h"]))
+    """obj_loader.js + mtl_loader.js + getMaterial + TexturePacker ids + mergeSceneProps + scene.normalize +
+    bvh.js + the packing loops, run UNMODIFIED under Node (tools/js_ref), against the native pipeline: every
+    packed array byte for byte, and the atlas layer list (colour / image, sRGB flag, swizzle) entry for entry.
+    'mtl': usemtl groups with MTL materials, array-index group names, skips, worldTransforms, normalize,
+    static + animated props; 'variant': mesh normals, negative indices, quads, MTL emission."""
+    z, a = native_build(name)
     for k in ("bvh", "tri", "mat", "norm", "uv"):
         got, want = getattr(a, k), z[k]
         assert got.size == want.size, k
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{k} differs from the reference JS output"
     assert np.array_equal(a.bins, z["bins"])
     assert a.depth == int(z["depth"])
+    assert a.meta["layers"] == json.loads(str(z["image_set"]))
+    assert a.atlas_layers == len(a.meta["layers"])
+    # shootAutoFocusRay (main.js:447-546), float64 on the host tree: lensFeatures[0] bit for bit
+    assert np.array_equal(np.array(a.meta["focus"], np.float64).view(np.uint64), z["focus"].view(np.uint64))
+
+
+def test_mtl_parser_quirks():
+    """ParseMaterials (mtl_loader.js): keys are case-folded, falsy scalars are dropped (`if (value)`), vectors are
+    kept, url set in first-seen order, lines before the first newmtl ignored."""
+    mats, urls = S.parse_materials("Kd 1 1 1\nnewmtl  a\nKD 0.5 0.25 1\nNs 0\nior 1.5\nmap_Kd  t/x.png\nmap_Bump t/x.png\n"
+                                   "newmtl b\nPmr 0 0 0\ndielectric abc\nmap_kem\n", "base")
+    assert mats == {"a": {"kd": [0.5, 0.25, 1.0], "ior": 1.5, "map_kd": "t/x.png", "map_bump": "t/x.png"},
+                    "b": {"pmr": [0.0, 0.0, 0.0]}}
+    assert urls == ["base/t/x.png"]
 
 
 def test_d0_70k_scene_digests():

@@ -4,10 +4,16 @@
 // dumps what main.js would upload.  main.js itself cannot be imported (it
 // touches the DOM at import time, main.js:953-975), so its pure array-pushing
 // packing loops (main.js:360-392) and maskBVHBuffer (main.js:272-282) are
-// restated here; getMaterial's result is supplied per prop by the caller.
+// restated here.  getMaterial (main.js:206-270) and mergeSceneProps (main.js:869-871) are NOT restated:
+// js_ref.py cuts their source text out of main.js at run time into ref_functions.js (never committed),
+// and they run unmodified against the reference's own TexturePacker (texture_packer.js, imported).
 import * as ObjLoader from './obj_loader.js';
 import { BVH } from './bvh.js';
 import { ProcessEnvRadiance } from './env_sampler.js';
+import { TexturePacker } from './texture_packer.js';
+import { BoundingBox } from './bvh.js';
+import { Vec3 } from './vector.js';
+import { getMaterial, mergeSceneProps, autoFocus } from './ref_functions.js';
 import fs from 'fs';
 
 (async () => {
@@ -20,20 +26,67 @@ import fs from 'fs';
     const bins = ProcessEnvRadiance({ width: job.env.width, height: job.env.height });
     out.bins = Array.from(bins);
   }
-  if (job.props) {
+  if (job.props || job.scene) {
     const realLog = console.log;
     console.log = () => {};
     let geometry = [];
-    for (const prop of job.props) {
-      const parsed = await ObjLoader.parseMesh(job.objs[prop.path], prop, job.worldTransforms, 'x');
-      Object.values(parsed.groups).forEach((group) => {
-        group.triangles.forEach((t) => { t.material = prop.material; geometry.push(t); });
-      });
+    if (job.scene) {
+      // initBVH's prop loop (main.js:311-335) with the reference's own getMaterial / TexturePacker / mergeSceneProps.
+      // utility.js getText uses XMLHttpRequest: serve the job's files (mtllib texts).
+      global.XMLHttpRequest = class {
+        addEventListener(ev, fn) { if (ev === 'load') this.onload = fn; }
+        open(method, url) { this.url = url; }
+        send() {
+          if (!(this.url in job.files)) throw new Error('no such file in job: ' + this.url);
+          setTimeout(() => this.onload({ target: { responseText: job.files[this.url] } }), 0);
+        }
+      };
+      const scene = job.scene;
+      const props = mergeSceneProps(scene);
+      const texturePacker = new TexturePacker(scene.atlasRes || 2048, props.length);
+      // stand-ins for decoded HTMLImageElements: addTexture only looks at currentSrc and height
+      const assets = {};
+      for (const url of Object.keys(job.images || {})) assets[url] = { currentSrc: url, height: job.images[url].height };
+      const bounds = new BoundingBox();
+      for (let i = 0; i < props.length; i++) {
+        const prop = props[i];
+        const basePath = prop.path.split('/').slice(0, -1).join('/');
+        const parsed = await ObjLoader.parseMesh(job.objs[prop.path], prop, scene.worldTransforms, basePath);
+        bounds.addVertex(parsed.bounds.max);
+        bounds.addVertex(parsed.bounds.min);
+        Object.values(parsed.groups).forEach((group) => {
+          const material = getMaterial(prop, group, texturePacker, assets, basePath);
+          group.triangles.forEach((t) => { t.material = material; geometry.push(t); });
+        });
+      }
+      if (scene.normalize) {                                  // main.js:337-348
+        let diff = Vec3.sub(bounds.max, bounds.min);
+        let longest = Math.max(Math.max(diff[0], diff[1]), diff[2]);
+        let centroid = bounds.centroid;
+        let scale = 2 * scene.normalize / longest;
+        for (let i = 0; i < geometry.length; i++) {
+          for (let j = 0; j < geometry[i].verts.length; j++) {
+            geometry[i].verts[j] = Vec3.scale(Vec3.sub(geometry[i].verts[j], centroid), scale)
+          }
+        }
+      }
+      out.image_set = texturePacker.imageSet.map((e) => Array.isArray(e) ? { color: e } :
+        { src: e.currentSrc, corrected: !!e.corrected, swizzle: e.swizzle || null });
+      out.n_props = props.length;
+    } else {
+      for (const prop of job.props) {
+        const parsed = await ObjLoader.parseMesh(job.objs[prop.path], prop, job.worldTransforms, 'x');
+        Object.values(parsed.groups).forEach((group) => {
+          group.triangles.forEach((t) => { t.material = prop.material; geometry.push(t); });
+        });
+      }
     }
     const t0 = Date.now();
     const bvh = new BVH(geometry, job.leaf_size || 4);
     out.build_ms = Date.now() - t0;
     console.log = realLog;
+    // shootAutoFocusRay (main.js:447-546) needs the un-serialized tree: run it first
+    out.autofocus = (job.autofocus || []).map(([eye, dir]) => autoFocus(Vec3, bvh, eye, dir));
     const bvhArray = bvh.serializeTree();
     let bvhBuffer = [], trianglesBuffer = [], materialBuffer = [], normalBuffer = [], uvBuffer = [];
     for (let i = 0; i < bvhArray.length; i++) {           // main.js:360-392

@@ -16,17 +16,44 @@ def available():
     return os.path.isdir(REF) and shutil.which("node") is not None
 
 
+def _cut_function(src, name):
+    """The source text of `function name(...) {...}` inside main.js (brace matching)."""
+    a = src.index("function " + name + "(")
+    i = src.index("{", a)
+    depth = 0
+    while True:
+        c = src[i]
+        if c == "{":
+            depth += 1
+        elif c == "}":
+            depth -= 1
+            if depth == 0:
+                return src[a:i + 1]
+        i += 1
+
+
 def run(job, max_old_space_mb=6000):
     with tempfile.TemporaryDirectory() as td:
-        for f in ("vector.js", "bvh.js", "obj_loader.js", "mtl_loader.js", "utility.js", "env_sampler.js"):
+        for f in ("vector.js", "bvh.js", "obj_loader.js", "mtl_loader.js", "utility.js", "env_sampler.js",
+                  "texture_packer.js"):
             shutil.copy(os.path.join(REF, f), td)
+        # main.js cannot be imported (DOM at import time): lift its pure functions, unmodified, into a module
+        main_src = open(os.path.join(REF, "main.js")).read()
+        with open(os.path.join(td, "ref_functions.js"), "w") as fh:
+            fh.write("export " + _cut_function(main_src, "getMaterial") + "\n")
+            fh.write("export " + _cut_function(main_src, "mergeSceneProps") + "\n")
+            # shootAutoFocusRay closes over PathTracer's locals: give it the same names
+            fh.write("export function autoFocus(Vec3, bvh, eye, dir) {\n  const maxT = 1e6;\n  let lensFeatures = [0, 0];\n"
+                     "  let elements = { focalDepthElement: {} };\n" + _cut_function(main_src, "shootAutoFocusRay") +
+                     "\n  shootAutoFocusRay();\n  return lensFeatures[0];\n}\n")
         shutil.copy(os.path.join(HERE, "driver.js"), td)
         with open(os.path.join(td, "package.json"), "w") as fh:
             fh.write('{"type":"module"}')
         with open(os.path.join(td, "job.json"), "w") as fh:
             json.dump(job, fh)
         subprocess.check_call(["node", f"--max-old-space-size={max_old_space_mb}", "--experimental-modules",
-                               "driver.js", "job.json", "out.json"], cwd=td, stderr=subprocess.DEVNULL)
+                               "driver.js", "job.json", "out.json"], cwd=td,
+                              stderr=None if os.environ.get("JS_REF_DEBUG") else subprocess.DEVNULL)
         out = json.load(open(os.path.join(td, "out.json")))
     for k in ("bvh", "tri", "mat", "norm", "uv"):
         if k in out:
@@ -44,6 +71,14 @@ def scene_job(props, obj_texts, materials, leaf_size=4):
         q["material"] = m
         jp.append(q)
     return {"props": jp, "objs": obj_texts, "leaf_size": leaf_size}
+
+
+def full_scene_job(scene, obj_texts, files=None, images=None, leaf_size=4, autofocus=None):
+    """scene: the scene JSON (props / static_props / animated_props, worldTransforms, normalize, atlasRes);
+    files: {url: text} served to obj_loader.js's mtllib fetches; images: {url: {"height": h}};
+    autofocus: [[eye, dir], ...] -> out["autofocus"] = lensFeatures[0] of shootAutoFocusRay for each."""
+    return {"scene": scene, "objs": obj_texts, "files": files or {}, "images": images or {}, "leaf_size": leaf_size,
+            "autofocus": autofocus or []}
 
 
 def env_job(rgba, w, h):

@@ -57,27 +57,75 @@ f 4/1/1 1/2/1 5/3/1
 
 
 def small_inputs():
-    props = S.bunny_props()
+    scene = {"props": S.bunny_props()}
     texts = {"synthetic/cube_sphere.obj": S.cube_sphere_obj(8), "synthetic/quad.obj": S.QUAD_OBJ}
     env, w, h = S.synthetic_env(64, 32)
-    return props, texts, env, w, h
+    return scene, texts, {}, {}, env, w, h
 
 
 def variant_inputs():
+    # the second prop's emissive colour comes from an MTL `Kem` (getMaterial ignores an array-valued
+    # scene-JSON `emission`, main.js:249-253)
     props = [
         {"path": "variant.obj", "scale": 0.8, "rotate": [{"angle": 0.3, "axis": [0, 1, 0]}, {"angle": -0.2, "axis": [1, 0, 0]}],
          "translate": [0.1, -0.2, 0.3], "diffuse": [0.9, 0.2, 0.1], "emittance": [0, 0, 0],
          "metallicRoughness": [0, 0.25, 0], "normals": "mesh", "ior": 1.5, "dielectric": 0.5},
-        {"path": "variant.obj", "scale": 0.5, "rotate": [{"angle": 1.1, "axis": [0, 0, 1]}],
+        {"path": "lit/variant_em.obj", "scale": 0.5, "rotate": [{"angle": 1.1, "axis": [0, 0, 1]}],
          "translate": [1.5, 0.4, -0.6], "diffuse": [0.2, 0.9, 0.3], "emittance": [0, 0, 0],
-         "metallicRoughness": [0, 0.6, 0], "normals": "smooth", "emission": [0.3, 0.3, 0.1]},
+         "metallicRoughness": [0, 0.6, 0], "normals": "smooth"},
         {"path": "synthetic/quad.obj", "scale": 6, "rotate": [], "translate": [0, -1.0, 0], "emittance": [0, 0, 0],
          "normals": "flat"},
     ]
-    texts = {"variant.obj": VARIANT_OBJ, "synthetic/quad.obj": S.QUAD_OBJ}
+    texts = {"variant.obj": VARIANT_OBJ, "lit/variant_em.obj": "mtllib em.mtl\n" + VARIANT_OBJ, "synthetic/quad.obj": S.QUAD_OBJ}
+    files = {"lit/em.mtl": "newmtl floor\nKem 0.3 0.3 0.1\nnewmtl roof\nKem 0.3 0.3 0.1\n"}
     # 60x30: midpoint splits go fractional (env_sampler.js:34-36) yet stay under SwiftShader's 261-vec4 uniform limit
     env, w, h = S.synthetic_env(60, 30, sun_deg=8.0)
-    return props, texts, env, w, h
+    return {"props": props}, texts, files, {}, env, w, h
+
+
+def mtl_inputs():
+    """usemtl groups with their own MTL materials (colours and maps), array-index group names (JS iterates
+    them first), prop.skips, scene.worldTransforms, scene.normalize, static / animated props, a string ior,
+    one image used by several props with different swizzles."""
+    lines = S.cube_sphere_obj(3).split("\n")
+    faces = [l for l in lines if l.startswith("f ")]
+    other = [l for l in lines if not l.startswith("f ")]
+    n = len(faces)
+    parts = [faces[:n // 5], faces[n // 5:2 * n // 5], faces[2 * n // 5:3 * n // 5], faces[3 * n // 5:4 * n // 5], faces[4 * n // 5:]]
+    obj = "\n".join(other + parts[0] + ["mtllib mats.mtl", "usemtl shell"] + parts[1] + ["usemtl 7"] + parts[2] +
+                    ["usemtl skipme"] + parts[3] + ["usemtl 2"] + parts[4] + ["usemtl shell"] + faces[:3]) + "\n"
+    mtl = "\n".join(["# test library", "newmtl shell", "Kd 0.8 0.1 0.1", "Pmr 0.0 0.4 0.0", "ior 1.7", "newmtl 7",
+                     "map_Kd tex/wood.png", "Kem 0.5 0.4 0.1", "dielectric 0.5", "newmtl 2", "map_Pmr tex/mr.png",
+                     "pmr_swizzle 2 1 0 3", "map_Bump tex/nrm.png", "map_Kem tex/glow.png", "Ns 0", ""])
+    scene = {
+        "atlasRes": 64, "normalize": 1.5,
+        "worldTransforms": [{"rotate": [{"axis": [0, 1, 0], "angle": 0.4}]}, {"translate": [0.2, -0.1, 0.3]}, {"rotate": []}],
+        "props": [{"path": "models/ball.obj", "scale": 0.7, "rotate": [{"angle": 0.3, "axis": [1, 0, 0]}],
+                   "translate": [0.1, 0.2, -0.3], "diffuse": [0.2, 0.3, 0.9], "emittance": [0, 0, 0],
+                   "metallicRoughness": "models/tex/mr.png", "mrSwizzle": [1, 0, 2, 3], "normals": "smooth",
+                   "skips": ["skipme"], "emission": [0.3, 0.3, 0.1]}],
+        "static_props": [{"path": "synthetic/quad.obj", "scale": 5, "rotate": [], "translate": [0, -1, 0],
+                          "emittance": [0, 0, 0], "normals": "flat", "normal": "models/tex/nrm.png", "ior": "10"}],
+        "animated_props": {"a": {"path": "models/ball.obj", "scale": 0.3, "rotate": [], "translate": [1.0, 0.5, 0.0],
+                                 "emittance": [1, 1, 1], "normals": "flat", "dielectric": 0}},
+    }
+    texts = {"models/ball.obj": obj, "synthetic/quad.obj": S.QUAD_OBJ}
+    files = {"models/mats.mtl": mtl}
+    heights = {"models/tex/wood.png": 16, "models/tex/mr.png": 32, "models/tex/nrm.png": 8, "models/tex/glow.png": 4}
+    env, w, h = S.synthetic_env(32, 16)
+    return scene, texts, files, heights, env, w, h
+
+
+# (eye, dir) pairs for shootAutoFocusRay: the bench camera, axis-aligned directions (1/0 = Infinity, 0*Infinity =
+# NaN inside the slab test), a miss, an un-normalised direction
+FOCUS_RAYS = [[[-0.751, 0.665, 1.820], [0.304, -0.489, -0.818]], [[0.0, 0.0, 2.0], [0.0, 0.0, -1.0]],
+              [[0.0, 5.0, 0.0], [0.0, -1.0, 0.0]], [[0.0, 0.5, 3.0], [0.0, 1.0, 0.0]], [[1.0, 2.0, 3.0], [-0.5, -1.1, -1.6]],
+              [[0.1, 0.2, 0.3], [0.3, -0.2, 0.1]]]
+
+
+def stand_in_images(heights):
+    rng = np.random.default_rng(5)
+    return {u: rng.integers(0, 256, size=(h, h, 4), dtype=np.uint8) for u, h in sorted(heights.items())}
 
 
 def sha(a):
@@ -86,15 +134,20 @@ def sha(a):
 
 def make_js():
     import js_ref as J
-    for name, (props, texts, env, w, h) in (("small", small_inputs()), ("variant", variant_inputs())):
-        pk = S.TexturePacker()
-        mats = [S.get_material(p, pk) for p in props]
-        out = J.run(J.scene_job(props, texts, mats))
+    for name, (scene, texts, files, heights, env, w, h) in (("small", small_inputs()), ("variant", variant_inputs()),
+                                                            ("mtl", mtl_inputs())):
+        # the reference's own getMaterial / TexturePacker / mergeSceneProps / obj_loader / mtl_loader / bvh
+        out = J.run(J.full_scene_job(scene, texts, files, {u: {"height": hh} for u, hh in heights.items()},
+                                     autofocus=FOCUS_RAYS))
         bins = J.run(J.env_job(env, w, h))["bins"]
         np.savez_compressed(os.path.join(GOLD, f"js_scene_{name}.npz"), bvh=out["bvh"], tri=out["tri"], mat=out["mat"],
                             norm=out["norm"], uv=out["uv"], bins=bins, depth=np.int32(out["depth"]),
-                            props=json.dumps(props), texts=json.dumps(texts), env=env, env_w=w, env_h=h)
-        print("js", name, out["bvh"].size // 9, "nodes", out["tri"].size // 9, "tris", bins.size // 4, "bins")
+                            scene=json.dumps(scene), texts=json.dumps(texts), files=json.dumps(files),
+                            heights=json.dumps(heights), image_set=json.dumps(out["image_set"]),
+                            focus_rays=np.array(FOCUS_RAYS, np.float64), focus=np.array(out["autofocus"], np.float64),
+                            env=env, env_w=w, env_h=h)
+        print("js", name, out["bvh"].size // 9, "nodes", out["tri"].size // 9, "tris", bins.size // 4, "bins",
+              len(out["image_set"]), "layers")
     # env bins on an odd-sized image (NaN / fractional-edge quirks of env_sampler.js:25-47, 73)
     env, w, h = S.synthetic_env(100, 37, sun_deg=6.0)
     np.savez_compressed(os.path.join(GOLD, "js_env_bins_odd.npz"), env=env, env_w=w, env_h=h,
@@ -102,10 +155,8 @@ def make_js():
     # 70k-triangle scene: digests only (arrays are ~17 MB)
     props = S.bunny_props()
     texts = {"synthetic/cube_sphere.obj": S.cube_sphere_obj(76), "synthetic/quad.obj": S.QUAD_OBJ}
-    pk = S.TexturePacker()
-    mats = [S.get_material(p, pk) for p in props]
     t0 = time.time()
-    out = J.run(J.scene_job(props, texts, mats))
+    out = J.run(J.full_scene_job({"props": props}, texts))
     env, w, h = S.synthetic_env(2048, 1024)
     bins = J.run(J.env_job(env, w, h))["bins"]
     dig = {k: sha(out[k]) for k in ("bvh", "tri", "mat", "norm", "uv")}
@@ -127,14 +178,13 @@ def make_js():
 
 
 def load_scene(name):
+    """The reference JS pipeline's arrays + the atlas of the same scene."""
     z = np.load(os.path.join(GOLD, f"js_scene_{name}.npz"))
-    props = json.loads(str(z["props"]))
-    pk = S.TexturePacker()
-    for p in props:
-        S.get_material(p, pk)
-    atlas = pk.get_pixels()
-    return S.SceneArrays(bvh=z["bvh"], tri=z["tri"], mat=z["mat"], norm=z["norm"], uv=z["uv"], atlas=atlas,
-                         atlas_res=pk.res, atlas_layers=len(pk.image_set), env=z["env"], env_w=int(z["env_w"]),
+    scene, texts, files = (json.loads(str(z[k])) for k in ("scene", "texts", "files"))
+    images = stand_in_images(json.loads(str(z["heights"])))
+    nat = S.build_scene_json(scene, texts, files, images)
+    return S.SceneArrays(bvh=z["bvh"], tri=z["tri"], mat=z["mat"], norm=z["norm"], uv=z["uv"], atlas=nat.atlas,
+                         atlas_res=nat.atlas_res, atlas_layers=nat.atlas_layers, env=z["env"], env_w=int(z["env_w"]),
                          env_h=int(z["env_h"]), bins=z["bins"], leaf_size=4, depth=int(z["depth"]))
 
 
