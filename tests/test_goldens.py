@@ -261,3 +261,41 @@ def test_d3_textured_scene_bilinear_atlas():
         assert d.max() <= tol, (field, d.max())
     # the maps really vary across the image (not a flat-colour scene in disguise)
     assert fh["diffuse"][hit].std() > 0.1 and fh["tex_normal"][hit][:, 0].std() > 0.05
+
+
+def write_asset_tree(root, z, scene, texts, files, frame_scenes=None):
+    """Lay a golden scene out on disk the way the reference's web root holds it."""
+    from PIL import Image
+    for rel, text in list(texts.items()) + list(files.items()):
+        os.makedirs(os.path.dirname(os.path.join(root, rel)), exist_ok=True)
+        with open(os.path.join(root, rel), "w") as fh:
+            fh.write(text)
+    for rel, img in stand_in_images(z).items():
+        os.makedirs(os.path.dirname(os.path.join(root, rel)), exist_ok=True)
+        Image.fromarray(img).save(os.path.join(root, rel))  # PNG keeps straight-alpha RGBA bytes
+    os.makedirs(os.path.join(root, "environment"), exist_ok=True)
+    Image.fromarray(z["env"].reshape(int(z["env_h"]), int(z["env_w"]), 4)).save(os.path.join(root, "environment", "sky.RGBE.PNG"))
+    os.makedirs(os.path.join(root, "scene"), exist_ok=True)
+    for name, sc in (frame_scenes or {"test.json": scene}).items():
+        sc = dict(sc, environment="environment/sky.RGBE.PNG")
+        with open(os.path.join(root, "scene", name), "w") as fh:
+            json.dump(sc, fh)
+
+
+def test_scene_file_loader_matches_reference_arrays(tmp_path):
+    """load_scene_file on an on-disk web root (JSON + OBJ + MTL + PNG maps + RGBE sky) gives the arrays the
+    reference's JS pipeline gives for the same scene, and the reference's camera defaults (main.js:50-75)."""
+    from fspt_amd import scene_file as F
+    z, scene, texts, files = load_js("mtl")
+    write_asset_tree(str(tmp_path), z, scene, texts, files)
+    a, st = F.load_scene_file(os.path.join(str(tmp_path), "scene", "test.json"))
+    for k in ("bvh", "tri", "mat", "norm", "uv"):
+        assert np.array_equal(getattr(a, k).view(np.uint32), z[k].view(np.uint32)), k
+    assert a.meta["layers"] == json.loads(str(z["image_set"]))
+    assert np.array_equal(a.env, z["env"]) and np.array_equal(a.bins, z["bins"])
+    assert st["eye"] == [0, 0, 2] and st["dir"] == [0, 0, -1] and st["fov_scale"] == 0.5 and st["samples"] == 2000
+    assert st["focus"] == float(z["focus"][1])  # FOCUS_RAYS[1] is the default camera
+    # the decoded maps really reach the atlas: layer 1 is mr.png through its last-assigned swizzle
+    img = stand_in_images(z)["models/tex/mr.png"]
+    want = S.resample_image(img, a.atlas_res, False, (2, 1, 0, 3))
+    assert np.array_equal(a.atlas.reshape(a.atlas_layers, a.atlas_res, a.atlas_res, 4)[1], want)

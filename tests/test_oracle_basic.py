@@ -80,7 +80,7 @@ def test_oracle_root_leaf_and_black_env():
     """2-triangle scene: root is a leaf; rays that miss see the black default environment."""
     from fspt_amd import scene as S
     props = [{"path": "q.obj", "scale": 3, "rotate": [], "translate": [0, -0.5, 0], "emittance": [0, 0, 0],
-              "diffuse": [0.8, 0.7, 0.6], "emission": [0.5, 0.5, 0.5], "normals": "flat"}]
+              "diffuse": [0.8, 0.7, 0.6], "normals": "flat"}]
     arrays = S.build_scene(props, {"q.obj": S.QUAD_OBJ})
     assert arrays.n_nodes == 1
     rays = np.array([[0, 1, 0, 0, -1, 0], [0, 1, 0, 0, 1, 0], [10, 1, 0, 0, -1, 0]], np.float32)

@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle.
 Integer/index results and every float32 result must be bit-identical
 (compared with ==, i.e. up to the sign of zero)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -224,8 +226,10 @@ def test_root_leaf_scene_and_tiny_frames(camera, pipeline):
     1-pixel-wide / 1-pixel-high frames."""
     from fspt_amd import scene as S
     props = [{"path": "q.obj", "scale": 3, "rotate": [], "translate": [0, -0.5, 0], "emittance": [0, 0, 0],
-              "diffuse": [0.8, 0.7, 0.6], "emission": [0.5, 0.5, 0.5], "normals": "flat"}]
-    arrays = S.build_scene(props, {"q.obj": S.QUAD_OBJ})  # no environment
+              "diffuse": [0.8, 0.7, 0.6], "normals": "flat"}]
+    # the emissive colour comes from an MTL `Kem` (getMaterial has no colour-valued prop-level emission)
+    arrays = S.build_scene(props, {"q.obj": "mtllib e.mtl\nusemtl lit\n" + S.QUAD_OBJ},
+                           mtl_texts={"/e.mtl": "newmtl lit\nKem 0.5 0.5 0.5\n"})  # no environment
     assert arrays.n_nodes == 1 and arrays.n_tris == 2 and arrays.env is None
     rays = random_rays(arrays, 2000, seed=2)
     sc = Scene(arrays)
@@ -368,3 +372,38 @@ def test_bound_torch_accumulator_and_tile_gather_on_gpu(small_scene, camera):
     assert np.array_equal(full.cpu().numpy(), want)
     g = D.TileGather(0, 1, W, H, full.device)
     assert np.array_equal(g.exchange(full.clone()).cpu().numpy(), want)
+
+
+def test_frame_sequence_from_scene_files(tmp_path):
+    """`?frame=N` sequencing (main.js:851-866, 869-871, 966-969): per-frame scene JSONs whose animated_props
+    move, loaded from an on-disk web root (OBJ + MTL + PNG maps + RGBE sky), auto-focused, rendered and
+    tone-mapped; every PNG equals the oracle's render + draw.fs of the same frame, byte for byte."""
+    import copy
+    import json
+    from PIL import Image
+    from test_goldens import load_js, write_asset_tree
+    from fspt_amd import scene_file as F
+    z, scene, texts, files = load_js("mtl")
+    scene = dict(scene, cameraPos=[0.2, 0.6, 2.4], cameraDir=[-0.05, -0.2, -1.0], samples=3, exposure=1.3,
+                 environmentTheta=0.7)
+    frames = {}
+    for n in range(2):
+        sc = copy.deepcopy(scene)
+        sc["animated_props"]["a"]["translate"] = [1.0 - 0.4 * n, 0.5, 0.1 * n]
+        frames[f"anim_{n}.json"] = sc
+    root = str(tmp_path)
+    write_asset_tree(root, z, scene, texts, files, frames)
+    W, H = 80, 48
+    outs = F.render_sequence(os.path.join(root, "scene", "anim_{frame}.json"), range(2), os.path.join(root, "up", "{frame}.png"),
+                             W, H, bounces=4, seed=9)
+    imgs = []
+    for n, path in enumerate(outs):
+        arrays, st = F.load_scene_file(os.path.join(root, "scene", f"anim_{n}.json"))
+        acc = np.zeros((H, W, 4), np.float32)
+        O.render(arrays, W, H, st["eye"], st["dir"], st["fov_scale"], [st["focus"], st["aperture"]], st["env_theta"], 4, 0,
+                 st["samples"], 9, acc)
+        want = O.draw(acc, st["exposure"], 1.0, False, 3.0)[::-1, :, :3]
+        got = np.asarray(Image.open(path).convert("RGB"))
+        assert np.array_equal(got, want), f"frame {n}"
+        imgs.append(got)
+    assert (imgs[0] != imgs[1]).mean() > 0.01  # the animated prop really moved
