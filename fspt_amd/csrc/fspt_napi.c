@@ -18,7 +18,8 @@
  *   draw(target, exposure, saturation, denoise, maxSigma, Uint8Array(W*H*4))   (drawQuad, main.js:809-824)
  *   setShard(target, shard, nShards, tile) / setPipeline(target, pipeline, batch)
  *   enableCounters(target, on) / counters(target) -> object
- *   buildScene(props[], leafSize) -> {bvh,tri,mat,norm,uv,depth}     (native obj_loader.js + bvh.js)
+ *   builderCreate / builderParseObj / builderCommit / builderNormalize / builderBuild / builderAutofocus /
+ *   builderDestroy                                                   (native obj_loader.js + bvh.js, 1:1 fspt_builder_*)
  *   envBins(Uint8Array rgbe, w, h) -> Uint32Array                    (native env_sampler.js)
  *   sceneDestroy / targetDestroy / deviceCount / abiVersion
  */
@@ -308,91 +309,213 @@ static napi_value f32_out(napi_env env, size_t n, float **data) {
   if (napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta) != napi_ok) return NULL;
   return ta;
 }
-/* buildScene([{obj: string, rotate:[{axis:[x,y,z],angle}], scale, translate:[3], normals:'flat'|'smooth'|'mesh',
- *              material:{diffuseIndex,specularIndex,normalIndex,roughnessIndex,emittance:[3],ior,dielectric}}], leafSize) */
-static napi_value BuildScene(napi_env env, napi_callback_info info) {
-  napi_value a[2];
-  if (get_args(env, info, 2, a)) return NULL;
-  uint32_t nprops = 0, leaf = 4;
-  NAPI_OK(napi_get_array_length(env, a[0], &nprops));
-  NAPI_OK(napi_get_value_uint32(env, a[1], &leaf));
+/* --- native scene builder, one call per fspt_builder_* entry point (orchestrated by fspt.js buildScene) --- */
+static int read_rotations(napi_env env, napi_value obj, double *rot, uint32_t cap, uint32_t *n, bool *present) {
+  napi_value v;
+  *n = 0; *present = false;
+  if (napi_get_named_property(env, obj, "rotate", &v) != napi_ok) return 0;
+  bool isarr = false;
+  napi_is_array(env, v, &isarr);
+  if (!isarr) return 0;
+  *present = true;
+  napi_get_array_length(env, v, n);
+  if (*n > cap) { napi_throw_range_error(env, NULL, "fspt_napi: too many rotations (max 16)"); return -1; }
+  for (uint32_t r = 0; r < *n; ++r) {
+    napi_value re, ax, e;
+    napi_get_element(env, v, r, &re);
+    if (prop(env, re, "axis", &ax)) return -1;
+    for (uint32_t k = 0; k < 3; ++k) { napi_get_element(env, ax, k, &e); if (get_f64(env, e, &rot[4 * r + k])) return -1; }
+    if (prop_f64(env, re, "angle", 0.0, &rot[4 * r + 3])) return -1;
+  }
+  return 0;
+}
+static int read_vec3(napi_env env, napi_value obj, const char *name, double *out, bool *present) {
+  napi_value v;
+  *present = false;
+  if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+  bool isarr = false;
+  napi_is_array(env, v, &isarr);
+  if (!isarr) return 0;
+  *present = true;
+  for (uint32_t k = 0; k < 3; ++k) { napi_value e; napi_get_element(env, v, k, &e); if (get_f64(env, e, &out[k])) return -1; }
+  return 0;
+}
+static char *dup_string(napi_env env, napi_value v, size_t *len) {
+  if (napi_get_value_string_utf8(env, v, NULL, 0, len) != napi_ok) { napi_throw_type_error(env, NULL, "fspt_napi: expected a string"); return NULL; }
+  char *text = (char *)malloc(*len + 1);
+  napi_get_value_string_utf8(env, v, text, *len + 1, len);
+  return text;
+}
+static napi_value BuilderCreate(napi_env env, napi_callback_info info) {
+  (void)info;
   fspt_builder *b = NULL;
   FSPT_OK_OR_THROW(fspt_builder_create(&b));
+  napi_value h;
+  NAPI_OK(napi_create_external(env, b, NULL, NULL, &h));
+  return h;
+}
+static napi_value BuilderDestroy(napi_env env, napi_callback_info info) {
+  napi_value a[1]; void *h;
+  if (get_args(env, info, 1, a)) return NULL;
+  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  fspt_builder_destroy((fspt_builder *)h);
+  return undefined(env);
+}
+/* builderParseObj(b, objText, {rotate, scale, translate, normals}, worldTransforms[] | null, skips[] | null)
+ *   -> [{name, nTris, mtllib: string | null}]   groups in the reference's iteration order */
+#define MAX_WORLD 16
+static napi_value BuilderParseObj(napi_env env, napi_callback_info info) {
+  napi_value a[5]; void *h;
+  if (get_args(env, info, 5, a)) return NULL;
+  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  fspt_builder *b = (fspt_builder *)h;
+  fspt_prop_desc pd;
+  memset(&pd, 0, sizeof(pd));
+  double rot[4 * 16];
+  uint32_t nrot = 0; bool present;
+  if (read_rotations(env, a[2], rot, 16, &nrot, &present)) return NULL;
+  pd.rotate = rot; pd.n_rotate = nrot;
+  if (prop_f64(env, a[2], "scale", 1.0, &pd.scale)) return NULL;
+  if (read_vec3(env, a[2], "translate", pd.translate, &present)) return NULL;
+  napi_value v;
+  if (napi_get_named_property(env, a[2], "normals", &v) == napi_ok) {
+    char buf[16]; size_t len = 0;
+    if (napi_get_value_string_utf8(env, v, buf, sizeof(buf), &len) == napi_ok) {
+      if (!strcmp(buf, "smooth")) pd.normals_mode = 1; else if (!strcmp(buf, "mesh")) pd.normals_mode = 2;
+    }
+  }
+  /* scene.worldTransforms */
+  fspt_world_transform wt[MAX_WORLD];
+  static double wrot[MAX_WORLD][4 * 16];
+  uint32_t nworld = 0;
+  bool isarr = false;
+  memset(wt, 0, sizeof(wt));
+  napi_is_array(env, a[3], &isarr);
+  if (isarr) {
+    napi_get_array_length(env, a[3], &nworld);
+    if (nworld > MAX_WORLD) { napi_throw_range_error(env, NULL, "fspt_napi: too many worldTransforms (max 16)"); return NULL; }
+    for (uint32_t i = 0; i < nworld; ++i) {
+      napi_value e; bool has;
+      napi_get_element(env, a[3], i, &e);
+      if (read_rotations(env, e, wrot[i], 16, &wt[i].n_rotate, &has)) return NULL;
+      wt[i].rotate = wrot[i]; wt[i].has_rotate = has ? 1u : 0u;
+      if (!has) { if (read_vec3(env, e, "translate", wt[i].translate, &has)) return NULL; wt[i].has_translate = has ? 1u : 0u; }
+    }
+  }
+  /* prop.skips */
+  char *skips[64]; uint32_t nskips = 0;
+  napi_is_array(env, a[4], &isarr);
+  if (isarr) {
+    uint32_t n = 0;
+    napi_get_array_length(env, a[4], &n);
+    if (n > 64) n = 64;
+    for (uint32_t i = 0; i < n; ++i) {
+      napi_value e; size_t len;
+      napi_get_element(env, a[4], i, &e);
+      napi_value str;
+      if (napi_coerce_to_string(env, e, &str) != napi_ok) continue;
+      skips[nskips] = dup_string(env, str, &len);
+      if (skips[nskips]) nskips++;
+    }
+  }
+  size_t len = 0;
+  char *text = dup_string(env, a[1], &len);
   napi_value result = NULL;
-  for (uint32_t i = 0; i < nprops; ++i) {
-    napi_value pr, v, m;
-    if (napi_get_element(env, a[0], i, &pr) != napi_ok) goto fail;
-    fspt_prop_desc pd;
-    memset(&pd, 0, sizeof(pd));
-    double rot[4 * 16];
-    uint32_t nrot = 0;
-    if (napi_get_named_property(env, pr, "rotate", &v) == napi_ok) {
-      bool isarr = false;
-      napi_is_array(env, v, &isarr);
-      if (isarr) {
-        napi_get_array_length(env, v, &nrot);
-        if (nrot > 16) nrot = 16;
-        for (uint32_t r = 0; r < nrot; ++r) {
-          napi_value re, ax, e;
-          napi_get_element(env, v, r, &re);
-          if (prop(env, re, "axis", &ax)) goto fail;
-          for (uint32_t k = 0; k < 3; ++k) { napi_get_element(env, ax, k, &e); if (get_f64(env, e, &rot[4 * r + k])) goto fail; }
-          if (prop_f64(env, re, "angle", 0.0, &rot[4 * r + 3])) goto fail;
-        }
-      }
-    }
-    pd.rotate = rot; pd.n_rotate = nrot;
-    if (prop_f64(env, pr, "scale", 1.0, &pd.scale)) goto fail;
-    if (napi_get_named_property(env, pr, "translate", &v) == napi_ok) {
-      bool isarr = false;
-      napi_is_array(env, v, &isarr);
-      if (isarr) for (uint32_t k = 0; k < 3; ++k) { napi_value e; napi_get_element(env, v, k, &e); if (get_f64(env, e, &pd.translate[k])) goto fail; }
-    }
-    pd.normals_mode = 0;
-    if (napi_get_named_property(env, pr, "normals", &v) == napi_ok) {
-      char buf[16]; size_t len = 0;
-      if (napi_get_value_string_utf8(env, v, buf, sizeof(buf), &len) == napi_ok) {
-        if (!strcmp(buf, "smooth")) pd.normals_mode = 1; else if (!strcmp(buf, "mesh")) pd.normals_mode = 2;
-      }
-    }
-    if (prop(env, pr, "material", &m)) goto fail;
-    if (prop_f64(env, m, "diffuseIndex", 0, &pd.diffuse_layer) || prop_f64(env, m, "specularIndex", 0, &pd.emissive_layer) ||
-        prop_f64(env, m, "normalIndex", 0, &pd.normal_layer) || prop_f64(env, m, "roughnessIndex", 0, &pd.mr_layer) ||
-        prop_f64(env, m, "ior", 1.4, &pd.ior) || prop_f64(env, m, "dielectric", -1, &pd.dielectric)) goto fail;
-    if (napi_get_named_property(env, m, "emittance", &v) == napi_ok) {
-      bool isarr = false;
-      napi_is_array(env, v, &isarr);
-      if (isarr) for (uint32_t k = 0; k < 3; ++k) { napi_value e; napi_get_element(env, v, k, &e); if (get_f64(env, e, &pd.emittance[k])) goto fail; }
-    }
-    if (prop(env, pr, "obj", &v)) goto fail;
-    size_t len = 0;
-    if (napi_get_value_string_utf8(env, v, NULL, 0, &len) != napi_ok) { napi_throw_type_error(env, NULL, "prop.obj must be the OBJ text"); goto fail; }
-    char *text = (char *)malloc(len + 1);
-    napi_get_value_string_utf8(env, v, text, len + 1, &len);
-    int rc = fspt_builder_add_obj(b, text, len, &pd);
+  if (text) {
+    uint32_t ng = 0;
+    int rc = fspt_builder_parse_obj(b, text, len, &pd, wt, nworld, (const char *const *)skips, nskips, &ng);
     free(text);
-    if (rc) { char msg[640]; snprintf(msg, sizeof(msg), "libfspt error %d: %s", rc, fspt_last_error()); napi_throw_error(env, NULL, msg); goto fail; }
+    if (rc) {
+      char msg[640]; snprintf(msg, sizeof(msg), "libfspt error %d: %s", rc, fspt_last_error()); napi_throw_error(env, NULL, msg);
+    } else {
+      napi_create_array_with_length(env, ng, &result);
+      for (uint32_t g = 0; g < ng; ++g) {
+        const char *name; uint32_t nt; int32_t mi;
+        fspt_builder_group_info(b, g, &name, &nt, &mi);
+        napi_value o, vv;
+        napi_create_object(env, &o);
+        napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &vv); napi_set_named_property(env, o, "name", vv);
+        napi_create_uint32(env, nt, &vv); napi_set_named_property(env, o, "nTris", vv);
+        if (mi >= 0) { const char *ln; fspt_builder_mtllib_name(b, (uint32_t)mi, &ln); napi_create_string_utf8(env, ln, NAPI_AUTO_LENGTH, &vv); }
+        else napi_get_null(env, &vv);
+        napi_set_named_property(env, o, "mtllib", vv);
+        napi_set_element(env, result, g, o);
+      }
+    }
+  }
+  for (uint32_t i = 0; i < nskips; ++i) free(skips[i]);
+  return result;
+}
+/* builderCommit(b, [{diffuseIndex, specularIndex, normalIndex, roughnessIndex, emittance[3], ior, dielectric}]) */
+static napi_value BuilderCommit(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h;
+  if (get_args(env, info, 2, a)) return NULL;
+  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  uint32_t n = 0;
+  NAPI_OK(napi_get_array_length(env, a[1], &n));
+  fspt_group_material *gm = (fspt_group_material *)calloc(n ? n : 1, sizeof(*gm));
+  napi_value result = NULL;
+  for (uint32_t i = 0; i < n; ++i) {
+    napi_value m; bool present;
+    napi_get_element(env, a[1], i, &m);
+    if (prop_f64(env, m, "diffuseIndex", 0, &gm[i].diffuse_layer) || prop_f64(env, m, "specularIndex", 0, &gm[i].emissive_layer) ||
+        prop_f64(env, m, "normalIndex", 0, &gm[i].normal_layer) || prop_f64(env, m, "roughnessIndex", 0, &gm[i].mr_layer) ||
+        prop_f64(env, m, "ior", 1.4, &gm[i].ior) || prop_f64(env, m, "dielectric", -1, &gm[i].dielectric) ||
+        read_vec3(env, m, "emittance", gm[i].emittance, &present)) goto done;
   }
   {
-    int rc = fspt_builder_build(b, leaf);
-    if (rc) { char msg[640]; snprintf(msg, sizeof(msg), "libfspt error %d: %s", rc, fspt_last_error()); napi_throw_error(env, NULL, msg); goto fail; }
-    uint32_t nn, nt, depth;
-    fspt_builder_counts(b, &nn, &nt, &depth);
-    float *bvh, *tri, *mat, *norm, *uv;
-    napi_value o, v;
-    napi_create_object(env, &o);
-    napi_value tb = f32_out(env, (size_t)nn * 9, &bvh), tt = f32_out(env, (size_t)nt * 9, &tri), tm = f32_out(env, (size_t)nt * 12, &mat),
-               tn = f32_out(env, (size_t)nt * 27, &norm), tu = f32_out(env, (size_t)nt * 6, &uv);
-    if (!tb || !tt || !tm || !tn || !tu) { napi_throw_error(env, NULL, "fspt_napi: allocation failed"); goto fail; }
-    fspt_builder_get(b, bvh, tri, mat, norm, uv);
-    napi_set_named_property(env, o, "bvh", tb); napi_set_named_property(env, o, "tri", tt); napi_set_named_property(env, o, "mat", tm);
-    napi_set_named_property(env, o, "norm", tn); napi_set_named_property(env, o, "uv", tu);
-    napi_create_uint32(env, depth, &v); napi_set_named_property(env, o, "depth", v);
-    result = o;
+    int rc = fspt_builder_commit_obj((fspt_builder *)h, gm, n);
+    if (rc) { char msg[640]; snprintf(msg, sizeof(msg), "libfspt error %d: %s", rc, fspt_last_error()); napi_throw_error(env, NULL, msg); goto done; }
+    result = undefined(env);
   }
-fail:
-  fspt_builder_destroy(b);
+done:
+  free(gm);
   return result;
+}
+static napi_value BuilderNormalize(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h; double size;
+  if (get_args(env, info, 2, a)) return NULL;
+  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  if (get_f64(env, a[1], &size)) return NULL;
+  FSPT_OK_OR_THROW(fspt_builder_normalize((fspt_builder *)h, size));
+  return undefined(env);
+}
+/* builderBuild(b, leafSize) -> {bvh,tri,mat,norm,uv: Float32Array, depth} */
+static napi_value BuilderBuild(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h; uint32_t leaf = 4;
+  if (get_args(env, info, 2, a)) return NULL;
+  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  NAPI_OK(napi_get_value_uint32(env, a[1], &leaf));
+  fspt_builder *b = (fspt_builder *)h;
+  FSPT_OK_OR_THROW(fspt_builder_build(b, leaf));
+  uint32_t nn, nt, depth;
+  fspt_builder_counts(b, &nn, &nt, &depth);
+  float *bvh, *tri, *mat, *norm, *uv;
+  napi_value o, v;
+  napi_create_object(env, &o);
+  napi_value tb = f32_out(env, (size_t)nn * 9, &bvh), tt = f32_out(env, (size_t)nt * 9, &tri), tm = f32_out(env, (size_t)nt * 12, &mat),
+             tn = f32_out(env, (size_t)nt * 27, &norm), tu = f32_out(env, (size_t)nt * 6, &uv);
+  if (!tb || !tt || !tm || !tn || !tu) { napi_throw_error(env, NULL, "fspt_napi: allocation failed"); return NULL; }
+  fspt_builder_get(b, bvh, tri, mat, norm, uv);
+  napi_set_named_property(env, o, "bvh", tb); napi_set_named_property(env, o, "tri", tt); napi_set_named_property(env, o, "mat", tm);
+  napi_set_named_property(env, o, "norm", tn); napi_set_named_property(env, o, "uv", tu);
+  napi_create_uint32(env, depth, &v); napi_set_named_property(env, o, "depth", v);
+  return o;
+}
+/* builderAutofocus(b, eye[3], dir[3]) -> distance (shootAutoFocusRay, main.js:447-546) */
+static napi_value BuilderAutofocus(napi_env env, napi_callback_info info) {
+  napi_value a[3]; void *h; double eye[3], dir[3], dist = 0;
+  if (get_args(env, info, 3, a)) return NULL;
+  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  for (uint32_t k = 0; k < 3; ++k) {
+    napi_value e;
+    napi_get_element(env, a[1], k, &e); if (get_f64(env, e, &eye[k])) return NULL;
+    napi_get_element(env, a[2], k, &e); if (get_f64(env, e, &dir[k])) return NULL;
+  }
+  FSPT_OK_OR_THROW(fspt_builder_autofocus((fspt_builder *)h, eye, dir, &dist));
+  napi_value v;
+  NAPI_OK(napi_create_double(env, dist, &v));
+  return v;
 }
 static napi_value EnvBins(napi_env env, napi_callback_info info) {
   napi_value a[3]; void *p; size_t n; uint32_t w, h;
@@ -428,7 +551,9 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"render", Render}, {"clear", Clear},
       {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setPipeline", SetPipeline},
-      {"enableCounters", EnableCounters}, {"counters", GetCounters}, {"buildScene", BuildScene}, {"envBins", EnvBins},
+      {"enableCounters", EnableCounters}, {"counters", GetCounters}, {"builderCreate", BuilderCreate}, {"builderDestroy", BuilderDestroy},
+      {"builderParseObj", BuilderParseObj}, {"builderCommit", BuilderCommit}, {"builderNormalize", BuilderNormalize},
+      {"builderBuild", BuilderBuild}, {"builderAutofocus", BuilderAutofocus}, {"envBins", EnvBins},
       {"randBaseNext", RandBaseNext}, {"deviceCount", DeviceCount}, {"abiVersion", AbiVersion}};
   for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
     napi_value f;

@@ -4,7 +4,8 @@
  *
  * Mirrors the reference's own host code so that main.js can switch from WebGL2
  * to the MI355X kernels with the same call order (INTEGRATION.md):
- *   TexturePacker / getMaterial   texture_packer.js:5-63, main.js:206-270 (colour-valued maps)
+ *   TexturePacker / getMaterial / parseMaterials / mergeSceneProps
+ *                                 texture_packer.js:5-63, main.js:206-270,869-871, mtl_loader.js (images: decoded RGBA8)
  *   packReferenceScene            main.js:355-392 + maskBVHBuffer 272-282, fed with the
  *                                 reference's own BVH / Triangle objects (bvh.js, obj_loader.js)
  *   buildScene                    native obj_loader.js + bvh.js (same decisions, float64) for
@@ -16,12 +17,67 @@ const addon = require('./fspt_napi.node');
 
 function jsNum(v) { return String(Number(v)); }
 
+const f = Math.fround;
+
+/** WebGLTextureWriter.setAndDrawTexture + its shader (texture_packer.js:103-121,159-175) on the CPU, float32:
+ *  bilinear (S = REPEAT, T = CLAMP_TO_EDGE) resample of a decoded image {width, height, data: RGBA8, row 0 = top}
+ *  to res x res at uv = (x+.5, res-(y+.5))/res, sRGB -> linear before filtering when `corrected`, channel swizzle,
+ *  rgb premultiplied by alpha, alpha = 1.  Output row 0 = bottom (readPixels).  Same arithmetic as scene.py. */
+function resampleImage(img, res, corrected, swizzle) {
+  const w = img.width, h = img.height, sw = swizzle || [0, 1, 2, 3];
+  const lut = new Float32Array(256), lin = new Float32Array(256);
+  for (let i = 0; i < 256; i++) {
+    const c = f(i / 255);
+    lin[i] = c;
+    lut[i] = c <= 0.04045 ? f(c / 12.92) : f(Math.pow(f(f(c + 0.055) / 1.055), 2.4));
+  }
+  const out = new Uint8Array(res * res * 4);
+  const i0 = new Int32Array(res), i1 = new Int32Array(res), ax = new Float32Array(res);
+  for (let x = 0; x < res; x++) {
+    const px = f(f(x + 0.5) / res), u = f(f(px * w) - 0.5), fl = Math.floor(u);
+    ax[x] = f(u - fl);
+    i0[x] = ((fl % w) + w) % w; i1[x] = (((fl + 1) % w) + w) % w;
+  }
+  const c = new Float32Array(4);
+  for (let y = 0; y < res; y++) {
+    const py = f(f(y + 0.5) / res), v = f(f(f(1 - py) * h) - 0.5), fl = Math.floor(v), by = f(v - fl);
+    const j0 = Math.min(Math.max(fl, 0), h - 1), j1 = Math.min(Math.max(fl + 1, 0), h - 1);
+    for (let x = 0; x < res; x++) {
+      const a = ax[x], na = f(1 - a), nb = f(1 - by);
+      for (let k = 0; k < 4; k++) {
+        const t = (k < 3 && corrected) ? lut : lin;
+        const p00 = t[img.data[(j0 * w + i0[x]) * 4 + k]], p01 = t[img.data[(j0 * w + i1[x]) * 4 + k]];
+        const p10 = t[img.data[(j1 * w + i0[x]) * 4 + k]], p11 = t[img.data[(j1 * w + i1[x]) * 4 + k]];
+        const top = f(f(p00 * na) + f(p01 * a)), bot = f(f(p10 * na) + f(p11 * a));
+        c[k] = f(f(top * nb) + f(bot * by));
+      }
+      const al = c[sw[3]], o = (y * res + x) * 4;
+      for (let k = 0; k < 3; k++) {
+        const q = Math.floor(f(f(f(c[sw[k]] * al) * 255) + 0.5));
+        out[o + k] = Math.min(Math.max(q, 0), 255);
+      }
+      out[o + 3] = 255;
+    }
+  }
+  return out;
+}
+
+/** texture_packer.js:5-63; images are decoded RGBA8 objects {currentSrc, width, height, data} instead of
+ *  HTMLImageElements, and the atlas is written on the CPU (resampleImage) instead of by a WebGL context. */
 class TexturePacker {
   constructor(atlasRes) { this.res = atlasRes || 2048; this.imageSet = []; this.imageKeys = {}; this.maxRes = 1; }
+  addTexture(image, corrected) {
+    if (this.imageKeys[image.currentSrc]) return this.imageKeys[image.currentSrc];
+    this.maxRes = Math.max(this.maxRes, image.height);
+    image.corrected = corrected;
+    this.imageSet.push(image);
+    this.imageKeys[image.currentSrc] = this.imageSet.length - 1;
+    return this.imageKeys[image.currentSrc];
+  }
   addColor(color) {
-    const key = color.map(jsNum).join(' ');
+    const key = color.join(' ');
     if (this.imageKeys[key]) return this.imageKeys[key];   // index 0 is falsy: never de-duplicated (texture_packer.js:27)
-    this.imageSet.push(color.map(Number));
+    this.imageSet.push(color);
     this.imageKeys[key] = this.imageSet.length - 1;
     return this.imageKeys[key];
   }
@@ -30,24 +86,90 @@ class TexturePacker {
     const res = this.setAndGetResolution();
     const out = new Uint8Array(res * res * 4 * this.imageSet.length);
     this.imageSet.forEach((c, i) => {
-      const px = [0, 1, 2].map((k) => Math.floor(Math.min(Math.max(c[k], 0), 1) * 255 + 0.5)).concat([255]);
-      for (let t = 0; t < res * res; t++) out.set(px, (i * res * res + t) * 4);
+      if (Array.isArray(c)) {   // gl.clearColor(c) + readPixels RGBA8 (texture_packer.js:152-157)
+        const px = [0, 1, 2].map((k) => Math.floor(Math.min(Math.max(Number(c[k]), 0), 1) * 255 + 0.5)).concat([255]);
+        for (let t = 0; t < res * res; t++) out.set(px, (i * res * res + t) * 4);
+      } else {
+        out.set(resampleImage(c, res, !!c.corrected, c.swizzle), i * res * res * 4);
+      }
     });
     return out;
   }
+  describe() {
+    return this.imageSet.map((e) => (Array.isArray(e) ? { color: e.map(Number) } :
+      { src: e.currentSrc, corrected: !!e.corrected, swizzle: e.swizzle ? Array.from(e.swizzle, Number) : null }));
+  }
 }
 
-function getMaterial(prop, packer) {
-  const colour = (v, d) => (Array.isArray(v) ? v : d);
+/** ParseMaterials (mtl_loader.js:3-43). */
+function parseMaterials(mtlText, basePath) {
+  const materials = {}, urls = new Set();
+  const scalarTokens = new Set(['ns', 'ni', 'd', 'illum', 'dielectric', 'ior']);
+  const vectorTokens = new Set(['ka', 'kd', 'kem', 'ks', 'ke', 'pr', 'pm', 'pmr', 'pmr_swizzle']);
+  const stringTokens = new Set(['map_bump', 'map_kd', 'map_kem', 'map_ks', 'map_d', 'map_ns', 'map_pmr']);
+  let mtlName = null;
+  for (const line of mtlText.split('\n')) {
+    const tokens = line.trim().split(/[ ]+/), key = tokens[0].toLowerCase();
+    if (key === 'newmtl') { mtlName = tokens[1]; materials[mtlName] = {}; }
+    if (!mtlName) continue;
+    let value, isUrl = false;
+    if (scalarTokens.has(key)) value = parseFloat(tokens[1]);
+    else if (vectorTokens.has(key)) value = tokens.slice(1).map(parseFloat);
+    else if (stringTokens.has(key)) { value = tokens[1]; isUrl = true; }
+    if (value) {
+      if (isUrl) urls.add(basePath + '/' + value);
+      materials[mtlName][key] = value;
+    }
+  }
+  return { materials, urls };
+}
+
+/** getMaterial (main.js:206-270), same signature: the OBJ group's MTL entry wins over the prop's scene-JSON fields;
+ *  assets = {url: decoded image}. */
+function getMaterial(transforms, group, texturePacker, assets, basePath) {
+  const gm = (group && group.material) || {};
+  const asset = (url) => {
+    if (!assets || !assets[url]) throw new Error('texture ' + url + ' is not in assets');
+    if (!assets[url].currentSrc) assets[url].currentSrc = url;
+    return assets[url];
+  };
   const material = {};
-  material.diffuseIndex = packer.addColor(colour(prop.diffuse, [0.5, 0.5, 0.5]));
-  material.roughnessIndex = packer.addColor(colour(prop.metallicRoughness, [0.0, 0.3, 0]));
-  material.specularIndex = packer.addColor(colour(prop.emission, [0, 0, 0]));
-  material.normalIndex = packer.addColor([0.5, 0.5, 1]);
-  material.ior = prop.ior || 1.4;
-  material.dielectric = prop.dielectric || -1;
-  material.emittance = prop.emittance || [0, 0, 0];
+  if (gm.map_kd) material.diffuseIndex = texturePacker.addTexture(asset(basePath + '/' + gm.map_kd), true);
+  else if (gm.kd) material.diffuseIndex = texturePacker.addColor(gm.kd);
+  else if (typeof transforms.diffuse === 'string') material.diffuseIndex = texturePacker.addTexture(asset(transforms.diffuse), true);
+  else if (typeof transforms.diffuse === 'object' && transforms.diffuse) material.diffuseIndex = texturePacker.addColor(transforms.diffuse);
+  else material.diffuseIndex = texturePacker.addColor([0.5, 0.5, 0.5]);
+
+  if (gm.map_pmr) {
+    const img = asset(basePath + '/' + gm.map_pmr);
+    img.swizzle = gm.pmr_swizzle;            // set on the shared image before de-duplication: the last use decides
+    material.roughnessIndex = texturePacker.addTexture(img);
+  } else if (gm.pmr) material.roughnessIndex = texturePacker.addColor(gm.pmr);
+  else if (typeof transforms.metallicRoughness === 'string') {
+    const img = asset(transforms.metallicRoughness);
+    img.swizzle = transforms.mrSwizzle;
+    material.roughnessIndex = texturePacker.addTexture(img);
+  } else if (typeof transforms.metallicRoughness === 'object' && transforms.metallicRoughness) {
+    material.roughnessIndex = texturePacker.addColor(transforms.metallicRoughness);
+  } else material.roughnessIndex = texturePacker.addColor([0.0, 0.3, 0]);
+
+  if (gm.map_kem) material.specularIndex = texturePacker.addTexture(asset(basePath + '/' + gm.map_kem));
+  else if (gm.kem) material.specularIndex = texturePacker.addColor(gm.kem);
+  else if (typeof transforms.emission === 'string') material.specularIndex = texturePacker.addTexture(asset(transforms.emission));
+  else material.specularIndex = texturePacker.addColor([0, 0, 0]);
+
+  if (gm.map_bump) material.normalIndex = texturePacker.addTexture(asset(basePath + '/' + gm.map_bump));
+  else if (transforms.normal) material.normalIndex = texturePacker.addTexture(asset(transforms.normal));
+  else material.normalIndex = texturePacker.addColor([0.5, 0.5, 1]);
+  material.ior = Number(gm.ior || transforms.ior || 1.4);
+  material.dielectric = Number(gm.dielectric || transforms.dielectric || -1);
+  material.emittance = transforms.emittance || [0, 0, 0];
   return material;
+}
+
+/** mergeSceneProps (main.js:869-871) */
+function mergeSceneProps(scene) {
+  return [].concat((scene.props || []), (scene.static_props || []), Object.values(scene.animated_props || []));
 }
 
 /** main.js:355-392 for a reference `BVH` instance whose triangles carry `.material`. */
@@ -74,13 +196,45 @@ function packReferenceScene(bvh) {
            uv: new Float32Array(uv), depth: bvh.depth };
 }
 
-/** initBVH (main.js:284-445) through the native builder.  props: scene-JSON props, objTexts: {path: text}. */
-function buildScene(props, objTexts, env, leafSize) {
-  const packer = new TexturePacker();
-  const jobs = props.map((p) => ({ obj: objTexts[p.path], rotate: p.rotate || [], scale: p.scale === undefined ? 1 : p.scale,
-    translate: p.translate || [0, 0, 0], normals: p.normals || 'flat', material: getMaterial(p, packer) }));
-  const s = addon.buildScene(jobs, leafSize || 4);
+/** initBVH (main.js:284-445) through the native builder (same decisions, float64).
+ *  sceneOrProps: the scene JSON (props / static_props / animated_props, worldTransforms, normalize, atlasRes) or a
+ *  bare props array; objTexts: {path: OBJ text}; env: {rgbe, width, height} | null;
+ *  opts: {mtlTexts: {url: MTL text}, assets: {url: decoded image}, focusRays: [[eye, dir], ...]}. */
+function buildScene(sceneOrProps, objTexts, env, leafSize, opts) {
+  opts = opts || {};
+  const scene = Array.isArray(sceneOrProps) ? { props: sceneOrProps } : sceneOrProps;
+  const props = mergeSceneProps(scene);
+  const packer = new TexturePacker(scene.atlasRes || 2048);
+  const b = addon.builderCreate();
+  let s;
+  try {
+    for (const p of props) {
+      const basePath = p.path.split('/').slice(0, -1).join('/');
+      const groups = addon.builderParseObj(b, objTexts[p.path], { rotate: p.rotate || [], scale: p.scale === undefined ? 1 : p.scale,
+        translate: p.translate || [0, 0, 0], normals: p.normals || 'flat' }, scene.worldTransforms || null, p.skips || null);
+      const libs = {};
+      const mats = groups.map((g) => {
+        let material = {};
+        if (g.mtllib !== null) {
+          const url = basePath + '/' + g.mtllib;
+          if (!libs[url]) {
+            if (!opts.mtlTexts || opts.mtlTexts[url] === undefined) throw new Error('mtllib ' + url + ' is not in opts.mtlTexts');
+            libs[url] = parseMaterials(opts.mtlTexts[url], basePath).materials;
+          }
+          material = libs[url][g.name] || {};
+        }
+        return getMaterial(p, { material }, packer, opts.assets, basePath);
+      });
+      addon.builderCommit(b, mats);
+    }
+    if (scene.normalize) addon.builderNormalize(b, scene.normalize);
+    s = addon.builderBuild(b, leafSize || 4);
+    s.focus = (opts.focusRays || []).map(([eye, dir]) => 1 - 1 / addon.builderAutofocus(b, eye, dir));   // main.js:544
+  } finally {
+    addon.builderDestroy(b);
+  }
   s.atlas = packer.getPixels(); s.atlasRes = packer.res; s.atlasLayers = packer.imageSet.length;
+  s.layers = packer.describe();
   if (env) { s.env = env.rgbe; s.envW = env.width; s.envH = env.height; s.bins = addon.envBins(env.rgbe, env.width, env.height); }
   else { s.env = null; s.envW = 0; s.envH = 0; s.bins = new Uint32Array([0, 0, 1, 2048]); }   // main.js:292
   s.leafSize = leafSize || 4;
@@ -168,4 +322,5 @@ class PathTracer {
   close() { if (this._target) { addon.targetDestroy(this._target); addon.sceneDestroy(this._scene); this._target = null; } }
 }
 
-module.exports = { addon, TexturePacker, getMaterial, packReferenceScene, buildScene, PathTracer, saveBlob, loadBlob };
+module.exports = { addon, TexturePacker, getMaterial, parseMaterials, mergeSceneProps, resampleImage, packReferenceScene, buildScene,
+  PathTracer, saveBlob, loadBlob };

@@ -16,6 +16,16 @@ if (mode === 'exports') {
   const s = F.buildScene(job.props, job.objs, env, 4);
   for (const k of ['bvh', 'tri', 'mat', 'norm', 'uv', 'bins', 'atlas']) out[k] = b64(s[k]);
   out.depth = s.depth; out.atlasLayers = s.atlasLayers;
+} else if (mode === 'build_full') {
+  // whole scene JSON: MTL group materials, decoded images, worldTransforms, normalize, auto-focus rays
+  const assets = {};
+  for (const [url, im] of Object.entries(job.images)) {
+    assets[url] = { width: im.width, height: im.height, data: Uint8Array.from(Buffer.from(im.rgba_b64, 'base64')) };
+  }
+  const s = F.buildScene(job.scene, job.objs, env, 4, { mtlTexts: job.files, assets, focusRays: job.focus_rays });
+  for (const k of ['bvh', 'tri', 'mat', 'norm', 'uv', 'bins', 'atlas']) out[k] = b64(s[k]);
+  out.depth = s.depth; out.atlasLayers = s.atlasLayers; out.atlasRes = s.atlasRes; out.layers = s.layers;
+  out.focus = b64(new Float64Array(s.focus));
 } else if (mode === 'blob') {
   // read a blob written by Python, write it back from JS
   const s = F.loadBlob(job.blob_in);

@@ -41,7 +41,8 @@ def test_addon_exports():
     out = run_node("exports", {})
     assert out["abi"] == 1
     for name in ("sceneCreate", "targetCreate", "camera", "trace", "render", "clear", "readRadiance", "setShard",
-                 "buildScene", "envBins", "counters"):
+                 "builderCreate", "builderParseObj", "builderCommit", "builderNormalize", "builderBuild",
+                 "builderAutofocus", "builderDestroy", "envBins", "counters"):
         assert name in out["exports"]
 
 
@@ -54,6 +55,31 @@ def test_js_build_scene_matches_python_host(small_scene):
     assert np.array_equal(dec(out["bins"], np.uint32), small_scene.bins)
     assert np.array_equal(dec(out["atlas"], np.uint8), small_scene.atlas)
     assert out["depth"] == small_scene.depth
+
+
+def test_js_full_scene_build_matches_reference_js():
+    """The JS host's own getMaterial / parseMaterials / mergeSceneProps / TexturePacker over the native builder:
+    the 'mtl' golden scene (MTL groups, image maps, worldTransforms, normalize, static + animated props) gives
+    the arrays, layer list and auto-focus values of the reference's JS pipeline, and the Python host's atlas."""
+    from test_goldens import load_js, stand_in_images, native_build
+    z, scene, texts, files = load_js("mtl")
+    imgs = stand_in_images(z)
+    job = {"scene": scene, "objs": texts, "files": files, "focus_rays": z["focus_rays"].tolist(),
+           "images": {u: {"width": int(a.shape[1]), "height": int(a.shape[0]),
+                          "rgba_b64": base64.b64encode(a.tobytes()).decode()} for u, a in imgs.items()},
+           "env": {"rgbe_b64": base64.b64encode(z["env"].tobytes()).decode(), "width": int(z["env_w"]), "height": int(z["env_h"])}}
+    out = run_node("build_full", job)
+    for k in ("bvh", "tri", "mat", "norm", "uv"):
+        assert np.array_equal(dec(out[k], np.uint32), z[k].view(np.uint32)), k
+    assert np.array_equal(dec(out["bins"], np.uint32), z["bins"])
+    assert out["layers"] == json.loads(str(z["image_set"]))
+    assert np.array_equal(dec(out["focus"], np.uint64), z["focus"].view(np.uint64))
+    _, nat = native_build("mtl")
+    assert (out["atlasRes"], out["atlasLayers"]) == (nat.atlas_res, nat.atlas_layers)
+    got = dec(out["atlas"], np.uint8).astype(np.int16)
+    # same float32 filter arithmetic; only pow() of the sRGB decode may round differently (V8 vs numpy)
+    assert np.abs(got - nat.atlas.astype(np.int16)).max() <= 1
+    assert (got != nat.atlas).mean() < 1e-3
 
 
 def test_js_host_fails_loudly_without_gpu():
