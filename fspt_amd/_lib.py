@@ -90,6 +90,7 @@ SIGNATURES = {
     "fspt_set_rays": (C.c_int, [_VP, _F, _F]),
     "fspt_read_rays": (C.c_int, [_VP, _F, _F]),
     "fspt_trace": (C.c_int, [_VP, C.c_uint32, C.c_float, C.c_float, C.c_uint32]),
+    "fspt_trace_test": (C.c_int, [_VP, C.c_uint32]),
     "fspt_render": (C.c_int, [_VP, C.POINTER(CameraParams), C.c_uint32, C.c_uint32, C.c_uint64]),
     "fspt_rand_base_next": (C.c_float, [C.POINTER(C.c_uint64)]),
     "fspt_clear": (C.c_int, [_VP]),

@@ -578,6 +578,21 @@ int fspt_trace(fspt_target *t, uint32_t tick, float rand_base, float env_theta, 
   return FSPT_OK;
 }
 
+int fspt_trace_test(fspt_target *t, uint32_t tick) {
+  if (!t) { fspt_set_error("fspt_trace_test: NULL target"); return FSPT_E_INVALID; }
+  if (!t->rays_valid) { fspt_set_error("fspt_trace_test: call fspt_camera or fspt_set_rays first"); return FSPT_E_STATE; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  fspt::TraceP p{};
+  fill_trace_params(t, p);
+  p.tick = tick;
+  t->ev_used = 0;
+  HIP_TRY(hipEventRecord(t->ev0, t->stream));
+  HIP_TRY(fspt::launch_bvh_test(p, t->stream));
+  HIP_TRY(hipEventRecord(t->ev1, t->stream));
+  t->timed = true; t->last_launches = 1;
+  return FSPT_OK;
+}
+
 int fspt_render(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks, uint64_t seed) {
   if (!t || !cam) { fspt_set_error("fspt_render: NULL argument"); return FSPT_E_INVALID; }
   if (n_ticks == 0) return FSPT_OK;

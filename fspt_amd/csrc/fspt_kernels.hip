@@ -1220,6 +1220,33 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_intersect(const IntersectP p)
   if (p.leaves_out) p.leaves_out[i] = cnt.leaves;
 }
 
+// bvh_test.fs main (224-232): traversal-step heat map of the camera rays, the reference's `mode=test`
+__global__ __launch_bounds__(BLOCK_THREADS) void k_bvh_test(const TraceP p) {
+  extern __shared__ int lds_stack[];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  int *stack = lds_stack + (size_t)wave * p.scene.stack_n * WAVE + lane;
+  const uint32_t work_total = p.n_owned_tiles * p.tile * p.tile;
+  uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t x, y;
+  if (w >= work_total || !work_to_pixel(p, w, x, y)) return;
+  uint32_t pix = y * p.W + x;
+  float4 po = p.ray_pos[pix], di = p.ray_dir[pix];
+  V3 o = v3(po.x, po.y, po.z), d = v3(di.x, di.y, di.z);
+  Counters cnt = {0, 0, 0, 0, 0, 0};
+  int hitA, hitB;
+  float tB;
+  trace_rays<true>(p.scene, stack, o, false, d, d, hitA, tB, hitB, cnt);
+  float c = (float)cnt.steps * 0.001f;
+  float ft = (float)p.tick, den = ft + 1.0f;
+  float4 prev = p.accum[pix], o4;
+  o4.x = fma_(prev.x, ft, c) / den;
+  o4.y = fma_(prev.y, ft, c) / den;
+  o4.z = fma_(prev.z, ft, c) / den;
+  o4.w = 1.0f;
+  p.accum[pix] = o4;
+}
+
 __global__ void k_math(int op, const float *a, const float *b, uint32_t n, float *out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1314,6 +1341,14 @@ hipError_t launch_draw(const float4 *acc, uint32_t W, uint32_t H, float exposure
   uint32_t n = W * H;
   hipLaunchKernelGGL(k_draw, dim3((n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS), 0, stream, acc, W, H,
                      exposure, saturation, denoise, max_sigma, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_bvh_test(const TraceP &p, hipStream_t stream) {
+  uint32_t n = p.n_owned_tiles * p.tile * p.tile;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_bvh_test, dim3((n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS), stack_bytes(p.scene),
+                     stream, p);
   return hipGetLastError();
 }
 

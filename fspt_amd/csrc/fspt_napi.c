@@ -12,6 +12,7 @@
  *   targetCreate(scene, W, H)                      -> target handle  (initBuffers, main.js:598-617)
  *   camera(target, P[3], I[3], fovScale, lens[2], randBase)          (drawCamera, main.js:741-756)
  *   trace(target, tick, randBase, envTheta, numBounces)              (drawTracer, main.js:758-807)
+ *   traceTest(target, tick)                                          (drawTracer with bvh_test.fs, mode=test)
  *   render(target, {P,I,fovScale,lens,envTheta,numBounces}, firstTick, nTicks, seed)
  *   clear(target) / sync(target)                                     (clear, main.js:826-836)
  *   readRadiance(target, Float32Array(W*H*4))                        (what draw.fs:87 reads)
@@ -195,6 +196,14 @@ static napi_value Camera(napi_env env, napi_callback_info info) {
   if (float_list(env, a[1], P, 3) || float_list(env, a[2], I, 3) || get_f64(env, a[3], &fov) || float_list(env, a[4], lens, 2) ||
       get_f64(env, a[5], &rb)) return NULL;
   FSPT_OK_OR_THROW(fspt_camera((fspt_target *)h, P, I, (float)fov, lens, (float)rb));
+  return undefined(env);
+}
+static napi_value TraceTest(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h; uint32_t tick;
+  if (get_args(env, info, 2, a)) return NULL;
+  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  NAPI_OK(napi_get_value_uint32(env, a[1], &tick));
+  FSPT_OK_OR_THROW(fspt_trace_test((fspt_target *)h, tick));
   return undefined(env);
 }
 static napi_value Trace(napi_env env, napi_callback_info info) {
@@ -549,7 +558,7 @@ static napi_value AbiVersion(napi_env env, napi_callback_info info) {
 static napi_value Init(napi_env env, napi_value exports) {
   struct { const char *name; napi_callback fn; } fns[] = {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
-      {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"render", Render}, {"clear", Clear},
+      {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"traceTest", TraceTest}, {"render", Render}, {"clear", Clear},
       {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setPipeline", SetPipeline},
       {"enableCounters", EnableCounters}, {"counters", GetCounters}, {"builderCreate", BuilderCreate}, {"builderDestroy", BuilderDestroy},
       {"builderParseObj", BuilderParseObj}, {"builderCommit", BuilderCommit}, {"builderNormalize", BuilderNormalize},

@@ -295,6 +295,7 @@ class PathTracer {
   _randBase() { return addon.randBaseNext(this._rng); }
   drawCamera(randBase) { addon.camera(this._target, this.eye, this.dir, this.fovScale, this.lensFeatures, randBase === undefined ? this._randBase() : randBase); }
   drawTracer(i, randBase) { addon.trace(this._target, i, randBase === undefined ? this._randBase() : randBase, this.envTheta, this.numBounces); }
+  drawTracerTest(i) { addon.traceTest(this._target, i); }   // mode=test: bvh_test.fs (main.js:879-883)
   tick() { this.drawCamera(); this.drawTracer(this.pingpong); this.pingpong++; }            // main.js:838-857
   render(nTicks) {
     addon.render(this._target, { P: this.eye, I: this.dir, fovScale: this.fovScale, lens: this.lensFeatures,

@@ -127,6 +127,10 @@ class PathTracer:
     def drawTracer(self, i, randBase):
         L.check(L.lib().fspt_trace(self._t, int(i), float(randBase), self.envTheta, self.num_bounces))
 
+    def drawTracerTest(self, i):
+        """drawTracer with bvh_test.fs (`mode=test`, main.js:879-883): traversal-step heat map."""
+        L.check(L.lib().fspt_trace_test(self._t, int(i)))
+
     def tick(self):
         """One iteration of main.js:838-857 (camera draw, trace draw, pingpong++)."""
         self.drawCamera(self.next_rand_base())

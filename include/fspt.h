@@ -134,6 +134,12 @@ int fspt_read_rays(fspt_target *target, float *pos, float *dir);
 int fspt_trace(fspt_target *target, uint32_t tick, float rand_base,
                float env_theta, uint32_t num_bounces);
 
+/* drawTracer in the reference's `mode=test` (main.js:879-883 swaps tracer.fs for bvh_test.fs): every
+ * pixel's camera ray is traced once and the number of traversal-loop iterations x 0.001 is folded into
+ * the accumulator's running mean (bvh_test.fs:224-232; no clamp).  Same ray buffers, accumulator, shard
+ * and read-out as fspt_trace. */
+int fspt_trace_test(fspt_target *target, uint32_t tick);
+
 /* tick() loop (main.js:838-857): n_ticks x (drawCamera + drawTracer) starting
  * at tick first_tick, with Math.random()*10000 (main.js:748,777) replaced by
  * the documented xorshift64* stream seeded with seed: per tick two draws,

@@ -614,6 +614,34 @@ void oracle_trace(const oracle_scene *s, uint32_t W, uint32_t H, const float *po
   }
 }
 
+/* bvh_test.fs main (224-232), the reference's `mode=test` replacement of tracer.fs (main.js:879-883): the
+ * number of traversal-loop iterations of the camera ray (bvh_test.fs:183, same loop as tracer.fs:366-404),
+ * times 0.001, in every colour channel, folded into the running mean WITHOUT the clamp of tracer.fs:516. */
+void oracle_trace_test(const oracle_scene *s, uint32_t W, uint32_t H, const float *pos, const float *dir,
+                       uint32_t tick, float *accum, uint32_t shard, uint32_t n_shards, uint32_t tile) {
+  if (n_shards == 0) n_shards = 1;
+  if (tile == 0) tile = 32;
+  uint32_t tiles_x = (W + tile - 1) / tile;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int64_t y = 0; y < (int64_t)H; ++y)
+    for (uint32_t x = 0; x < W; ++x) {
+      uint32_t tid = ((uint32_t)y / tile) * tiles_x + x / tile;
+      if (tid % n_shards != shard) continue;
+      size_t p = (size_t)y * W + x;
+      vec3 ro = v3(pos[p * 4], pos[p * 4 + 1], pos[p * 4 + 2]);
+      vec3 rd = v3(dir[p * 4], dir[p * 4 + 1], dir[p * 4 + 2]);
+      uint32_t st, lv;
+      (void)intersect_scene(s, ro, rd, NULL, &st, &lv);
+      float c = (float)st * 0.001f;
+      float ft = (float)tick, den = ft + 1.0f;
+      float *a = accum + p * 4;
+      a[0] = om_fma(a[0], ft, c) / den;
+      a[1] = om_fma(a[1], ft, c) / den;
+      a[2] = om_fma(a[2], ft, c) / den;
+      a[3] = 1.0f;
+    }
+}
+
 void oracle_intersect(const oracle_scene *s, const float *rays, uint32_t n, float *t_out, int32_t *index_out,
                       uint32_t *steps_out, uint32_t *leaves_out) {
 #pragma omp parallel for schedule(dynamic, 256)

@@ -104,6 +104,15 @@ def trace(arrays, W, H, pos, d, tick, rand_base, env_theta, num_bounces, accum, 
     return fh
 
 
+def trace_test(arrays, W, H, pos, d, tick, accum, shard=0, n_shards=1, tile=32):
+    """bvh_test.fs main (the reference's mode=test draw)."""
+    s = oscene(arrays)
+    pos = np.ascontiguousarray(pos, np.float32); d = np.ascontiguousarray(d, np.float32)
+    assert accum.dtype == np.float32 and accum.flags.c_contiguous
+    lib().oracle_trace_test(C.byref(s), C.c_uint32(W), C.c_uint32(H), _fp(pos), _fp(d), C.c_uint32(tick), _fp(accum),
+                            C.c_uint32(shard), C.c_uint32(n_shards), C.c_uint32(tile))
+
+
 def render(arrays, W, H, P, I, fov_scale, lens, env_theta, num_bounces, first_tick, n_ticks, seed, accum,
            counters=None, shard=0, n_shards=1, tile=32):
     s = oscene(arrays)

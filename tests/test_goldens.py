@@ -299,3 +299,24 @@ def test_scene_file_loader_matches_reference_arrays(tmp_path):
     img = stand_in_images(z)["models/tex/mr.png"]
     want = S.resample_image(img, a.atlas_res, False, (2, 1, 0, 3))
     assert np.array_equal(a.atlas.reshape(a.atlas_layers, a.atlas_res, a.atlas_res, 4)[1], want)
+
+
+@pytest.mark.parametrize("name,W,H", [("small", 64, 40), ("mtl", 48, 32)])
+def test_bvh_test_mode_counts_equal_reference_glsl(name, W, H):
+    """The reference's `mode=test` shader (bvh_test.fs, unmodified apart from the quad-replication fetch
+    substitution) run on SwiftShader: per-pixel traversal-loop iteration counts x 0.001, two ticks of running
+    mean.  Integer work counters -> exact: the oracle's traversal visits exactly the reference's node sequence
+    lengths for every camera ray, and the accumulate arithmetic is bit-equal."""
+    z = np.load(os.path.join(GOLD, "glsl_bvh_test.npz"))
+    a = scene_from_golden(name)
+    acc = np.zeros((H, W, 4), np.float32)
+    for tick in range(2):
+        O.trace_test(a, W, H, z[f"{name}_pos{tick}"], z[f"{name}_dir{tick}"], tick, acc)
+        want = z[f"{name}_img{tick}"]
+        assert np.array_equal(acc.view(np.uint32), want.view(np.uint32)), f"tick {tick}"
+    # and they are the step counters fspt_intersect / oracle_intersect report
+    rays = np.concatenate([z[f"{name}_pos1"][..., :3], z[f"{name}_dir1"][..., :3]], -1).reshape(-1, 6)
+    _, _, steps, _ = O.intersect(a, rays)
+    c0 = np.rint(z[f"{name}_img0"][..., 0] / np.float32(0.001))
+    c1 = np.rint((z[f"{name}_img1"][..., 0].astype(np.float64) * 2 - z[f"{name}_img0"][..., 0]) / 0.001)
+    assert np.array_equal(steps.reshape(H, W), c1) and c0.max() > 10

@@ -407,3 +407,29 @@ def test_frame_sequence_from_scene_files(tmp_path):
         assert np.array_equal(got, want), f"frame {n}"
         imgs.append(got)
     assert (imgs[0] != imgs[1]).mean() > 0.01  # the animated prop really moved
+
+
+def test_bvh_test_mode_bitwise(small_scene, camera):
+    """fspt_trace_test (bvh_test.fs, the reference's mode=test draw) == oracle, two ticks, full frame and as
+    the sum of 3 tile shards."""
+    W, H = 77, 45
+    pos0, d0 = O.camera(W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], 11.0)
+    pos1, d1 = O.camera(W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], 12.0)
+    want = np.zeros((H, W, 4), np.float32)
+    O.trace_test(small_scene, W, H, pos0, d0, 0, want)
+    O.trace_test(small_scene, W, H, pos1, d1, 1, want)
+    sc = Scene(small_scene)
+    total = np.zeros_like(want)
+    for shard, n in [(0, 1), (0, 3), (1, 3), (2, 3)]:
+        pt = PathTracer(sc, W, H)
+        pt.set_shard(shard, n, 16)
+        pt.setRays(pos0, d0); pt.drawTracerTest(0)
+        pt.setRays(pos1, d1); pt.drawTracerTest(1)
+        got = pt.readRadiance()
+        if n == 1:
+            assert np.array_equal(got, want)
+        else:
+            total += got
+    assert np.array_equal(total[..., :3], want[..., :3]) and want[..., 0].max() > 0.01
+    with pytest.raises(L.FsptError):
+        PathTracer(sc, 8, 8).drawTracerTest(0)  # no rays yet

@@ -90,6 +90,24 @@ def tracer_source(n_bins, leaf_size=4, replicate=True, num_bounces=None, main_ov
     return src
 
 
+def tracer_test_source(n_bins, leaf_size=4, replicate=True):
+    """bvh_test.fs (what main.js:879-883 swaps in for tracer.fs under mode=test) with the same preprocessor
+    lines; only the two camera-texture fetches of main() are re-pointed for the quad replication."""
+    src = read_shader("bvh_test.fs")
+    lines = src.split("\n")
+    lines[1:1] = [f"#define ENV_BINS {n_bins}", "#define NUM_LIGHT_RANGES 1", f"#define LEAF_SIZE {leaf_size}"]
+    src = "\n".join(lines)
+    if replicate:
+        a = "void main(void) {"
+        assert src.count(a) == 1
+        src = src.replace(a, a + "\n  vec2 FC = floor(gl_FragCoord.xy * 0.5) + vec2(0.5);")
+        for tex in ("cameraPosTex", "cameraDirTex"):
+            old = f"texelFetch({tex}, ivec2(gl_FragCoord), 0)"
+            assert src.count(old) == 1, old
+            src = src.replace(old, f"texelFetch({tex}, ivec2(FC), 0)")
+    return src
+
+
 class GlslRef:
     def __init__(self):
         self.lib = C.CDLL(_build())
@@ -131,6 +149,10 @@ class GlslRef:
 
     def tracer(self, num_bounces=None, main_override=None, leaf_size=4):
         src = tracer_source(self.n_bins, leaf_size, self.rep == 2, num_bounces, main_override)
+        self._ck(self.lib.gh_tracer_program(read_shader("tracer.vs").encode(), src.encode()))
+
+    def tracer_test(self, leaf_size=4):
+        src = tracer_test_source(self.n_bins, leaf_size, self.rep == 2)
         self._ck(self.lib.gh_tracer_program(read_shader("tracer.vs").encode(), src.encode()))
 
     def set_int(self, name, value):

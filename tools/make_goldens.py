@@ -333,6 +333,34 @@ def make_converged(name):
                         streams=np.int32([11, 12]))
 
 
+def make_bvh_test():
+    """bvh_test.fs (mode=test) on SwiftShader: traversal-iteration counts per pixel for injected camera rays, two
+    ticks (the second folds into the running mean) -> exact integers, stage D2's work counters."""
+    import glsl_ref as G
+    import oracle as O
+    out = {}
+    for name, (W, H) in (("small", (64, 40)), ("mtl", (48, 32))):
+        cam = dict(S.BUNNY_CAMERA)
+        lens = S.lens_features(cam["focal_depth"], cam["aperture"])
+        g = G.GlslRef()
+        arrays = load_scene(name)
+        g.scene(arrays)
+        g.target(W, H, replicate=True)
+        g.tracer_test()
+        imgs = []
+        for tick, rb in enumerate((4321.0, 99.5)):
+            pos, d = O.camera(W, H, cam["P"], cam["I"], cam["fov_scale"], lens, rb)
+            g.set_camera(pos, d)
+            g.draw_tracer(tick, 1.0, 0.0)
+            img, mism = g.read_screen(tick)
+            assert mism == 0, mism
+            out[f"{name}_pos{tick}"], out[f"{name}_dir{tick}"], out[f"{name}_img{tick}"] = pos, d, img
+            imgs.append(img)
+        print("bvh_test", name, "max count", float(imgs[0][..., 0].max()) / 0.001, "replica mismatches 0")
+        del g
+    np.savez_compressed(os.path.join(GOLD, "glsl_bvh_test.npz"), **out)
+
+
 def make_draw():
     """draw.fs (tonemap + firefly filter) on SwiftShader: HDR input = a converged golden image, with a few
     injected fireflies so the 5x5 filter has something to do."""
@@ -411,6 +439,8 @@ if __name__ == "__main__":
             make_textured()
         elif w == "atlas":
             make_atlas()
+        elif w == "bvhtest":
+            make_bvh_test()
         elif w == "draw":
             make_draw()
         elif w.startswith("converged:"):
