@@ -26,6 +26,12 @@ namespace fspt {
 using namespace fm;
 
 #define WAVE 64
+#ifndef FSPT_TAP2
+#define FSPT_TAP2 1
+#endif
+#ifndef WF_LOGIC_LDSTAB
+#define WF_LOGIC_LDSTAB 1
+#endif
 #define BLOCK_THREADS 256
 #define WAVES_PER_BLOCK (BLOCK_THREADS / WAVE)
 #define WORK_CHUNK 256u
@@ -199,10 +205,23 @@ FM_DEV Tap4 bilinear_taps(const uint32_t *texels, int w, int h, float s, float t
   int j1, j0w;
   if (repeat_t) { j1 = wrap_repeat(j0 + 1, h); j0w = wrap_repeat(j0, h); }
   else { j1 = wrap_clamp(j0 + 1, h); j0w = wrap_clamp(j0, h); }
+#if FSPT_TAP2
+  // the two taps of a row are neighbours unless the column wraps: one 8-byte load (dword-aligned) instead of two
+  // 4-byte loads - half the lane-requests on the vector-memory pipeline, same texel values
+  typedef uint32_t u2a __attribute__((ext_vector_type(2), aligned(4)));
+  const uint32_t *r0 = texels + (size_t)j0w * w, *r1 = texels + (size_t)j1 * w;
+  if (i1 == i0 + 1) {
+    u2a q0 = *reinterpret_cast<const u2a *>(r0 + i0), q1 = *reinterpret_cast<const u2a *>(r1 + i0);
+    r.t00 = q0.x; r.t10 = q0.y; r.t01 = q1.x; r.t11 = q1.y;
+  } else {
+    r.t00 = r0[i0]; r.t10 = r0[i1]; r.t01 = r1[i0]; r.t11 = r1[i1];
+  }
+#else
   r.t00 = texels[(size_t)j0w * w + i0];
   r.t10 = texels[(size_t)j0w * w + i1];
   r.t01 = texels[(size_t)j1 * w + i0];
   r.t11 = texels[(size_t)j1 * w + i1];
+#endif
   r.a = a; r.b = b;
   return r;
 }
@@ -990,16 +1009,42 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 // FIRST: round 1, where every path is a fresh primary: the queue is the identity (slot = index, validity
 // recomputed from the pixel mapping) and thr / colour / flags are constants, so neither is read - round 1
 // streams the whole batch's path state through HBM and is bandwidth-bound.
-template <bool COUNT, bool FIRST>
-__global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(const WfP p) {
+#ifndef WF_LOGIC_WAVES_FIRST
+#define WF_LOGIC_WAVES_FIRST WF_LOGIC_WAVES
+#endif
+#ifndef WF_LOGIC_U_FIRST
+#define WF_LOGIC_U_FIRST WF_LOGIC_U
+#endif
+// LDSTAB: the small read-only tables every shading event gathers from - the flat-colour atlas (one texel per layer),
+// the environment's importance bins and the batch's randBase values - are staged in LDS once per block, so those
+// gathers go through the LDS pipeline instead of the vector-memory pipeline that bounds the kernel.
+#ifndef WF_LDS_ATLAS
+#define WF_LDS_ATLAS 1024
+#endif
+#ifndef WF_LDS_BINS
+#define WF_LDS_BINS 1024
+#endif
+template <bool COUNT, bool FIRST, bool LDSTAB>
+__global__ __launch_bounds__(WF_LOGIC_THREADS, FIRST ? WF_LOGIC_WAVES_FIRST : WF_LOGIC_WAVES) void k_wf_logic(const WfP p) {
   static_assert(WF_LOGIC_THREADS % WAVE == 0, "whole waves");
   constexpr int NW = WF_LOGIC_THREADS / WAVE;
-  constexpr int U = WF_LOGIC_U; // paths per thread between two compactions (amortises 2 barriers + 1 atomic)
+  constexpr int U = FIRST ? WF_LOGIC_U_FIRST : WF_LOGIC_U; // paths per thread between two compactions (amortises 2 barriers + 1 atomic)
   __shared__ uint32_t s_cnt[2][U][NW];
   __shared__ uint32_t s_base[2];
+  __shared__ uint32_t s_atlas[LDSTAB ? WF_LDS_ATLAS : 1];
+  __shared__ uint4 s_bins[LDSTAB ? WF_LDS_BINS : 1];
+  __shared__ float s_rb[LDSTAB ? WF_MAX_BATCH : 1];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
-  const DScene &S = p.scene;
+  DScene S = p.scene;
+  if (LDSTAB) {
+    for (uint32_t i = threadIdx.x; i < S.atlas_layers; i += WF_LOGIC_THREADS) s_atlas[i] = p.scene.atlas[i];
+    for (uint32_t i = threadIdx.x; i < S.n_bins; i += WF_LOGIC_THREADS) s_bins[i] = p.scene.bins[i];
+    if (threadIdx.x < WF_MAX_BATCH) s_rb[threadIdx.x] = p.rb_trace[threadIdx.x];
+    S.atlas = s_atlas;
+    S.bins = s_bins;
+    __syncthreads();
+  }
   const uint32_t rd_i = (p.round - 1) & 1, wr_i = p.round & 1;
   const uint32_t *__restrict__ q_in = p.q_ext[rd_i];
   uint32_t *__restrict__ q_out = p.q_ext[wr_i];
@@ -1055,7 +1100,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
           hitA = ldi(p.shadow_hit + s);
         }
         const uint32_t j = s % p.n_batch;
-        bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), p.rb_trace[j], p.env_theta,
+        bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), LDSTAB ? s_rb[j] : p.rb_trace[j], p.env_theta,
                                             p.num_bounces, cnt);
         if (finished) {
           // park the sample colour tick-major (fin[j][w]) so that resolve reads coalesced
@@ -1314,13 +1359,16 @@ hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int nu
   } else if (kernel == WF_K_LOGIC) {
     uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * 4u);
     const bool first = (p.round == 1);
+    const bool lds = WF_LOGIC_LDSTAB && p.scene.atlas_res == 1u && p.scene.atlas_layers <= WF_LDS_ATLAS && p.scene.n_bins <= WF_LDS_BINS;
+#define FSPT_LAUNCH_LOGIC(C, F, T) hipLaunchKernelGGL((k_wf_logic<C, F, T>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p)
     if (count) {
-      if (first) hipLaunchKernelGGL((k_wf_logic<true, true>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
-      else hipLaunchKernelGGL((k_wf_logic<true, false>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
+      if (first) { if (lds) FSPT_LAUNCH_LOGIC(true, true, true); else FSPT_LAUNCH_LOGIC(true, true, false); }
+      else { if (lds) FSPT_LAUNCH_LOGIC(true, false, true); else FSPT_LAUNCH_LOGIC(true, false, false); }
     } else {
-      if (first) hipLaunchKernelGGL((k_wf_logic<false, true>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
-      else hipLaunchKernelGGL((k_wf_logic<false, false>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p);
+      if (first) { if (lds) FSPT_LAUNCH_LOGIC(false, true, true); else FSPT_LAUNCH_LOGIC(false, true, false); }
+      else { if (lds) FSPT_LAUNCH_LOGIC(false, false, true); else FSPT_LAUNCH_LOGIC(false, false, false); }
     }
+#undef FSPT_LAUNCH_LOGIC
   } else {
     uint32_t grid = min((p.work_total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 16u);
     hipLaunchKernelGGL(k_wf_resolve, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
