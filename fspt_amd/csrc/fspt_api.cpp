@@ -10,6 +10,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <climits>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -152,7 +154,9 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     std::memcpy(&v, desc->bvh + (size_t)node * 9 + w, 4);
     return v;
   };
-  // ---- validate + renumber interior nodes (pre-order is kept) ----------------
+  // ---- validate + renumber interior nodes ------------------------------------------
+  // The first TOP_BFS interior nodes in breadth-first order get the lowest numbers (every ray walks the top of
+  // the tree: the traversal kernel keeps a prefix of them in LDS); the rest keep their pre-order.
   std::vector<int32_t> ref(N);
   uint32_t n_interior = 0;
   for (uint32_t i = 0; i < N; ++i) {
@@ -166,8 +170,24 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
         fspt_set_error("node %u: child indices (%d,%d) violate pre-order / range [%u,%u)", i, l, r, i + 1, N);
         return FSPT_E_INVALID;
       }
-      ref[i] = (int32_t)n_interior++;
+      ref[i] = INT32_MAX; // interior, numbered below
+      n_interior++;
     }
+  }
+  {
+    const uint32_t TOP_BFS = 256;
+    uint32_t next = 0;
+    std::vector<uint32_t> queue;
+    if (N && word(0, 2) <= -1) queue.push_back(0);
+    for (size_t q = 0; q < queue.size() && next < TOP_BFS; ++q) {
+      uint32_t i = queue[q];
+      ref[i] = (int32_t)next++;
+      uint32_t l = (uint32_t)word(i, 0), r = (uint32_t)word(i, 1);
+      if (word(l, 2) <= -1) queue.push_back(l);
+      if (word(r, 2) <= -1) queue.push_back(r);
+    }
+    for (uint32_t i = 0; i < N; ++i)
+      if (ref[i] == INT32_MAX) ref[i] = (int32_t)next++;
   }
   std::vector<float> nodes((size_t)(n_interior ? n_interior : 1) * 16, 0.0f);
   // depth of every node (root 0); a child's depth = parent's + 1
@@ -257,6 +277,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   s->d.leaf_size = desc->leaf_size;
   s->d.root_ref = ref[0];
   s->d.stack_n = max_depth + 1;
+  s->d.n_top = n_interior < 256u ? n_interior : 256u; // interior nodes numbered breadth-first
   s->depth = max_depth;
   s->n_nodes = N;
   s->n_tris = T;

@@ -45,6 +45,7 @@ struct DScene {
   uint32_t leaf_size;
   int root_ref;
   uint32_t stack_n; // LDS stack entries per lane (tree depth + 1)
+  uint32_t n_top;   // nodes [0, n_top) are the top of the tree in breadth-first order
 };
 
 struct CameraP {
@@ -114,6 +115,7 @@ struct alignas(16) WfCounts { // one per round, zeroed before the batch
 };
 
 struct WfP {
+  uint32_t lds_top; // top-of-tree nodes k_wf_trace keeps in LDS (<= scene.n_top; set by launch_wf)
   DScene scene;
   float4 *ray_o, *ray_d, *thr, *col, *shd, *pend;
   float4 *fin; // finished sample colours, tick-major [j][w] (resolve reads them coalesced)

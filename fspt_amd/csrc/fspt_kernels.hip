@@ -32,6 +32,10 @@ using namespace fm;
 #ifndef WF_LOGIC_LDSTAB
 #define WF_LOGIC_LDSTAB 1
 #endif
+#ifndef WF_TRACE_LDS_TOP
+#define WF_TRACE_LDS_TOP 31 // top-of-tree nodes (breadth-first) k_wf_trace keeps in LDS: measured best of {0, 31, 77} (profiles/r01)
+#endif
+#define WF_TRACE_BLOCKS_PER_CU 7u // resident 256-thread blocks per CU at 66 VGPRs
 #define BLOCK_THREADS 256
 #define WAVES_PER_BLOCK (BLOCK_THREADS / WAVE)
 #define WORK_CHUNK 256u
@@ -871,6 +875,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   const uint32_t n_shd = cn->n_shd;
   const uint32_t total = n_shd + cn->n_ext;
 
+  // top of the tree in LDS (behind the waves' stacks): every ray walks these nodes, and a fetch from LDS does not
+  // occupy the vector-memory pipeline that bounds this kernel
+  const int n_top = (int)p.lds_top;
+  float4 *top = reinterpret_cast<float4 *>(lds_stack + (size_t)WAVES_PER_BLOCK * S.stack_n * WAVE);
+  if (n_top > 0) {
+    for (int i = threadIdx.x; i < n_top * NODE_F4; i += BLOCK_THREADS) top[i] = nodes[i];
+    __syncthreads();
+  }
+
   // pool chunk: large while rays are plentiful (few atomics), one wave-load when they are scarce
   // (late rounds), so that every resident wave gets work
   const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
@@ -946,9 +959,23 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 #endif
       if (cur >= 0) {
       if (COUNT) c_steps++;
-      const float4 *n = nodes + (size_t)cur * NODE_F4;
-      float4 n0 = n[0], n1 = n[1], n2 = n[2];
-      int4 n3 = *reinterpret_cast<const int4 *>(n + 3);
+      float4 n0, n1, n2;
+      int2 n3;
+      if (cur < n_top) {
+        // explicit LDS address space: keeps these ds_read_b128 from being merged with the global path into flat loads
+        typedef float lds_f4 __attribute__((ext_vector_type(4)));
+        typedef int lds_i2 __attribute__((ext_vector_type(2)));
+        const __attribute__((address_space(3))) lds_f4 *n =
+            (const __attribute__((address_space(3))) lds_f4 *)(top + cur * NODE_F4);
+        lds_f4 a = n[0], b = n[1], c = n[2];
+        lds_i2 r = *(const __attribute__((address_space(3))) lds_i2 *)(n + 3);
+        n0 = make_float4(a.x, a.y, a.z, a.w); n1 = make_float4(b.x, b.y, b.z, b.w); n2 = make_float4(c.x, c.y, c.z, c.w);
+        n3 = make_int2(r.x, r.y);
+      } else {
+        const float4 *n = nodes + (size_t)cur * NODE_F4;
+        n0 = n[0]; n1 = n[1]; n2 = n[2];
+        n3 = *reinterpret_cast<const int2 *>(n + 3);
+      }
       float tl = ray_box(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv);
       float tr = ray_box(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv);
       bool hl = tl < t, hr = tr < t;
@@ -1354,8 +1381,20 @@ hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int nu
     // persistent: the grid only has to fill the machine; the pool head balances the work
     uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
     size_t lds = stack_bytes(p.scene);
-    if (count) hipLaunchKernelGGL((k_wf_trace<true>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);
-    else hipLaunchKernelGGL((k_wf_trace<false>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);
+    // LDS left over per block at the occupancy the stacks (and the registers: 7 blocks) allow -> top-of-tree cache
+    WfP q = p;
+    {
+      const size_t LDS_CU = 160u * 1024u;
+      size_t blocks = LDS_CU / (lds ? lds : 1);
+      if (blocks > WF_TRACE_BLOCKS_PER_CU) blocks = WF_TRACE_BLOCKS_PER_CU;
+      if (blocks < 1) blocks = 1;
+      size_t spare = (LDS_CU / blocks - lds) & ~(size_t)255; // allocation granularity
+      uint32_t fit = (uint32_t)(spare / (NODE_F4 * sizeof(float4)));
+      q.lds_top = WF_TRACE_LDS_TOP ? min(min(fit, p.scene.n_top), (uint32_t)WF_TRACE_LDS_TOP) : 0u;
+      lds += (size_t)q.lds_top * NODE_F4 * sizeof(float4);
+    }
+    if (count) hipLaunchKernelGGL((k_wf_trace<true>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, q);
+    else hipLaunchKernelGGL((k_wf_trace<false>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, q);
   } else if (kernel == WF_K_LOGIC) {
     uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * 4u);
     const bool first = (p.round == 1);
