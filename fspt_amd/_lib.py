@@ -128,12 +128,32 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 (same soname as /opt/rocm's, but
+    libtorch_hip asks for it by file name): if libfspt pulled in /opt/rocm's copy first, a later `import torch`
+    would load a second runtime and find "No HIP GPUs".  Loading torch's copy first (without importing torch)
+    makes both bind to the same one, whatever the import order; bound accumulators (torch tensors) then live
+    in the runtime that launches the kernels."""
+    if os.environ.get("FSPT_OWN_HIP_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # no torch: libfspt uses the system runtime
+
+
 def lib():
     """Load libfspt.so (once).  Raises if the HIP extension has not been built."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FsptError(-100, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _share_hip_runtime_with_torch()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
