@@ -97,6 +97,7 @@ SIGNATURES = {
     "fspt_sync": (C.c_int, [_VP]),
     "fspt_read_radiance": (C.c_int, [_VP, _F]),
     "fspt_draw": (C.c_int, [_VP, C.c_float, C.c_float, C.c_int, C.c_float, C.POINTER(C.c_uint8)]),
+    "fspt_draw_scaled": (C.c_int, [_VP, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint8)]),
     "fspt_intersect": (C.c_int, [_VP, _F, C.c_uint32, _F, C.POINTER(C.c_int32), _U32, _U32]),
     "fspt_enable_counters": (C.c_int, [_VP, C.c_int]),
     "fspt_get_counters": (C.c_int, [_VP, C.POINTER(Counters)]),

@@ -679,12 +679,18 @@ int fspt_read_radiance(fspt_target *t, float *out) {
 }
 
 int fspt_draw(fspt_target *t, float exposure, float saturation, int denoise, float max_sigma, uint8_t *out_rgba8) {
+  return fspt_draw_scaled(t, exposure, saturation, denoise, max_sigma, 1.0f, out_rgba8);
+}
+
+int fspt_draw_scaled(fspt_target *t, float exposure, float saturation, int denoise, float max_sigma, float scale,
+                     uint8_t *out_rgba8) {
   if (!t || !out_rgba8) { fspt_set_error("fspt_draw: NULL argument"); return FSPT_E_INVALID; }
+  if (!(scale > 0.0f && scale <= 1.0f)) { fspt_set_error("fspt_draw: scale must be in (0, 1]"); return FSPT_E_INVALID; }
   HIP_TRY(hipSetDevice(t->scene->device));
   size_t n = (size_t)t->W * t->H;
   uint32_t *d = nullptr;
   HIP_TRY(hipMalloc((void **)&d, n * 4));
-  hipError_t e = fspt::launch_draw(t->accum, t->W, t->H, exposure, saturation, denoise, max_sigma, d, t->stream);
+  hipError_t e = fspt::launch_draw(t->accum, t->W, t->H, exposure, saturation, denoise, max_sigma, scale, d, t->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(out_rgba8, d, n * 4, hipMemcpyDeviceToHost, t->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
   hipFree(d);

@@ -150,7 +150,7 @@ hipError_t launch_camera(uint32_t W, uint32_t H, const CameraP &cam, float rand_
 hipError_t launch_intersect(const IntersectP &p, hipStream_t stream);
 hipError_t launch_bvh_test(const TraceP &p, hipStream_t stream);
 hipError_t launch_draw(const float4 *acc, uint32_t W, uint32_t H, float exposure, float saturation, int denoise,
-                       float max_sigma, uint32_t *out, hipStream_t stream);
+                       float max_sigma, float scale, uint32_t *out, hipStream_t stream);
 hipError_t launch_math(int op, const float *a, const float *b, uint32_t n, float *out, hipStream_t stream);
 
 } // namespace fspt

@@ -1231,10 +1231,12 @@ FM_DEV float rrt_odt(float v) {
   return a / b;
 }
 __global__ __launch_bounds__(BLOCK_THREADS) void k_draw(const float4 *acc, uint32_t W, uint32_t H, float exposure,
-                                                       float saturation, int denoise, float maxSigma, uint32_t *out) {
+                                                       float saturation, int denoise, float maxSigma, float scale,
+                                                       uint32_t *out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= W * H) return;
-  int x = (int)(i % W), y = (int)(i / W);
+  // ivec2(gl_FragCoord * scale) (draw.fs:59,87): the reference draws with scale 0.25 while the camera moves
+  int x = (int)(((float)(i % W) + 0.5f) * scale), y = (int)(((float)(i / W) + 0.5f) * scale);
   V3 c;
   if (denoise) {
     float sum = 0.0f, sq = 0.0f, middleLuma = 0.0f;
@@ -1424,10 +1426,10 @@ hipError_t launch_camera(uint32_t W, uint32_t H, const CameraP &cam, float rand_
 }
 
 hipError_t launch_draw(const float4 *acc, uint32_t W, uint32_t H, float exposure, float saturation, int denoise,
-                       float max_sigma, uint32_t *out, hipStream_t stream) {
+                       float max_sigma, float scale, uint32_t *out, hipStream_t stream) {
   uint32_t n = W * H;
   hipLaunchKernelGGL(k_draw, dim3((n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS), 0, stream, acc, W, H,
-                     exposure, saturation, denoise, max_sigma, out);
+                     exposure, saturation, denoise, max_sigma, scale, out);
   return hipGetLastError();
 }
 

@@ -262,13 +262,18 @@ static napi_value ReadRadiance(napi_env env, napi_callback_info info) {
   return a[1];
 }
 static napi_value Draw(napi_env env, napi_callback_info info) {
-  /* draw(target, exposure, saturation, denoise, maxSigma, Uint8Array(W*H*4)) : drawQuad (main.js:809-824) */
-  napi_value a[6]; void *h, *p; size_t n; double ex, sat, sig; bool den;
-  if (get_args(env, info, 6, a) || unwrap(env, a[0], &h)) return NULL;
+  /* draw(target, exposure, saturation, denoise, maxSigma, Uint8Array(W*H*4)[, scale]) : drawQuad (main.js:809-824) */
+  napi_value a[7]; void *h, *p; size_t n, argc = 7; double ex, sat, sig, scale = 1.0; bool den;
+  if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 6) {
+    napi_throw_type_error(env, NULL, "fspt_napi: wrong number of arguments");
+    return NULL;
+  }
+  if (unwrap(env, a[0], &h)) return NULL;
   if (get_f64(env, a[1], &ex) || get_f64(env, a[2], &sat)) return NULL;
   NAPI_OK(napi_get_value_bool(env, a[3], &den));
   if (get_f64(env, a[4], &sig) || typed(env, a[5], napi_uint8_array, 0, &p, &n)) return NULL;
-  FSPT_OK_OR_THROW(fspt_draw((fspt_target *)h, (float)ex, (float)sat, den ? 1 : 0, (float)sig, (uint8_t *)p));
+  if (argc > 6) { napi_valuetype vt; napi_typeof(env, a[6], &vt); if (vt == napi_number && get_f64(env, a[6], &scale)) return NULL; }
+  FSPT_OK_OR_THROW(fspt_draw_scaled((fspt_target *)h, (float)ex, (float)sat, den ? 1 : 0, (float)sig, (float)scale, (uint8_t *)p));
   return a[5];
 }
 static napi_value SetShard(napi_env env, napi_callback_info info) {

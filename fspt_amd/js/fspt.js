@@ -310,11 +310,11 @@ class PathTracer {
     return addon.readRadiance(this._target, out);
   }
   /** drawQuad (main.js:809-824) -> draw.fs: tonemapped RGBA8 as the canvas would hold it (row 0 = bottom). */
-  drawQuad(exposure, saturation, denoise, maxSigma, out) {
+  drawQuad(exposure, saturation, denoise, maxSigma, out, resScale) {
     out = out || new Uint8Array(this.resolution[0] * this.resolution[1] * 4);
     if (out.length !== this.resolution[0] * this.resolution[1] * 4) throw new RangeError('drawQuad: need W*H*4 bytes');
     return addon.draw(this._target, exposure === undefined ? 1 : exposure, saturation === undefined ? 1 : saturation,
-      !!denoise, maxSigma === undefined ? 3 : maxSigma, out);
+      !!denoise, maxSigma === undefined ? 3 : maxSigma, out, resScale === undefined ? 1 : resScale);   // draw.fs `scale`
   }
   setShard(shard, nShards, tile) { addon.setShard(this._target, shard, nShards, tile || 32); }
   setPipeline(name, batch) { addon.setPipeline(this._target, name === 'megakernel' ? 0 : (name === 'wavefront2' ? 2 : 1), batch || 0); }

@@ -178,12 +178,13 @@ class PathTracer:
         L.check(L.lib().fspt_read_radiance(self._t, L.fptr(out)))
         return out
 
-    def draw(self, exposure=1.0, saturation=1.0, denoise=False, max_sigma=3.0):
-        """drawQuad (main.js:809-824) / draw.fs: tonemapped RGBA8 [H, W, 4], row 0 = bottom."""
+    def draw(self, exposure=1.0, saturation=1.0, denoise=False, max_sigma=3.0, scale=1.0):
+        """drawQuad (main.js:809-824) / draw.fs: tonemapped RGBA8 [H, W, 4], row 0 = bottom.  scale = draw.fs's
+        `scale` uniform (resScale: 0.25 while the camera moves, main.js:819,840)."""
         W, H = self.resolution
         out = np.zeros((H, W, 4), np.uint8)
-        L.check(L.lib().fspt_draw(self._t, float(exposure), float(saturation), 1 if denoise else 0, float(max_sigma),
-                                  L.u8ptr(out)))
+        L.check(L.lib().fspt_draw_scaled(self._t, float(exposure), float(saturation), 1 if denoise else 0,
+                                         float(max_sigma), float(scale), L.u8ptr(out)))
         return out
 
     def counters(self):

@@ -186,6 +186,10 @@ int fspt_read_radiance(fspt_target *target, float *out);
  * accumulator; writes what the canvas would hold: RGBA8, W*H*4 bytes, row 0 = bottom.  Blocking. */
 int fspt_draw(fspt_target *target, float exposure, float saturation, int denoise, float max_sigma,
               uint8_t *out_rgba8);
+/* The same with draw.fs's `scale` uniform (draw.fs:59,87: texel = ivec2(gl_FragCoord * scale)); the reference
+ * draws with scale 0.25 while the camera is being dragged (main.js:819,840), 1.0 otherwise. */
+int fspt_draw_scaled(fspt_target *target, float exposure, float saturation, int denoise,
+                     float max_sigma, float scale, uint8_t *out_rgba8);
 
 /* ------------------------------------------------------------------------
  * intersectScene (tracer.fs:366-404) as a stand-alone entry: n rays

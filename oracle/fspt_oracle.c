@@ -763,11 +763,20 @@ static inline float rrt_odt(float v) { /* draw.fs:32-37 */
   float b = om_fma(v, om_fma(0.983729f, v, 0.4329510f), 0.238081f);
   return a / b;
 }
+void oracle_draw_scaled(const float *acc, uint32_t W, uint32_t H, float exposure, float saturation, int denoise,
+                        float maxSigma, float scale, uint8_t *out);
 void oracle_draw(const float *acc, uint32_t W, uint32_t H, float exposure, float saturation, int denoise,
                  float maxSigma, uint8_t *out) {
+  oracle_draw_scaled(acc, W, H, exposure, saturation, denoise, maxSigma, 1.0f, out);
+}
+
+/* draw.fs with its `scale` uniform: every fetch is at ivec2(gl_FragCoord * scale) (+ the filter offset), draw.fs:59,87 */
+void oracle_draw_scaled(const float *acc, uint32_t W, uint32_t H, float exposure, float saturation, int denoise,
+                        float maxSigma, float scale, uint8_t *out) {
 #pragma omp parallel for schedule(static)
-  for (int64_t y = 0; y < (int64_t)H; ++y)
-    for (uint32_t x = 0; x < W; ++x) {
+  for (int64_t yy = 0; yy < (int64_t)H; ++yy)
+    for (uint32_t xx = 0; xx < W; ++xx) {
+      int x = (int)(((float)xx + 0.5f) * scale), y = (int)(((float)yy + 0.5f) * scale);
       vec3 c;
       if (denoise) { /* filterFireflies, draw.fs:52-80 */
         float sum = 0.0f, sq = 0.0f, middleLuma = 0.0f;
@@ -800,7 +809,7 @@ void oracle_draw(const float *acc, uint32_t W, uint32_t H, float exposure, float
       float os = 1.0f - saturation;
       m = v3(om_fma(m.x, saturation, l * os), om_fma(m.y, saturation, l * os), om_fma(m.z, saturation, l * os));
       float g[3] = {om_pow(m.x, 0.454545f), om_pow(m.y, 0.454545f), om_pow(m.z, 0.454545f)};
-      uint8_t *o = out + ((size_t)y * W + x) * 4;
+      uint8_t *o = out + ((size_t)yy * W + xx) * 4;
       for (int k = 0; k < 3; ++k) o[k] = (uint8_t)om_floor(om_fma(om_clamp(g[k], 0.0f, 1.0f), 255.0f, 0.5f));
       o[3] = 255;
     }

@@ -156,10 +156,11 @@ def brdf_probe(arrays, which, inputs):
     return out
 
 
-def draw(accum, exposure=1.0, saturation=1.0, denoise=False, max_sigma=3.0):
+def draw(accum, exposure=1.0, saturation=1.0, denoise=False, max_sigma=3.0, scale=1.0):
     accum = np.ascontiguousarray(accum, np.float32)
     H, W = accum.shape[:2]
     out = np.zeros((H, W, 4), np.uint8)
-    lib().oracle_draw(_fp(accum), C.c_uint32(W), C.c_uint32(H), C.c_float(exposure), C.c_float(saturation),
-                      C.c_int(1 if denoise else 0), C.c_float(max_sigma), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    lib().oracle_draw_scaled(_fp(accum), C.c_uint32(W), C.c_uint32(H), C.c_float(exposure), C.c_float(saturation),
+                             C.c_int(1 if denoise else 0), C.c_float(max_sigma), C.c_float(scale),
+                             out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out

@@ -320,3 +320,23 @@ def test_bvh_test_mode_counts_equal_reference_glsl(name, W, H):
     c0 = np.rint(z[f"{name}_img0"][..., 0] / np.float32(0.001))
     c1 = np.rint((z[f"{name}_img1"][..., 0].astype(np.float64) * 2 - z[f"{name}_img0"][..., 0]) / 0.001)
     assert np.array_equal(steps.reshape(H, W), c1) and c0.max() > 10
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_draw_scale_uniform_matches_reference_glsl(i):
+    """draw.fs with scale = 0.25 (what the reference draws while the camera moves): every output pixel fetches
+    texel ivec2(gl_FragCoord * scale) of the accumulator.  Same tolerance as the unscaled cases; filtered
+    variants exclude the pixels whose 5x5 window leaves the image (undefined fetch in GLES 3.0)."""
+    z = np.load(os.path.join(GOLD, "glsl_draw.npz"))
+    e, s, d, g, sc = [float(v) for v in z[f"scaled_params{i}"]]
+    o = O.draw(z["hdr"], e, s, bool(d), g, sc).astype(int)
+    want = z[f"scaled_rgba{i}"].astype(int)
+    if d:  # texel (x*sc, y*sc) must be >= 2 from the border: drop the first 8+ output rows/columns
+        o, want = o[12:, 12:], want[12:, 12:]
+    diff = np.abs(o - want)
+    assert diff.max() <= 1 and (diff == 0).mean() >= 0.99
+    # a 4x4 block of output pixels shows one texel
+    full = O.draw(z["hdr"], e, s, False, g, 1.0)
+    quarter = O.draw(z["hdr"], e, s, False, g, 0.25)
+    H, W = full.shape[:2]
+    assert np.array_equal(quarter[:H - H % 4:4, :W - W % 4:4], full[:H // 4, :W // 4])

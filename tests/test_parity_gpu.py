@@ -206,6 +206,7 @@ def test_draw_bitwise(small_scene, camera, params):
     want = O.draw(acc, *params)
     assert np.array_equal(got, want)
     assert got[..., :3].std() > 5
+    assert np.array_equal(pt.draw(*params, scale=0.25), O.draw(acc, *params, 0.25))  # draw.fs `scale` (moving camera)
 
 
 def test_log2_pow_bitwise():

@@ -183,7 +183,7 @@ class GlslRef:
         mism = self._ck(self.lib.gh_read_screen(which % 2, out.ctypes.data_as(_F)))
         return out, mism
 
-    def draw(self, acc, exposure=1.0, saturation=1.0, denoise=False, max_sigma=3.0):
+    def draw(self, acc, exposure=1.0, saturation=1.0, denoise=False, max_sigma=3.0, scale=1.0):
         """drawQuad (main.js:809-824): the reference's draw.fs on an RGBA32F buffer -> RGBA8."""
         if not getattr(self, "_draw_ready", False):
             self._ck(self.lib.gh_draw_program(read_shader("draw.vs").encode(), read_shader("draw.fs").encode()))
@@ -191,7 +191,7 @@ class GlslRef:
         acc = np.ascontiguousarray(acc, np.float32)
         H, W = acc.shape[:2]
         out = np.zeros((H, W, 4), np.uint8)
-        self._ck(self.lib.gh_draw(acc.ctypes.data_as(_F), W, H, C.c_float(exposure), C.c_float(saturation), C.c_float(1.0),
+        self._ck(self.lib.gh_draw(acc.ctypes.data_as(_F), W, H, C.c_float(exposure), C.c_float(saturation), C.c_float(scale),
                                   C.c_float(max_sigma), 1 if denoise else 0, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 

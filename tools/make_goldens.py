@@ -376,6 +376,10 @@ def make_draw():
                                               (0.7, 1.3, True, 1.5)]):
         out[f"rgba{i}"] = g.draw(hdr, exp, sat, den, sig)
         out[f"params{i}"] = np.float32([exp, sat, float(den), sig])
+    # draw.fs's `scale` uniform (resScale = 0.25 while the camera moves, main.js:819,840)
+    for i, (exp, sat, den, sig, scale) in enumerate([(1.0, 1.0, False, 3.0, 0.25), (1.4, 0.9, True, 2.0, 0.25)]):
+        out[f"scaled_rgba{i}"] = g.draw(hdr, exp, sat, den, sig, scale)
+        out[f"scaled_params{i}"] = np.float32([exp, sat, float(den), sig, scale])
     np.savez_compressed(os.path.join(GOLD, "glsl_draw.npz"), renderer=g.renderer, **out)
     print("draw goldens", out["rgba0"].shape, out["rgba0"][..., :3].mean())
 
