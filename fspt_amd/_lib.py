@@ -83,6 +83,7 @@ SIGNATURES = {
     "fspt_scene_depth": (C.c_int, [_VP, _U32]),
     "fspt_target_create": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "fspt_target_destroy": (C.c_int, [_VP]),
+    "fspt_target_set_viewport": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
     "fspt_target_set_shard": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32]),
     "fspt_target_bind_accumulator": (C.c_int, [_VP, _VP]),
     "fspt_target_accumulator": (C.c_int, [_VP, C.POINTER(_VP)]),

@@ -61,6 +61,7 @@ struct fspt_target {
   bool timed = false;
   uint32_t last_launches = 0;
   // wavefront pipeline
+  uint32_t vw = 0, vh = 0;    // viewport (gl.viewport of the two draws); default = the whole target
   int pipeline = 1;           // 0 = megakernel, 1 = wavefront (2 = wavefront with two overlapped lanes sets n_lanes)
   uint32_t batch_ticks = 64;  // ticks traced together by the wavefront pipeline (18.8 GB of path state at 1080p)
   // Two lanes = two independent batches in flight on two HIP streams: while one batch sits in a latency-bound
@@ -317,6 +318,7 @@ int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **
   fspt_target *t = new fspt_target();
   t->scene = scene;
   t->W = W; t->H = H;
+  t->vw = W; t->vh = H;
   size_t px = (size_t)W * H;
   hipError_t e = hipMalloc((void **)&t->accum_own, px * 16);
   if (e == hipSuccess) e = hipMalloc((void **)&t->ray_pos, px * 16);
@@ -390,7 +392,7 @@ int fspt_camera(fspt_target *t, const float P[3], const float I[3], float fov_sc
   fspt::CameraP c;
   std::memcpy(c.P, P, 12); std::memcpy(c.I, I, 12);
   c.fov_scale = fov_scale; c.lens[0] = lens[0]; c.lens[1] = lens[1];
-  HIP_TRY(fspt::launch_camera(t->W, t->H, c, rand_base, t->ray_pos, t->ray_dir, t->stream));
+  HIP_TRY(fspt::launch_camera(t->W, t->H, t->vw, t->vh, c, rand_base, t->ray_pos, t->ray_dir, t->stream));
   t->rays_valid = true;
   return FSPT_OK;
 }
@@ -420,6 +422,7 @@ int fspt_read_rays(fspt_target *t, float *pos, float *dir) {
 static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
   p.scene = t->scene->d;
   p.W = t->W; p.H = t->H;
+  p.vw = t->vw; p.vh = t->vh;
   p.ray_pos = t->ray_pos; p.ray_dir = t->ray_dir;
   p.accum = t->accum;
   p.counters = t->count ? t->counters : nullptr;
@@ -496,7 +499,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
 
   fspt::WfP p{};
   p.scene = t->scene->d;
-  p.W = t->W; p.H = t->H; p.work_total = work_total;
+  p.W = t->W; p.H = t->H; p.vw = t->vw; p.vh = t->vh; p.work_total = work_total;
   p.env_theta = cam->env_theta; p.num_bounces = cam->num_bounces;
   std::memcpy(p.cam.P, cam->P, 12); std::memcpy(p.cam.I, cam->I, 12);
   p.cam.fov_scale = cam->fov_scale; p.cam.lens[0] = cam->lens[0]; p.cam.lens[1] = cam->lens[1];
@@ -705,6 +708,14 @@ int fspt_last_kernel_ms(fspt_target *t, float *ms, uint32_t *launches) {
   HIP_TRY(hipEventSynchronize(t->ev1));
   HIP_TRY(hipEventElapsedTime(ms, t->ev0, t->ev1));
   if (launches) *launches = t->last_launches;
+  return FSPT_OK;
+}
+
+int fspt_target_set_viewport(fspt_target *t, uint32_t w, uint32_t h) {
+  if (!t) { fspt_set_error("fspt_target_set_viewport: NULL target"); return FSPT_E_INVALID; }
+  if (w > t->W || h > t->H) { fspt_set_error("fspt_target_set_viewport: %ux%u exceeds the target %ux%u", w, h, t->W, t->H); return FSPT_E_INVALID; }
+  t->vw = w ? w : t->W;
+  t->vh = h ? h : t->H;
   return FSPT_OK;
 }
 

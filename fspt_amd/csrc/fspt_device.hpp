@@ -58,6 +58,7 @@ struct CameraP {
 struct TraceP {
   DScene scene;
   uint32_t W, H;
+  uint32_t vw, vh; // gl.viewport(0, 0, vw, vh): only these pixels are drawn (main.js:744,761)
   uint32_t tick;
   float rand_base;     // drawTracer's randBase
   float rand_base_cam; // drawCamera's randBase (fused ray generation only)
@@ -126,6 +127,7 @@ struct WfP {
   WfCounts *counts;
   uint32_t round;
   uint32_t W, H;
+  uint32_t vw, vh; // viewport, as in TraceP
   uint32_t work_total; // work indices per tick (owned tiles * tile^2)
   uint32_t n_batch;    // ticks in this batch (<= WF_MAX_BATCH)
   uint32_t first_tick;
@@ -145,7 +147,7 @@ hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int nu
 
 // launchers (fspt_kernels.hip)
 hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream);
-hipError_t launch_camera(uint32_t W, uint32_t H, const CameraP &cam, float rand_base, float4 *pos, float4 *dir,
+hipError_t launch_camera(uint32_t W, uint32_t H, uint32_t vw, uint32_t vh, const CameraP &cam, float rand_base, float4 *pos, float4 *dir,
                          hipStream_t stream);
 hipError_t launch_intersect(const IntersectP &p, hipStream_t stream);
 hipError_t launch_bvh_test(const TraceP &p, hipStream_t stream);

@@ -633,7 +633,7 @@ FM_DEV bool work_to_pixel(const P &p, uint32_t idx, uint32_t &x, uint32_t &y) {
   uint32_t sx = sub % subs_x, sy = sub / subs_x;
   x = tx * tile + sx * 8 + (l & 7u);
   y = ty * tile + sy * 8 + (l >> 3);
-  return x < p.W && y < p.H;
+  return x < p.vw && y < p.vh;
 }
 
 // ---------------------------------------------------------------------------
@@ -1207,11 +1207,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
 }
 
 // camera.fs as a stand-alone pass (drawCamera, main.js:741-756)
-__global__ __launch_bounds__(BLOCK_THREADS) void k_camera(uint32_t W, uint32_t H, CameraP cam, float randBase,
-                                                         float4 *pos, float4 *dir) {
+__global__ __launch_bounds__(BLOCK_THREADS) void k_camera(uint32_t W, uint32_t H, uint32_t vw, uint32_t vh, CameraP cam,
+                                                         float randBase, float4 *pos, float4 *dir) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= W * H) return;
   uint32_t x = i % W, y = i / W;
+  if (x >= vw || y >= vh) return; // outside gl.viewport: the ray textures keep their old texels
   V3 o, d;
   camera_ray(x, y, W, H, cam, randBase, o, d);
   pos[i] = make_float4(o.x, o.y, o.z, 1.0f);
@@ -1417,10 +1418,10 @@ hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int nu
   return hipGetLastError();
 }
 
-hipError_t launch_camera(uint32_t W, uint32_t H, const CameraP &cam, float rand_base, float4 *pos, float4 *dir,
+hipError_t launch_camera(uint32_t W, uint32_t H, uint32_t vw, uint32_t vh, const CameraP &cam, float rand_base, float4 *pos, float4 *dir,
                          hipStream_t stream) {
   uint32_t n = W * H;
-  hipLaunchKernelGGL(k_camera, dim3((n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS), 0, stream, W, H, cam,
+  hipLaunchKernelGGL(k_camera, dim3((n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS), 0, stream, W, H, vw, vh, cam,
                      rand_base, pos, dir);
   return hipGetLastError();
 }

@@ -276,6 +276,14 @@ static napi_value Draw(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_draw_scaled((fspt_target *)h, (float)ex, (float)sat, den ? 1 : 0, (float)sig, (float)scale, (uint8_t *)p));
   return a[5];
 }
+static napi_value SetViewport(napi_env env, napi_callback_info info) {
+  napi_value a[3]; void *h; uint32_t w, hh;
+  if (get_args(env, info, 3, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &w));
+  NAPI_OK(napi_get_value_uint32(env, a[2], &hh));
+  FSPT_OK_OR_THROW(fspt_target_set_viewport((fspt_target *)h, w, hh));
+  return undefined(env);
+}
 static napi_value SetShard(napi_env env, napi_callback_info info) {
   napi_value a[4]; void *h; uint32_t s, n, tile;
   if (get_args(env, info, 4, a) || unwrap(env, a[0], &h)) return NULL;
@@ -564,7 +572,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   struct { const char *name; napi_callback fn; } fns[] = {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"traceTest", TraceTest}, {"render", Render}, {"clear", Clear},
-      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setPipeline", SetPipeline},
+      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline},
       {"enableCounters", EnableCounters}, {"counters", GetCounters}, {"builderCreate", BuilderCreate}, {"builderDestroy", BuilderDestroy},
       {"builderParseObj", BuilderParseObj}, {"builderCommit", BuilderCommit}, {"builderNormalize", BuilderNormalize},
       {"builderBuild", BuilderBuild}, {"builderAutofocus", BuilderAutofocus}, {"envBins", EnvBins},

@@ -316,6 +316,8 @@ class PathTracer {
     return addon.draw(this._target, exposure === undefined ? 1 : exposure, saturation === undefined ? 1 : saturation,
       !!denoise, maxSigma === undefined ? 3 : maxSigma, out, resScale === undefined ? 1 : resScale);   // draw.fs `scale`
   }
+  /** gl.viewport(0, 0, w, h) of drawCamera / drawTracer (main.js:744,761); the reference: resolution * resScale. */
+  setViewport(w, h) { addon.setViewport(this._target, w || 0, h || 0); }
   setShard(shard, nShards, tile) { addon.setShard(this._target, shard, nShards, tile || 32); }
   setPipeline(name, batch) { addon.setPipeline(this._target, name === 'megakernel' ? 0 : (name === 'wavefront2' ? 2 : 1), batch || 0); }
   enableCounters(on) { addon.enableCounters(this._target, !!on); }

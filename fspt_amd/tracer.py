@@ -95,6 +95,11 @@ class PathTracer:
     def set_shard(self, shard, n_shards, tile=32):
         L.check(L.lib().fspt_target_set_shard(self._t, shard, n_shards, tile))
 
+    def set_viewport(self, w=0, h=0):
+        """gl.viewport(0, 0, w, h) of drawCamera / drawTracer (main.js:744,761); 0, 0 = the whole target.  The
+        reference uses resolution * 0.25 while the camera moves (resScale, main.js:840)."""
+        L.check(L.lib().fspt_target_set_viewport(self._t, int(w), int(h)))
+
     def bind_accumulator(self, device_ptr, keep=None):
         """Accumulate into caller-owned device memory (e.g. a torch tensor) so a
         collective can run on it in place; `keep` is held to keep it alive."""

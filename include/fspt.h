@@ -160,6 +160,12 @@ int fspt_render(fspt_target *target, const fspt_camera_params *cam,
  * reproduce the stream for the two-call (camera + trace) form. */
 float fspt_rand_base_next(uint64_t *state);
 
+/* gl.viewport(0, 0, w, h) of drawCamera / drawTracer (main.js:744,761): only pixels x < w, y < h are generated and
+ * traced; the rest of the ray buffers and of the accumulator keep their contents.  The reference shrinks the viewport
+ * to resolution * 0.25 while the camera is being dragged (resScale, main.js:840) and shows that corner magnified
+ * through draw.fs's `scale` (fspt_draw_scaled).  0, 0 restores the whole target. */
+int fspt_target_set_viewport(fspt_target *target, uint32_t w, uint32_t h);
+
 /* Execution strategy of fspt_trace / fspt_render (results are bit-identical):
  *   pipeline 1 (default) "wavefront": gen -> [trace <-> logic] x rounds -> resolve, queue-driven
  *              kernels over batch_ticks ticks at a time (0 keeps the current batch size, max 64);

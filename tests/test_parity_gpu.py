@@ -434,3 +434,37 @@ def test_bvh_test_mode_bitwise(small_scene, camera):
     assert np.array_equal(total[..., :3], want[..., :3]) and want[..., 0].max() > 0.01
     with pytest.raises(L.FsptError):
         PathTracer(sc, 8, 8).drawTracerTest(0)  # no rays yet
+
+
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_viewport_is_the_moving_camera_preview(small_scene, camera, pipeline):
+    """gl.viewport(0, 0, W*0.25, H*0.25) (resScale while the camera moves, main.js:744,761,840): only that corner
+    of the ray buffers and of the accumulator is drawn - with the rays and radiance the full-size draw gives those
+    pixels (camera.fs / tracer.fs use the full `resolution`) - the rest keeps its contents; draw.fs then magnifies
+    the corner (scale 0.25).  Restoring the viewport continues on the whole target."""
+    W, H = 96, 64
+    vw, vh = int(W * 0.25), int(H * 0.25)
+    full = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
+             0, 2, 13, full)
+    pt = make_pt(small_scene, W, H, camera, 4, pipeline)
+    pt.set_viewport(vw, vh)
+    pt.seed(13)
+    pt.render(2)
+    got = pt.readRadiance()
+    assert np.array_equal(got[:vh, :vw], full[:vh, :vw])
+    assert not got[vh:].any() and not got[:, vw:].any()
+    assert np.array_equal(pt.draw(1.0, 1.0, False, 3.0, 0.25), O.draw(got, 1.0, 1.0, False, 3.0, 0.25))
+    # two-call form: drawCamera only rewrites the viewport's texels of the ray textures
+    pt2 = make_pt(small_scene, W, H, camera, 4, pipeline)
+    pt2.drawCamera(77.0)
+    pos_full, dir_full = pt2.readRays()
+    pt2.set_viewport(vw, vh)
+    pt2.drawCamera(78.0)
+    pos, d = pt2.readRays()
+    opos, od = O.camera(W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], 78.0)
+    assert np.array_equal(pos[:vh, :vw], opos[:vh, :vw]) and np.array_equal(d[:vh, :vw], od[:vh, :vw])
+    assert np.array_equal(pos[vh:], pos_full[vh:]) and np.array_equal(d[:, vw:], dir_full[:, vw:])
+    pt2.set_viewport(0, 0)
+    with pytest.raises(L.FsptError):
+        pt2.set_viewport(W + 1, H)
