@@ -468,3 +468,92 @@ def test_viewport_is_the_moving_camera_preview(small_scene, camera, pipeline):
     pt2.set_viewport(0, 0)
     with pytest.raises(L.FsptError):
         pt2.set_viewport(W + 1, H)
+
+
+def _fuzz_scene(seed):
+    """Random triangle soup with awkward members (degenerate, sliver, huge, duplicated and coplanar triangles,
+    shared edges), random per-group MTL materials (dielectric, metallic, rough, emissive), random leaf size,
+    random small RGBE environment or none."""
+    from fspt_amd import scene as S
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3, 120))
+    lines, faces = [], []
+    for k in range(n):
+        c = rng.normal(size=3) * 1.5
+        kind = rng.integers(0, 10)
+        if kind == 0:      # degenerate: two equal vertices -> NaN normals (obj_loader.js:40-44)
+            a = c + rng.normal(size=3) * 0.3
+            tri = [c, a, a]
+        elif kind == 1:    # sliver
+            a = c + rng.normal(size=3)
+            tri = [c, a, a + rng.normal(size=3) * 1e-5]
+        elif kind == 2:    # huge
+            tri = [c * 50, c * 50 + rng.normal(size=3) * 40, c * 50 + rng.normal(size=3) * 40]
+        else:
+            tri = [c, c + rng.normal(size=3) * 0.8, c + rng.normal(size=3) * 0.8]
+        base = len(lines) // 1
+        for v in tri:
+            lines.append("v %.9g %.9g %.9g" % tuple(v))
+        faces.append((k, "f %d %d %d" % (3 * k + 1, 3 * k + 2, 3 * k + 3)))
+        if kind == 3:      # duplicate of the same triangle (equal t: first-visited wins)
+            faces.append((k, "f %d %d %d" % (3 * k + 1, 3 * k + 2, 3 * k + 3)))
+    mats = ["m%d" % i for i in range(int(rng.integers(1, 5)))]
+    obj = ["mtllib lib.mtl"] + lines
+    for k, f in faces:
+        obj += ["usemtl " + mats[k % len(mats)], f]
+    mtl = []
+    for m in mats:
+        mtl += ["newmtl " + m, "Kd %.3f %.3f %.3f" % tuple(rng.uniform(0.05, 1, 3)),
+                "Pmr %.3f %.3f 0" % (float(rng.choice([0, 0, 1, 0.5])), float(rng.uniform(0.02, 1)))]
+        if rng.random() < 0.3:
+            mtl += ["dielectric %.3f" % rng.uniform(0.1, 2), "ior %.3f" % rng.uniform(1.05, 2.2)]
+        if rng.random() < 0.4:
+            mtl += ["Kem %.3f %.3f %.3f" % tuple(rng.uniform(0, 1, 3))]
+    prop = {"path": "f/soup.obj", "scale": float(rng.uniform(0.3, 1.5)), "rotate": [{"angle": float(rng.uniform(0, 6)), "axis": [0, 1, 0]}],
+            "translate": [float(x) for x in rng.normal(size=3) * 0.2], "emittance": [0, 0, 0],
+            "normals": str(rng.choice(["flat", "smooth"]))}
+    floor = {"path": "q.obj", "scale": 8, "rotate": [], "translate": [0, -2.0, 0], "emittance": [0, 0, 0], "normals": "flat",
+             "diffuse": [0.6, 0.6, 0.6]}
+    env = None
+    ew = eh = 0
+    if rng.random() < 0.7:
+        ew, eh = int(rng.integers(2, 40)), int(rng.integers(2, 24))
+        env = rng.integers(0, 256, size=(eh, ew, 4), dtype=np.uint8)
+        env[..., 3] = rng.integers(118, 134, size=(eh, ew))  # exponents around 2^0
+    arrays = S.build_scene([prop, floor], {"f/soup.obj": "\n".join(obj) + "\n", "q.obj": S.QUAD_OBJ}, env=env, env_w=ew, env_h=eh,
+                           leaf_size=int(rng.choice([1, 2, 4, 4, 5])), mtl_texts={"f/lib.mtl": "\n".join(mtl) + "\n"})
+    cam = dict(P=[float(x) for x in rng.normal(size=3) * 2 + [0, 0.5, 3]], I=[float(x) for x in (rng.normal(size=3) * 0.3 + [0, -0.1, -1])],
+               fov_scale=float(rng.uniform(0.2, 1.2)), env_theta=float(rng.uniform(0, 6)),
+               lens=[float(rng.uniform(-0.5, 0.9)), float(rng.choice([0.0, 0.02, 0.3]))])
+    return arrays, cam, int(rng.integers(1, 7)), (int(rng.integers(1, 90)), int(rng.integers(1, 60))), int(rng.integers(1, 2 ** 31))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_random_scenes_bitwise(seed):
+    """Differential fuzzing, HIP (both pipelines) vs oracle: random triangle soups incl. degenerate / duplicate /
+    sliver / huge triangles (NaN normals, equal-t ties), refractive + emissive + metallic MTL materials, leaf sizes
+    1-5, random tiny environments or none, random cameras / lens / bounce counts / frame sizes.  Radiance (NaN
+    = NaN), work counters and traversal results must be identical."""
+    arrays, cam, bounces, (W, H), rseed = _fuzz_scene(seed)
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], bounces, 0, 3, rseed, want,
+             counters=oc)
+    sc = Scene(arrays)
+    rays = random_rays(arrays, 512, seed=seed)
+    t, idx, steps, leaves = sc.intersect(rays)
+    rt, ridx, rsteps, rleaves = O.intersect(arrays, rays)
+    assert np.array_equal(idx, ridx) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+    assert np.array_equal(steps, rsteps) and np.array_equal(leaves, rleaves)
+    for pipeline in PIPELINES:
+        pt = PathTracer(sc, W, H, num_bounces=bounces)
+        pt.eye, pt.dir, pt.fovScale, pt.envTheta, pt.lensFeatures = cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["lens"]
+        pt.set_pipeline(pipeline, 2)
+        pt.enable_counters(True)
+        pt.clear()
+        pt.seed(rseed)
+        pt.render(3)
+        got = pt.readRadiance()
+        assert np.array_equal(got, want, equal_nan=True), f"{pipeline}: {(got != want).any(-1).sum()} of {W * H} pixels differ"
+        assert pt.counters() == oc.as_dict(), pipeline
+        pt.close()
