@@ -340,3 +340,31 @@ def test_draw_scale_uniform_matches_reference_glsl(i):
     quarter = O.draw(z["hdr"], e, s, False, g, 0.25)
     H, W = full.shape[:2]
     assert np.array_equal(quarter[:H - H % 4:4, :W - W % 4:4], full[:H // 4, :W // 4])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5, 8])
+def test_bvh_test_counts_on_random_soups_equal_reference_glsl(seed):
+    """bvh_test.fs (the reference's own traversal, LEAF_SIZE 1 / 2 / 4 / 5) on SwiftShader over random triangle
+    soups with degenerate, duplicated, sliver and huge triangles: the oracle's per-pixel iteration counts are
+    exactly the GLSL's on all 960 camera rays of every scene."""
+    z = np.load(os.path.join(GOLD, "glsl_fuzz_bvh_test.npz"))
+    tri = z[f"s{seed}_tri"]
+    nt = tri.size // 9
+    a = S.SceneArrays(bvh=z[f"s{seed}_bvh"], tri=tri, mat=np.zeros(nt * 12, np.float32), norm=np.zeros(nt * 27, np.float32),
+                      uv=np.zeros(nt * 6, np.float32), atlas=np.zeros(4, np.uint8), atlas_res=1, atlas_layers=1, env=None,
+                      env_w=0, env_h=0, bins=np.array([0, 0, 1, 2048], np.uint32), leaf_size=int(z[f"s{seed}_leaf"]))
+    img = z[f"s{seed}_img"]
+    H, W = img.shape[:2]
+    acc = np.zeros((H, W, 4), np.float32)
+    O.trace_test(a, W, H, z[f"s{seed}_pos"], z[f"s{seed}_dir"], 0, acc)
+    assert np.array_equal(acc.view(np.uint32), img.view(np.uint32))
+    assert img[..., 0].max() > 0.015
+    # D2 on the same rays through tracer.fs's own intersectScene: the same triangle everywhere - incl. the equal-t
+    # ties of duplicated triangles, where the first one visited wins - and t to float32 rounding (sliver triangles
+    # amplify the GLSL compiler's freedom to contract a*b+c: 2.5e-5 on one scene, <= 8e-7 on the others)
+    rays = np.concatenate([z[f"s{seed}_pos"][..., :3], z[f"s{seed}_dir"][..., :3]], -1).reshape(-1, 6)
+    t, idx, _, _ = O.intersect(a, rays)
+    assert np.array_equal(idx, z[f"s{seed}_hit_index"].reshape(-1))
+    h = idx >= 0
+    assert h.sum() > 100
+    assert (np.abs(z[f"s{seed}_hit_t"].reshape(-1)[h] - t[h]) / np.maximum(t[h], 1e-6)).max() < 1e-4

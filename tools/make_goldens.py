@@ -361,6 +361,58 @@ def make_bvh_test():
     np.savez_compressed(os.path.join(GOLD, "glsl_bvh_test.npz"), **out)
 
 
+def make_fuzz_bvh_test():
+    """bvh_test.fs on the random triangle soups of tests/test_parity_gpu.py::_fuzz_scene (irregular trees, leaf
+    sizes 1-5, degenerate / duplicate / sliver / huge triangles): exact traversal-iteration counts per pixel."""
+    import glsl_ref as G
+    import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_parity_gpu import _fuzz_scene
+    out = {}
+    W, H = 40, 24
+    for seed in (0, 1, 2, 3, 5, 8):
+        arrays, cam, _, _, _ = _fuzz_scene(seed)
+        if arrays.env is None:  # the harness always binds an environment texture; traversal does not read it
+            arrays.env, arrays.env_w, arrays.env_h = np.zeros(2 * 2 * 4, np.uint8), 2, 2
+        g = G.GlslRef()
+        g.scene(arrays)
+        g.target(W, H, replicate=True)
+        g.tracer_test(leaf_size=arrays.leaf_size)
+        pos, d = O.camera(W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], 4321.0)
+        g.set_camera(pos, d)
+        g.draw_tracer(0, 1.0, 0.0)
+        img, mism = g.read_screen(0)
+        assert mism == 0, mism
+        acc = np.zeros((H, W, 4), np.float32)
+        O.trace_test(arrays, W, H, pos, d, 0, acc)
+        same = np.array_equal(acc.view(np.uint32), img.view(np.uint32))
+        print("fuzz bvh_test seed", seed, "leaf", arrays.leaf_size, "tris", arrays.n_tris, "max count", img[..., 0].max() / 0.001,
+              "oracle == glsl:", same, "" if same else int((acc != img).any(-1).sum()))
+        for k in ("bvh", "tri"):
+            out[f"s{seed}_{k}"] = getattr(arrays, k)
+        out[f"s{seed}_leaf"] = np.int32(arrays.leaf_size)
+        out[f"s{seed}_pos"], out[f"s{seed}_dir"], out[f"s{seed}_img"] = pos, d, img
+        del g
+        # D2 on the same rays through tracer.fs's own intersectScene (probe main): closest hit incl. the
+        # first-visited-wins ties of the duplicated triangles
+        g = G.GlslRef()
+        g.scene(arrays)
+        g._env_theta = 0.0
+        g.target(W, H, replicate=True)
+        g.set_camera(pos, d)
+        src_leaf = arrays.leaf_size
+        g.tracer(main_override=PROBE_MAIN.replace("FCOORD", FC_REP), leaf_size=src_leaf)
+        g._probe_ready = True
+        hit = probe(g, HIT)
+        t, idx, _, _ = O.intersect(arrays, np.concatenate([pos[..., :3], d[..., :3]], -1).reshape(-1, 6))
+        gi = hit[..., 1].astype(np.int32).reshape(-1)
+        rel = np.abs(hit[..., 0].reshape(-1)[idx >= 0] - t[idx >= 0]) / np.maximum(t[idx >= 0], 1e-6)
+        print("   D2 index equal:", float((gi == idx).mean()), "hits", int((idx >= 0).sum()), "t rel max", float(rel.max()) if rel.size else 0.0)
+        out[f"s{seed}_hit_t"], out[f"s{seed}_hit_index"] = hit[..., 0], hit[..., 1].astype(np.int32)
+        del g
+    np.savez_compressed(os.path.join(GOLD, "glsl_fuzz_bvh_test.npz"), **out)
+
+
 def make_draw():
     """draw.fs (tonemap + firefly filter) on SwiftShader: HDR input = a converged golden image, with a few
     injected fireflies so the 5x5 filter has something to do."""
@@ -445,6 +497,8 @@ if __name__ == "__main__":
             make_atlas()
         elif w == "bvhtest":
             make_bvh_test()
+        elif w == "fuzzbvh":
+            make_fuzz_bvh_test()
         elif w == "draw":
             make_draw()
         elif w.startswith("converged:"):
