@@ -739,7 +739,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 // Wavefront pipeline: gen -> [trace <-> logic] x rounds -> resolve
 // (layout and slot numbering: fspt_device.hpp)
 // ===========================================================================
+#ifndef WF_TRACE_CHUNK
 #define WF_TRACE_CHUNK 512u
+#endif
+#ifndef WF_TRACE_STATIC_CHUNKS
+#define WF_TRACE_STATIC_CHUNKS 1u // chunks of its own every wave starts with before it turns to the shared pool head
+#endif
 // measured on C2 (profiles/r01): 1 -> 0.462, 8 -> 0.348, 16 -> 0.338, 24 -> 0.336, 32 -> 0.343 ms per tick
 #ifndef WF_INTERIOR_MIN
 #define WF_INTERIOR_MIN 16
@@ -891,8 +896,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   chunk = chunk < 64u ? 64u : (chunk > WF_TRACE_CHUNK ? WF_TRACE_CHUNK : chunk);
 
   uint32_t c_rays = 0, c_steps = 0, c_leaves = 0;
-  uint32_t pool_next = 0, pool_end = 0;
-  bool exhausted = false;
+  // every wave's first chunk is its own slice [w*chunk, (w+1)*chunk) - no atomic: thousands of waves hitting the one
+  // pool head at start-up is what a small launch's run time consisted of; the head hands out what lies beyond
+  const uint32_t wave_id = blockIdx.x * WAVES_PER_BLOCK + wave;
+  const uint32_t own = chunk * WF_TRACE_STATIC_CHUNKS;
+  const uint32_t static_end = n_waves * own;
+  uint32_t pool_next = min(wave_id * own, total), pool_end = min(wave_id * own + own, total);
+  bool exhausted = static_end >= total; // nothing beyond the static slices
 
   bool idle = true;
   bool is_shadow = false;
@@ -915,7 +925,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
         if (exhausted) break;
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&cn->head, chunk);
-        base = __builtin_amdgcn_readfirstlane(base);
+        base = __builtin_amdgcn_readfirstlane(base) + static_end;
         if (base >= total) { exhausted = true; break; }
         pool_next = base;
         pool_end = min(base + chunk, total);
