@@ -61,7 +61,7 @@ def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "wavefront2"])
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="multi-GPU read-out: gather each rank's own tiles to rank 0 (default) or sum-reduce the full frame")
-    ap.add_argument("--batch", type=int, default=64, help="ticks per wavefront batch")
+    ap.add_argument("--batch", type=int, default=128, help="ticks per wavefront batch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

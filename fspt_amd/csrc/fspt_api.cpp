@@ -63,7 +63,8 @@ struct fspt_target {
   // wavefront pipeline
   uint32_t vw = 0, vh = 0;    // viewport (gl.viewport of the two draws); default = the whole target
   int pipeline = 1;           // 0 = megakernel, 1 = wavefront (2 = wavefront with two overlapped lanes sets n_lanes)
-  uint32_t batch_ticks = 64;  // ticks traced together by the wavefront pipeline (18.8 GB of path state at 1080p)
+  uint32_t batch_ticks = 128; // ticks traced together by the wavefront pipeline (37 GB of path state at 1080p;
+                              // measured 64 / 128 / 256 -> 3 619 / 3 794 / 3 750 Msamples/s, profiles/r01)
   // Two lanes = two independent batches in flight on two HIP streams: while one batch sits in a latency-bound
   // kernel or in the tail of a late round, the other batch's kernels fill the idle SIMDs.
   struct WfLane {
@@ -308,7 +309,7 @@ int fspt_scene_depth(const fspt_scene *s, uint32_t *depth) {
 static const uint32_t WORK_RING = 4096;
 static const uint32_t WF_ROUNDS_MAX = fspt::MAX_PATH_ITERS + 4;
 static const uint32_t EV_PAIRS = 4096;
-static const uint64_t WF_SLOT_BUDGET = 160ull << 20; // path slots, 140 B each (22 GB of the 288 GB HBM)
+static const uint64_t WF_SLOT_BUDGET = 576ull << 20; // path slots, 140 B each (up to 84 GB of the 288 GB HBM: a 4K frame x 64 ticks)
 
 int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **out) {
   if (!scene || !out || W == 0 || H == 0) { fspt_set_error("fspt_target_create: bad argument"); return FSPT_E_INVALID; }

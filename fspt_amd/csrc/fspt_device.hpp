@@ -104,7 +104,7 @@ struct IntersectP {
 // Queues hold slot ids; WF_DEAD marks a skipped entry (ragged tile edge).
 // ---------------------------------------------------------------------------
 constexpr uint32_t WF_DEAD = 0xFFFFFFFFu;
-constexpr int WF_MAX_BATCH = 64;
+constexpr int WF_MAX_BATCH = 128;
 constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17;
 
 struct alignas(16) WfCounts { // one per round, zeroed before the batch

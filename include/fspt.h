@@ -168,7 +168,7 @@ int fspt_target_set_viewport(fspt_target *target, uint32_t w, uint32_t h);
 
 /* Execution strategy of fspt_trace / fspt_render (results are bit-identical):
  *   pipeline 1 (default) "wavefront": gen -> [trace <-> logic] x rounds -> resolve, queue-driven
- *              kernels over batch_ticks ticks at a time (0 keeps the current batch size, max 64);
+ *              kernels over batch_ticks ticks at a time (0 keeps the current batch size; default and max 128);
  *   pipeline 0 "megakernel": one persistent kernel per tick (path regeneration);
  *   pipeline 2 "wavefront, two lanes": pipeline 1 with the batch split in two halves that run
  *              concurrently on two HIP streams (separate path state, resolves chained in tick order). */

@@ -56,7 +56,7 @@ for tag, name in (("", "c2_70k"), ("_c3", "c3_1M")):
         o[k] = {"launches": len(f), "FETCH_SIZE_KB_sum": sum(f), "WRITE_SIZE_KB_sum": sum(w),
                 "hbm_bytes_per_launch_corrected": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024,
                 "note": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per "
-                        "128-B request); separate --pmc passes over `bench.py --warmup 0 --no-cpu-baseline` (one 64-tick batch = the timed region; batch 64)"}
+                        "128-B request); separate --pmc passes over `bench.py --warmup 0 --no-cpu-baseline` (one 128-tick batch = the timed region)"}
     if o:
         out[name] = o
 json.dump(out, open(os.path.join(P, "final_hbm_traffic.json"), "w"), indent=1)
@@ -82,7 +82,7 @@ pb, pm = os.path.join(P, "l1_pmc_bench.txt"), os.path.join(P, "l1_pmc_microbench
 if os.path.exists(pb) and os.path.exists(pm):
     b, m = load(pb), load(pm)
     cal = [v["TCP_GATE_EN1_sum"] / v["GRBM_GUI_ACTIVE"] for k, v in m.items() if k.startswith("k<0>")][0]
-    res = {"note": "rocprofv3 --pmc (tools/pmc_l1.sh) over `bench.py --steps 64 --warmup 0 --no-cpu-baseline` and "
+    res = {"note": "rocprofv3 --pmc (tools/pmc_l1.sh) over `bench.py --warmup 0 --no-cpu-baseline` and "
                    "tools/microbench/gather2; busy = *_BUSY_sum / GRBM_GUI_ACTIVE / instances, instances = "
                    "TCP_GATE_EN1_sum/GRBM_GUI_ACTIVE of the saturated microbenchmark (%.2f)" % cal,
            "instances": cal, "kernels": {}, "microbench": {}}
