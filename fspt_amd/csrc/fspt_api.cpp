@@ -452,14 +452,15 @@ static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots) {
 
 // ticks per lane and number of lanes for a call of n_ticks (0 = the configured steady state)
 static void wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &lanes, uint32_t &per_lane) {
+  // the configured batch is the number of ticks in flight over all lanes (each lane at most WF_MAX_BATCH)
   uint32_t batch = t->batch_ticks;
-  if (batch > (uint32_t)fspt::WF_MAX_BATCH) batch = fspt::WF_MAX_BATCH;
   uint64_t fit = WF_SLOT_BUDGET / work_total;
   if (fit < 1) fit = 1;
   if (batch > fit) batch = (uint32_t)fit;
   if (batch < 1) batch = 1;
   lanes = (t->n_lanes >= 2 && batch >= 2) ? 2u : 1u;
-  per_lane = batch / lanes; // the configured batch is the number of ticks in flight over all lanes
+  per_lane = batch / lanes;
+  if (per_lane > (uint32_t)fspt::WF_MAX_BATCH) per_lane = fspt::WF_MAX_BATCH;
   (void)n_ticks;
 }
 
@@ -723,7 +724,10 @@ int fspt_target_set_viewport(fspt_target *t, uint32_t w, uint32_t h) {
 int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks) {
   if (!t) { fspt_set_error("fspt_target_set_pipeline: NULL target"); return FSPT_E_INVALID; }
   if (pipeline < 0 || pipeline > 2) { fspt_set_error("pipeline must be 0 (megakernel), 1 (wavefront) or 2 (wavefront, two lanes)"); return FSPT_E_INVALID; }
-  if (batch_ticks > (uint32_t)fspt::WF_MAX_BATCH) { fspt_set_error("batch_ticks must be <= %d", fspt::WF_MAX_BATCH); return FSPT_E_INVALID; }
+  if (batch_ticks > (uint32_t)fspt::WF_MAX_BATCH * (pipeline == 2 ? 2u : 1u)) {
+    fspt_set_error("batch_ticks must be <= %d per lane", fspt::WF_MAX_BATCH);
+    return FSPT_E_INVALID;
+  }
   t->pipeline = pipeline == 2 ? 1 : pipeline;
   t->n_lanes = pipeline == 2 ? 2u : 1u;
   if (batch_ticks) t->batch_ticks = batch_ticks;
