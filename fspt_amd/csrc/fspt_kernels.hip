@@ -740,7 +740,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 // (layout and slot numbering: fspt_device.hpp)
 // ===========================================================================
 #ifndef WF_TRACE_CHUNK
-#define WF_TRACE_CHUNK 512u
+#define WF_TRACE_CHUNK 1024u // measured at 128-tick batches: 256 / 512 / 1024 -> trace 0.317 / 0.223 / 0.214 ms per tick; 2048+ and guided (shrinking) chunk sizes are slower
 #endif
 #ifndef WF_TRACE_STATIC_CHUNKS
 #define WF_TRACE_STATIC_CHUNKS 1u // chunks of its own every wave starts with before it turns to the shared pool head

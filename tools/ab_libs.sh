@@ -2,7 +2,7 @@
 for rep in 1 2; do
 for n in "$@"; do
 echo "== $n (rep $rep)"
-FSPT_LIB=$PWD/ab_libs/$n.so timeout 300 python bench.py --steps 128 --warmup 64 --no-cpu-baseline 2>&1 | python -c "
+FSPT_LIB=$PWD/ab_libs/$n.so timeout 300 python bench.py --steps 256 --warmup 128 --no-cpu-baseline 2>&1 | python -c "
 import sys,json
 for line in sys.stdin:
     if line.startswith('{'):
