@@ -53,6 +53,11 @@ def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=15.0):
     n_shards = max(1, int(round(W * H / max(want, 1.0))))
     n_ticks = 1 if n_shards > 1 else max(1, min(256, int(want / (W * H))))
     t, s = run(n_shards, n_ticks)
+    if t < 0.6 * budget_s and n_shards == 1:
+        # the probe (a 1/32 tile sample) under-estimates how well the full frame scales over the cores: re-run with
+        # the tick count that fills the budget
+        n_ticks = max(n_ticks + 1, min(512, int(n_ticks * 0.8 * budget_s / max(t, 1e-3))))
+        t, s = run(n_shards, n_ticks)
     return {"value": round(s / t / 1e6, 5), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"oracle/liboracle.so (C restatement, OpenMP x{cores}), {n_ticks} tick(s) over every "
                       f"{n_shards}-th 32x32 tile of the same {W}x{H} depth-{bounces} frame: {s} samples in {t:.2f} s"}
