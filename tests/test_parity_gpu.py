@@ -271,6 +271,42 @@ def test_textured_scene_bitwise(camera, pipeline):
     assert pt.counters() == oc.as_dict()
 
 
+def test_million_triangle_config_shard_bitwise():
+    """BASELINE configs[2] (1 002 256 triangles, 248 MB scene, tree depth 22, 1920x1080, depth 8): every 64th tile
+    equals the CPU oracle bit for bit, work counters included; both schedulers agree on the whole frame."""
+    from fspt_amd import scene as S
+    from fspt_amd import distributed as D
+    arrays = S.bunny_scene(n=289)
+    assert arrays.n_tris > 1000000
+    cam = dict(S.BUNNY_CAMERA)
+    cam["lens"] = S.lens_features(cam["focal_depth"], cam["aperture"])
+    W, H, ticks, seed = 1920, 1080, 2, 777
+    sc = Scene(arrays)
+    pt = make_pt(sc, W, H, cam, 8, "wavefront")
+    pt.seed(seed)
+    pt.render(ticks)
+    wf = pt.readRadiance()
+    pt.close()
+    mk = make_pt(sc, W, H, cam, 8, "megakernel")
+    mk.seed(seed)
+    mk.render(ticks)
+    assert np.array_equal(mk.readRadiance(), wf)
+    mk.close()
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 8, 0, ticks, seed, want,
+             counters=oc, shard=0, n_shards=64, tile=32)
+    mask = D.owner_mask(0, 64, W, H)
+    assert np.array_equal(wf[mask], want[mask])
+    sh = make_pt(sc, W, H, cam, 8, "wavefront")
+    sh.set_shard(0, 64, 32)
+    sh.enable_counters(True)
+    sh.clear(); sh.seed(seed); sh.render(ticks)
+    assert sh.counters() == oc.as_dict()
+    sh.close()
+    sc.close()
+
+
 def test_full_size_baseline_config_properties():
     """BASELINE configs[1] at full size (69 316 triangles, 1920x1080, depth 8):
       * the two independent schedulers (wavefront / megakernel) agree on every pixel, bit for bit;
