@@ -271,6 +271,32 @@ def test_textured_scene_bitwise(camera, pipeline):
     assert pt.counters() == oc.as_dict()
 
 
+def test_4k_eight_way_tile_shards_bitwise():
+    """BASELINE configs[3] geometry (3840x2160, 32x32 tiles dealt round-robin to 8 ranks): the tiles of ranks 0 and 5,
+    rendered as shards on one GPU, equal the oracle's same shards bit for bit and touch no other pixel."""
+    from fspt_amd import scene as S
+    from fspt_amd import distributed as D
+    arrays = S.bunny_scene(n=76)
+    cam = dict(S.BUNNY_CAMERA)
+    cam["lens"] = S.lens_features(cam["focal_depth"], cam["aperture"])
+    W, H, seed = 3840, 2160, 99
+    sc = Scene(arrays)
+    for rank in (0, 5):
+        pt = make_pt(sc, W, H, cam, 8, "wavefront", 2)
+        pt.set_shard(rank, 8, D.TILE)
+        pt.seed(seed)
+        pt.render(2)
+        got = pt.readRadiance()
+        pt.close()
+        want = np.zeros((H, W, 4), np.float32)
+        O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 8, 0, 2, seed, want,
+                 shard=rank, n_shards=8, tile=D.TILE)
+        assert np.array_equal(got, want), rank
+        mask = D.owner_mask(rank, 8, W, H)
+        assert not got[~mask].any() and (got[mask][:, 3] == 1).all()
+    sc.close()
+
+
 def test_million_triangle_config_shard_bitwise():
     """BASELINE configs[2] (1 002 256 triangles, 248 MB scene, tree depth 22, 1920x1080, depth 8): every 64th tile
     equals the CPU oracle bit for bit, work counters included; both schedulers agree on the whole frame."""
