@@ -271,6 +271,24 @@ def test_textured_scene_bitwise(camera, pipeline):
     assert pt.counters() == oc.as_dict()
 
 
+@pytest.mark.parametrize("aperture", [0.02, 0.1])
+def test_baseline_c1_config_bitwise(aperture):
+    """BASELINE configs[0] - the reference's own CPU-runnable case: 256x256, depth 4, 16 spp on the 69 316-triangle
+    scene - and the same with configs[4]'s aperture 0.1: the whole frame equals the oracle bit for bit."""
+    from fspt_amd import scene as S
+    arrays = S.bunny_scene(n=76)
+    cam = dict(S.BUNNY_CAMERA, aperture=aperture)
+    cam["lens"] = S.lens_features(cam["focal_depth"], cam["aperture"])
+    W = H = 256
+    pt = make_pt(arrays, W, H, cam, 4, "wavefront")
+    pt.seed(1)
+    pt.render(16)
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 4, 0, 16, 1, want)
+    assert np.array_equal(pt.readRadiance(), want)
+    pt.close()
+
+
 def test_4k_eight_way_tile_shards_bitwise():
     """BASELINE configs[3] geometry (3840x2160, 32x32 tiles dealt round-robin to 8 ranks): the tiles of ranks 0 and 5,
     rendered as shards on one GPU, equal the oracle's same shards bit for bit and touch no other pixel."""
