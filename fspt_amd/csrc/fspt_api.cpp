@@ -440,14 +440,43 @@ static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots) {
   for (void *&m : ln.mem) { if (m) { HIP_TRY(hipFree(m)); m = nullptr; } }
   // ray_o ray_d thr col shd pend (float4) | hit (float2) | shadow_hit (int) | q_ext[2] q_shd[2] (u32) | fin (float4)
   const size_t sz[13] = {16, 16, 16, 16, 16, 16, 8, 4, 4, 4, 4, 4, 16};
+  ln.slots = 0;
+  // test hook: pretend allocations above this many slots run out of memory (exercises the batch-halving retry)
+  const char *lim = getenv("FSPT_WF_ALLOC_LIMIT_SLOTS");
+  const uint64_t limit = lim ? strtoull(lim, nullptr, 10) : ~0ull;
   for (int i = 0; i < 13; ++i) {
-    HIP_TRY(hipMalloc(&ln.mem[i], (size_t)slots * sz[i]));
+    hipError_t e = slots > limit ? hipErrorOutOfMemory : hipMalloc(&ln.mem[i], (size_t)slots * sz[i]);
+    if (e == hipErrorOutOfMemory) {
+      // not enough free HBM for this batch size: give everything back, the caller retries with half the batch
+      (void)hipGetLastError();
+      for (void *&m : ln.mem) { if (m) { hipFree(m); m = nullptr; } }
+      fspt_set_error("path state for %u slots does not fit the free device memory", slots);
+      return FSPT_E_NOMEM;
+    }
+    HIP_TRY(e);
     HIP_TRY(hipMemsetAsync(ln.mem[i], 0, (size_t)slots * sz[i], ln.stream)); // touch every page once, now
   }
   if (!ln.counts) HIP_TRY(hipMalloc((void **)&ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2)));
   HIP_TRY(hipStreamSynchronize(ln.stream));
   ln.slots = slots;
   return FSPT_OK;
+}
+
+static void wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &lanes, uint32_t &per_lane);
+
+// Plan the batch and make sure every lane's path state is allocated; when the device is short of memory the
+// configured batch is halved until it fits (results do not depend on the batch size).
+static int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &n_lanes, uint32_t &per_lane) {
+  while (true) {
+    wf_plan(t, work_total, n_ticks, n_lanes, per_lane);
+    if ((uint64_t)per_lane * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
+    int rc = FSPT_OK;
+    for (uint32_t l = 0; l < n_lanes && rc == FSPT_OK; ++l) rc = wf_ensure(t, t->lanes[l], (uint32_t)(per_lane * work_total));
+    if (rc != FSPT_E_NOMEM) return rc;
+    if (per_lane <= 1) return rc;
+    t->batch_ticks = per_lane * n_lanes / 2;
+    if (t->batch_ticks < 1) t->batch_ticks = 1;
+  }
 }
 
 // ticks per lane and number of lanes for a call of n_ticks (0 = the configured steady state)
@@ -486,14 +515,11 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
   fill_trace_params(t, tp);
   const uint32_t work_total = tp.n_owned_tiles * tp.tile * tp.tile;
   if (work_total == 0) return FSPT_OK;
-  uint32_t n_lanes, per_lane;
-  wf_plan(t, work_total, n_ticks, n_lanes, per_lane);
-  if ((uint64_t)per_lane * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
   // path-state buffers are sized for the CONFIGURED batch at first use (not for this call's tick count):
   // a short warm-up call must not cause a reallocation inside a later, longer call
-  int rc = FSPT_OK;
-  for (uint32_t l = 0; l < n_lanes; ++l)
-    if ((rc = wf_ensure(t, t->lanes[l], per_lane * work_total))) return rc;
+  uint32_t n_lanes, per_lane;
+  int rc = wf_plan_and_ensure(t, work_total, n_ticks, n_lanes, per_lane);
+  if (rc) return rc;
   // a short call is still split over both lanes so that its two halves overlap
   uint32_t batch = per_lane;
   if (n_lanes == 2 && n_ticks < 2 * per_lane) batch = (n_ticks + 1) / 2;
@@ -743,13 +769,7 @@ int fspt_target_prepare(fspt_target *t) {
   const uint64_t work_total = (uint64_t)tp.n_owned_tiles * tp.tile * tp.tile;
   if (work_total == 0) return FSPT_OK;
   uint32_t n_lanes, per_lane;
-  wf_plan(t, work_total, 0, n_lanes, per_lane);
-  if ((uint64_t)per_lane * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
-  for (uint32_t l = 0; l < n_lanes; ++l) {
-    int rc = wf_ensure(t, t->lanes[l], (uint32_t)(per_lane * work_total));
-    if (rc) return rc;
-  }
-  return FSPT_OK;
+  return wf_plan_and_ensure(t, work_total, 0, n_lanes, per_lane);
 }
 
 int fspt_last_stage_ms(fspt_target *t, float ms[4], uint32_t launches[4]) {

@@ -637,3 +637,26 @@ def test_fuzz_random_scenes_bitwise(seed):
         assert np.array_equal(got, want, equal_nan=True), f"{pipeline}: {(got != want).any(-1).sum()} of {W * H} pixels differ"
         assert pt.counters() == oc.as_dict(), pipeline
         pt.close()
+
+
+def test_batch_is_halved_when_path_state_does_not_fit(small_scene, camera, monkeypatch):
+    """Out of device memory for the configured batch (simulated through the allocation hook): the wavefront
+    pipeline halves its batch until the path state fits; the result does not depend on the batch size."""
+    W, H = 96, 64
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
+             0, 9, 31, want)
+    work_total = 3 * 2 * 1024  # 32x32 tiles covering 96x64
+    monkeypatch.setenv("FSPT_WF_ALLOC_LIMIT_SLOTS", str(3 * work_total))
+    pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
+    pt.prepare()
+    pt.seed(31)
+    pt.render(9)
+    assert np.array_equal(pt.readRadiance(), want)
+    st = pt.last_stage_ms()
+    assert st["gen"][1] == 5  # 9 ticks in batches of 2 (128 -> 64 -> ... -> 2 slots-per-pixel fit the limit)
+    monkeypatch.setenv("FSPT_WF_ALLOC_LIMIT_SLOTS", "10")
+    pt2 = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
+    with pytest.raises(L.FsptError) as ei:
+        pt2.render(1)
+    assert ei.value.code == -4
