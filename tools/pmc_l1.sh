@@ -15,7 +15,7 @@ for set in \
  "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
  "TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/b$i -- python3 $R/bench.py --warmup 0 --no-cpu-baseline > $O/b$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/b$i -- python3 $R/bench.py --warmup 0 --no-cpu-baseline "$@" > $O/b$i.log 2>&1
   timeout 120 rocprofv3 --pmc $set --output-format csv -d $O/m$i -- $R/tools/microbench/gather2 > $O/m$i.log 2>&1
 done
 python3 - "$O" <<'PY'
