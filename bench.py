@@ -162,18 +162,45 @@ def main():
         spt = cnt["samples"]  # samples per tick on this rank
         per_sample = {k: round(v / max(1, spt), 4) for k, v in cnt.items() if k != "samples"}
         if stages is not None:
-            # dominant kernel: intersectScene = fspt::k_wf_trace.  Its algorithmic bytes are the S and L terms
-            # of SURVEY 8d: 60 B per traversal step + 144 B per leaf visit (reference layout).
-            tr_ms, tr_n = stages["trace"]
-            trace_bytes = (60.0 * cnt["steps"] + 144.0 * cnt["leaves"]) * args.steps
-            achieved = trace_bytes / (tr_ms / 1e3) / 1e9
-            avg_launch_ms = tr_ms / max(1, tr_n)
-            kernel = "fspt::k_wf_trace<false>"
-            extra = {"launches": tr_n, "bytes_per_launch": round(trace_bytes / max(1, tr_n)),
+            # The same counters for the camera rays alone (depth 0: no shading, no secondary rays) split the algorithmic
+            # bytes of SURVEY 8d (60 S + 144 L + 280 H + 16 E + 64 per sample, reference layout) over the kernels:
+            #   primary launch (ray generation + camera ray traversal + its shading): 60 S0 + 144 L0 + 280 H1 + 16 E0 + 32
+            #   k_wf_trace  (rounds >= 1: extension and shadow rays)               : 60 (S - S0) + 144 (L - L0)
+            #   k_wf_logic  (rounds >= 2)                                          : 280 (H - H1) + 16 (E - E0)
+            #   k_wf_resolve (running mean)                                        : 32
+            nb_keep = pt.num_bounces
+            pt.num_bounces = 0
+            pt.enable_counters(True)
+            L.check(L.lib().fspt_counters_reset(pt._t))
+            pt.render(1)
+            c0 = pt.counters()
+            pt.enable_counters(False)
+            pt.num_bounces = nb_keep
+            h1 = (c0["samples"] - c0["env_lookups"]) if args.bounces >= 1 else 0  # camera rays that hit and get shaded
+            alg = {"primary": 60.0 * c0["steps"] + 144.0 * c0["leaves"] + 280.0 * h1 + 16.0 * c0["env_lookups"] + 32.0 * spt,
+                   "trace": 60.0 * (cnt["steps"] - c0["steps"]) + 144.0 * (cnt["leaves"] - c0["leaves"]),
+                   "logic": 280.0 * (cnt["shades"] - h1) + 16.0 * (cnt["env_lookups"] - c0["env_lookups"]),
+                   "resolve": 32.0 * spt}
+            names = {"primary": "fspt::k_wf_logic<false, true, true>", "trace": "fspt::k_wf_trace<false>",
+                     "logic": "fspt::k_wf_logic<false, false, true>", "resolve": "fspt::k_wf_resolve"}
+            kernels = {}
+            for k, (ms, n) in stages.items():
+                kernels[k] = {"kernel": names[k], "launches": n, "ms_per_step": round(ms / args.steps, 4),
+                              "avg_launch_ms": round(ms / max(1, n), 4), "alg_bytes_per_step": round(alg[k]),
+                              "achieved_GBps": round(alg[k] * args.steps / (ms / 1e3) / 1e9, 1) if ms > 0 else None}
+            # the roofline block is about the kernel class that takes the largest share of the timed region
+            dom = max(("primary", "trace", "logic"), key=lambda k: stages[k][0])
+            d_ms, d_n = stages[dom]
+            dom_bytes = alg[dom] * args.steps
+            achieved = dom_bytes / (d_ms / 1e3) / 1e9
+            avg_launch_ms = d_ms / max(1, d_n)
+            kernel = names[dom]
+            extra = {"launches": d_n, "bytes_per_launch": round(dom_bytes / max(1, d_n)), "kernels": kernels,
                      "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stages.items()},
                      "stage_launches": {k: v[1] for k, v in stages.items()},
                      "pipeline_GBps": round(bps * spt * args.steps / (kernel_ms / 1e3) / 1e9, 2)}
         else:
+            dom = None
             avg_launch_ms = kernel_ms / max(1, launches)
             achieved = bps * spt / (avg_launch_ms / 1e3) / 1e9
             kernel = "fspt::k_trace<true,false>"
@@ -183,24 +210,31 @@ def main():
                     "avg_launch_ms": round(avg_launch_ms, 4), "bytes_per_sample": round(bps, 1),
                     "per_sample": per_sample}
         roofline.update(extra)
-        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot run the
+        # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (bench.py cannot run the
         # profiler on itself): only reported for the exact workload those passes measured
         tpath = os.path.join(ROOT, "profiles", "r01", "final_hbm_traffic.json")
         key = {76: "c2_70k", 289: "c3_1M"}.get(args.mesh_n)
-        if (stages is not None and key and os.path.exists(tpath) and n_gpus == 1
+        if (stages is not None and key and os.path.exists(tpath) and n_gpus == 1 and args.steps == args.batch == 128
                 and (args.width, args.height, args.bounces) == (1920, 1080, 8)):
-            tj = json.load(open(tpath)).get(key, {}).get("k_wf_trace<false>")
-            if tj:
-                roofline["traffic"] = round(tj["hbm_bytes_per_launch_corrected"])
+            tall = json.load(open(tpath)).get(key, {})
+            for k in kernels:
+                tj = tall.get(names[k].replace("fspt::", ""))
+                if tj:
+                    kernels[k]["hbm_traffic_per_launch"] = round(tj["hbm_bytes_per_launch_corrected"])
+            if "hbm_traffic_per_launch" in kernels[dom]:
+                roofline["traffic"] = kernels[dom]["hbm_traffic_per_launch"]
                 roofline["traffic_source"] = "profiles/r01/final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
-            # what actually bounds the kernel on this cache-resident scene: the CU's vector-memory pipeline
-            # (TA address / TD data-return units of the L1), DESIGN.md 4.3
+            # what the kernels queue on besides HBM: the CU's vector-memory pipeline (TA address / TD data-return
+            # units of the L1), DESIGN.md 7
             lpath = os.path.join(ROOT, "profiles", "r01", "l1_pipe.json")
             if key == "c2_70k" and os.path.exists(lpath):
                 lj = json.load(open(lpath))
-                kj = lj["kernels"].get("k_wf_trace<false>")
-                if kj:
-                    roofline["vmem_pipe"] = {"TA_busy": kj["TA_busy"], "TD_busy": kj["TD_busy"],
+                for k in kernels:
+                    kj = lj["kernels"].get(names[k].replace("fspt::", ""))
+                    if kj:
+                        kernels[k]["vmem_pipe_busy"] = {"TA": kj["TA_busy"], "TD": kj["TD_busy"]}
+                if "vmem_pipe_busy" in kernels[dom]:
+                    roofline["vmem_pipe"] = {"TA_busy": kernels[dom]["vmem_pipe_busy"]["TA"], "TD_busy": kernels[dom]["vmem_pipe_busy"]["TD"],
                                              "l1_gather_peak_GBps": lj["l1_gather_GBps"]["divergent_64B_records"],
                                              "source": "profiles/r01/l1_pipe.json (rocprofv3 --pmc TA_TA_BUSY / TD_TD_BUSY; tools/microbench/gather2)"}
         out = {

@@ -568,15 +568,14 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     p.first_tick = first_tick + done;
     for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
     HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
-    p.round = 0;
-    if ((rc = launch(fspt::WF_K_GEN))) return rc;
-    if ((rc = launch(fspt::WF_K_TRACE))) return rc;
-    // round r: logic consumes the results of trace r-1 and shades bounce r-1; after round nb+1 every path
-    // has finished unless a refraction kept `i` from advancing (tracer.fs:488)
+    p.gen_rays = gen ? 1u : 0u;
+    // round 1 = the primary launch (ray generation + primary traversal + its shading); round r >= 2: logic consumes
+    // the results of trace r-1 and shades bounce r-1; after round nb+1 every path has finished unless a refraction
+    // kept `i` from advancing (tracer.fs:488)
     uint32_t r = 1;
     for (; r <= nb + 1; ++r) {
       p.round = r;
-      if ((rc = launch(fspt::WF_K_LOGIC))) return rc;
+      if ((rc = launch(r == 1 ? fspt::WF_K_PRIMARY : fspt::WF_K_LOGIC))) return rc;
       if (r <= nb || t->scene->has_dielectric) { if ((rc = launch(fspt::WF_K_TRACE))) return rc; }
     }
     if (t->scene->has_dielectric) {

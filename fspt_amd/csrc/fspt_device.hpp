@@ -116,6 +116,7 @@ struct alignas(16) WfCounts { // one per round, zeroed before the batch
 };
 
 struct WfP {
+  uint32_t gen_rays; // primary launch: 1 = camera.fs in the kernel, 0 = read the ray buffers (two-call form)
   uint32_t lds_top; // top-of-tree nodes k_wf_trace keeps in LDS (<= scene.n_top; set by launch_wf)
   DScene scene;
   float4 *ray_o, *ray_d, *thr, *col, *shd, *pend;
@@ -142,7 +143,7 @@ struct WfP {
   uint32_t shard, n_shards, tile, tiles_x, tiles_y, n_owned_tiles;
 };
 
-enum { WF_K_GEN = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3 };
+enum { WF_K_PRIMARY = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3 }; // also the slots of fspt_last_stage_ms
 hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream);
 
 // launchers (fspt_kernels.hip)

@@ -5,8 +5,9 @@
 // arithmetic (advance_path / shade_hit / trace loops below) and give
 // bit-identical results:
 //
-//  * wavefront pipeline (default; k_wf_gen / k_wf_trace / k_wf_logic / k_wf_resolve):
-//    path state in HBM, slot queues, one kernel per kind of work.  k_wf_trace is a
+//  * wavefront pipeline (default; k_wf_logic<first> / k_wf_trace / k_wf_logic / k_wf_resolve):
+//    path state in HBM, slot queues, one kernel per kind of work; the first launch of a batch does ray
+//    generation, the primary ray's traversal and its shading in one kernel.  k_wf_trace is a
 //    persistent while-while traversal with per-lane dynamic refill from the ray queue,
 //    its deferred-child stack in LDS; k_wf_logic does one S step per live path and
 //    compacts the survivors (one 64-bit atomic per 1024 paths).
@@ -822,40 +823,6 @@ FM_DEV uint32_t lane_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// ---- gen: camera.fs main for every (tick, pixel) of the batch; queue = identity -------
-template <bool GEN_RAYS, bool COUNT>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_wf_gen(const WfP p) {
-  const uint32_t total = p.n_batch * p.work_total;
-  uint32_t nsamples = 0;
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
-    uint32_t w = s / p.n_batch, j = s - w * p.n_batch; // pixel-major: the batch's ticks of a pixel are adjacent
-    uint32_t x, y;
-    uint32_t entry = WF_DEAD;
-    if (work_to_pixel(p, w, x, y)) {
-      V3 o, d;
-      if (GEN_RAYS) {
-        camera_ray(x, y, p.W, p.H, p.cam, p.rb_cam[j], o, d);
-      } else {
-        float4 po = p.ray_pos[y * p.W + x], di = p.ray_dir[y * p.W + x];
-        o = v3(po.x, po.y, po.z);
-        d = v3(di.x, di.y, di.z);
-      }
-      // thr = 1, colour = 0, flags = PRIMARY are implied in round 1 (k_wf_logic<.., true>): not stored
-      st4(p.ray_o + s, make_float4(o.x, o.y, o.z, 0.0f));
-      st4(p.ray_d + s, make_float4(d.x, d.y, d.z, 0.0f));
-      entry = s;
-      nsamples++;
-    }
-    p.q_ext[0][s] = entry;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) p.counts[0].n_ext = total;
-  if (COUNT) {
-    unsigned long long x = nsamples;
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
-    if ((threadIdx.x & (WAVE - 1)) == 0 && x) atomicAdd(p.counters + 0, x);
-  }
-}
-
 // ---- trace: intersectScene for a queue of rays; persistent waves, per-lane refill -------
 // Items [0, n_shd) are the NEE shadow rays of q_shd, items [n_shd, n_shd + n_ext) the
 // primary/extension rays of q_ext.  A lane whose ray is finished writes its result and
@@ -1043,9 +1010,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 #ifndef WF_LOGIC_WAVES
 #define WF_LOGIC_WAVES 4
 #endif
-// FIRST: round 1, where every path is a fresh primary: the queue is the identity (slot = index, validity
-// recomputed from the pixel mapping) and thr / colour / flags are constants, so neither is read - round 1
-// streams the whole batch's path state through HBM and is bandwidth-bound.
+// FIRST: round 1 = the PRIMARY launch.  It does camera.fs (or reads the injected ray buffers), traces the camera ray
+// (intersectScene in place, stack in LDS) and shades it, for every slot of the batch: the primary ray never travels
+// through HBM, thr / colour / flags are constants, and the VALU-bound shading of some waves overlaps the memory-bound
+// traversal of others on the same SIMD (measured +5.6 % over separate gen / trace / logic launches, profiles/r01).
 #ifndef WF_LOGIC_WAVES_FIRST
 #define WF_LOGIC_WAVES_FIRST WF_LOGIC_WAVES
 #endif
@@ -1063,6 +1031,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 #endif
 template <bool COUNT, bool FIRST, bool LDSTAB>
 __global__ __launch_bounds__(WF_LOGIC_THREADS, FIRST ? WF_LOGIC_WAVES_FIRST : WF_LOGIC_WAVES) void k_wf_logic(const WfP p) {
+  extern __shared__ int lds_dyn[]; // FIRST: the waves' traversal stacks
   static_assert(WF_LOGIC_THREADS % WAVE == 0, "whole waves");
   constexpr int NW = WF_LOGIC_THREADS / WAVE;
   constexpr int U = FIRST ? WF_LOGIC_U_FIRST : WF_LOGIC_U; // paths per thread between two compactions (amortises 2 barriers + 1 atomic)
@@ -1086,7 +1055,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, FIRST ? WF_LOGIC_WAVES_FIRST : WF
   const uint32_t *__restrict__ q_in = p.q_ext[rd_i];
   uint32_t *__restrict__ q_out = p.q_ext[wr_i];
   uint32_t *__restrict__ q_shd_out = p.q_shd[wr_i];
-  const uint32_t n_in = p.counts[p.round - 1].n_ext;
+  const uint32_t n_in = FIRST ? p.n_batch * p.work_total : p.counts[p.round - 1].n_ext;
   WfCounts *cn = p.counts + p.round;
   Counters cnt = {0, 0, 0, 0, 0, 0};
 
@@ -1098,21 +1067,40 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, FIRST ? WF_LOGIC_WAVES_FIRST : WF
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t i = base + (uint32_t)u * WF_LOGIC_THREADS + threadIdx.x;
-      uint32_t s = WF_DEAD;
+      uint32_t s = WF_DEAD, fx = 0, fy = 0;
       if (i < n_in) {
         if (FIRST) {
-          uint32_t px, py;
-          s = work_to_pixel(p, i / p.n_batch, px, py) ? i : WF_DEAD;
+          s = work_to_pixel(p, i / p.n_batch, fx, fy) ? i : WF_DEAD;
         } else {
           s = q_in[i];
         }
       }
       bool survive = false, shadow = false;
       if (s != WF_DEAD) {
-        float4 ro = ld4(p.ray_o + s), rd = ld4(p.ray_d + s);
+        float4 ro, rd;
+        float2 h;
+        if (FIRST) {
+          V3 o, d;
+          if (p.gen_rays) {
+            camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[s % p.n_batch], o, d);
+          } else {
+            float4 po = p.ray_pos[fy * p.W + fx], di = p.ray_dir[fy * p.W + fx];
+            o = v3(po.x, po.y, po.z);
+            d = v3(di.x, di.y, di.z);
+          }
+          if (COUNT) cnt.samples++;
+          int hitA, hitB;
+          float tB;
+          trace_rays<COUNT>(S, lds_dyn + (size_t)wave * S.stack_n * WAVE + lane, o, false, d, d, hitA, tB, hitB, cnt);
+          ro = make_float4(o.x, o.y, o.z, 0.0f);
+          rd = make_float4(d.x, d.y, d.z, 0.0f);
+          h = make_float2(tB, __int_as_float(hitB));
+        } else {
+          ro = ld4(p.ray_o + s); rd = ld4(p.ray_d + s);
+          h = ld2(p.hit + s);
+        }
         float4 th = make_float4(1.0f, 1.0f, 1.0f, 0.0f), co = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(WF_FLAG_PRIMARY));
         if (!FIRST) { th = ld4(p.thr + s); co = ld4(p.col + s); }
-        float2 h = ld2(p.hit + s);
         uint32_t flags = __float_as_uint(co.w);
         Path ps;
         ps.ro = v3(ro.x, ro.y, ro.z);
@@ -1191,12 +1179,12 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, FIRST ? WF_LOGIC_WAVES_FIRST : WF
     __syncthreads();
   }
   if (COUNT) {
-    unsigned long long v[2] = {cnt.shades, cnt.envs};
+    unsigned long long v[6] = {cnt.samples, cnt.rays, cnt.steps, cnt.leaves, cnt.shades, cnt.envs};
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = FIRST ? 0 : 4; i < 6; ++i) {
       unsigned long long x = v[i];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
-      if (lane == 0 && x) atomicAdd(p.counters + 4 + i, x);
+      if (lane == 0 && x) atomicAdd(p.counters + i, x);
     }
   }
 }
@@ -1381,16 +1369,7 @@ hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus,
 hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream) {
   const uint32_t total = p.n_batch * p.work_total;
   if (total == 0) return hipSuccess;
-  if (kernel == WF_K_GEN) {
-    uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 16u);
-    if (gen_rays) {
-      if (count) hipLaunchKernelGGL((k_wf_gen<true, true>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
-      else hipLaunchKernelGGL((k_wf_gen<true, false>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
-    } else {
-      if (count) hipLaunchKernelGGL((k_wf_gen<false, true>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
-      else hipLaunchKernelGGL((k_wf_gen<false, false>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
-    }
-  } else if (kernel == WF_K_TRACE) {
+  if (kernel == WF_K_TRACE) {
     // persistent: the grid only has to fill the machine; the pool head balances the work
     uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
     size_t lds = stack_bytes(p.scene);
@@ -1408,11 +1387,12 @@ hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int nu
     }
     if (count) hipLaunchKernelGGL((k_wf_trace<true>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, q);
     else hipLaunchKernelGGL((k_wf_trace<false>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, q);
-  } else if (kernel == WF_K_LOGIC) {
+  } else if (kernel == WF_K_LOGIC || kernel == WF_K_PRIMARY) { // PRIMARY = the logic kernel's round-1 specialisation
     uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * 4u);
-    const bool first = (p.round == 1);
+    const bool first = (kernel == WF_K_PRIMARY);
     const bool lds = WF_LOGIC_LDSTAB && p.scene.atlas_res == 1u && p.scene.atlas_layers <= WF_LDS_ATLAS && p.scene.n_bins <= WF_LDS_BINS;
-#define FSPT_LAUNCH_LOGIC(C, F, T) hipLaunchKernelGGL((k_wf_logic<C, F, T>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p)
+    const size_t dyn = first ? (size_t)(WF_LOGIC_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int) : 0;
+#define FSPT_LAUNCH_LOGIC(C, F, T) hipLaunchKernelGGL((k_wf_logic<C, F, T>), dim3(grid), dim3(WF_LOGIC_THREADS), dyn, stream, p)
     if (count) {
       if (first) { if (lds) FSPT_LAUNCH_LOGIC(true, true, true); else FSPT_LAUNCH_LOGIC(true, true, false); }
       else { if (lds) FSPT_LAUNCH_LOGIC(true, false, true); else FSPT_LAUNCH_LOGIC(true, false, false); }

@@ -119,7 +119,7 @@ class PathTracer:
     def last_stage_ms(self):
         ms = (C.c_float * 4)(); n = (C.c_uint32 * 4)()
         L.check(L.lib().fspt_last_stage_ms(self._t, ms, n))
-        return {k: (ms[i], n[i]) for i, k in enumerate(("gen", "trace", "logic", "resolve"))}
+        return {k: (ms[i], n[i]) for i, k in enumerate(("primary", "trace", "logic", "resolve"))}
 
     def enable_counters(self, on=True):
         L.check(L.lib().fspt_enable_counters(self._t, 1 if on else 0))

@@ -167,7 +167,7 @@ float fspt_rand_base_next(uint64_t *state);
 int fspt_target_set_viewport(fspt_target *target, uint32_t w, uint32_t h);
 
 /* Execution strategy of fspt_trace / fspt_render (results are bit-identical):
- *   pipeline 1 (default) "wavefront": gen -> [trace <-> logic] x rounds -> resolve, queue-driven
+ *   pipeline 1 (default) "wavefront": primary -> [trace <-> logic] x rounds -> resolve, queue-driven
  *              kernels over batch_ticks ticks at a time (0 keeps the current batch size; default and max 128);
  *   pipeline 0 "megakernel": one persistent kernel per tick (path regeneration);
  *   pipeline 2 "wavefront, two lanes": pipeline 1 with the batch split in two halves that run
@@ -177,7 +177,9 @@ int fspt_target_set_pipeline(fspt_target *target, int pipeline, uint32_t batch_t
  * instead of lazily inside the first fspt_trace / fspt_render.  Blocking. */
 int fspt_target_prepare(fspt_target *target);
 /* Per-kernel-class timing of the most recent fspt_trace / fspt_render (wavefront pipeline):
- * summed HIP-event durations and launch counts for {gen, trace, logic, resolve}. Blocking. */
+ * summed HIP-event durations and launch counts for {primary, trace, logic, resolve}: primary = the first launch of
+ * a batch (ray generation + the camera ray's traversal + its shading in one kernel), trace / logic = the later
+ * rounds' traversal and shading launches, resolve = the running-mean fold. Blocking. */
 int fspt_last_stage_ms(fspt_target *target, float ms[4], uint32_t launches[4]);
 
 /* clear() (main.js:826-836). */
