@@ -36,7 +36,7 @@ cp(f"{G}/{prefix}_l1/summary_b.txt", "l1_pmc_bench.txt")
 cp(f"{G}/{prefix}_l1/summary_m.txt", "l1_pmc_microbench.txt")
 cp(f"{G}/{prefix}_pmc/summary.txt", "final_pmc_summary.txt")
 
-KERNELS = ("k_wf_trace<false>", "k_wf_logic<false, false, true>", "k_wf_logic<false, true, true>", "k_wf_gen<true, false>", "k_wf_resolve")
+KERNELS = ("k_wf_trace<false>", "k_wf_logic<false, false, true>", "k_wf_logic<false, true, true>", "k_wf_resolve")
 out = {}
 for tag, name in (("", "c2_70k"), ("_c3", "c3_1M")):
     res = {}

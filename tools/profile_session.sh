@@ -13,7 +13,7 @@ timeout 600 python3 bench.py --mesh-n 289 --no-cpu-baseline > $O/${P}_c3.log 2>&
 timeout 300 python3 bench.py --aperture 0.1 --no-cpu-baseline > $O/${P}_c5.log 2>&1
 timeout 300 python3 bench.py --width 3840 --height 2160 --steps 64 --no-cpu-baseline > $O/${P}_4k.log 2>&1
 timeout 300 python3 bench.py --pipeline megakernel --steps 16 --no-cpu-baseline > $O/${P}_mega.log 2>&1
-timeout 300 python3 bench.py --pipeline wavefront2 --steps 256 --warmup 128 --no-cpu-baseline > $O/${P}_lanes2.log 2>&1
+timeout 300 python3 bench.py --pipeline wavefront2 --steps 512 --warmup 256 --batch 256 --no-cpu-baseline > $O/${P}_lanes2.log 2>&1
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${P}_kt -- python3 $R/bench.py --no-cpu-baseline > $O/${P}_kt.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
