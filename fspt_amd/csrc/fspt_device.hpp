@@ -88,7 +88,7 @@ struct IntersectP {
 // ---------------------------------------------------------------------------
 // Wavefront pipeline (fspt_render's default): the same per-path arithmetic cut
 // into queue-driven kernels so that every lane of a wave does the same kind of
-// work:  gen -> [ trace <-> logic ] x rounds -> resolve.
+// work:  primary (ray generation + camera-ray traversal + its shading) -> [ trace <-> logic ] x rounds -> resolve.
 //   slot s = w * n_batch + j  : sample of tick (first_tick + j) for work index w
 //   (pixel via work_to_pixel); a batch holds n_batch ticks.  Pixel-major on purpose:
 //   the ticks of one pixel are neighbours in every queue, so a wave's primary rays are

@@ -737,7 +737,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 }
 
 // ===========================================================================
-// Wavefront pipeline: gen -> [trace <-> logic] x rounds -> resolve
+// Wavefront pipeline: primary -> [trace <-> logic] x rounds -> resolve
 // (layout and slot numbering: fspt_device.hpp)
 // ===========================================================================
 #ifndef WF_TRACE_CHUNK

@@ -36,7 +36,7 @@ with open(O+'/summary.txt','w') as out:
 f=glob.glob(O+'/kt/*/*_kernel_trace.csv')
 if f:
     rows=sorted(csv.DictReader(open(f[0])), key=lambda r:int(r['Start_Timestamp']))
-    idx=[i for i,r in enumerate(rows) if 'k_wf_gen' in r['Kernel_Name']]
+    idx=[i for i,r in enumerate(rows) if 'k_wf_logic<false, true' in r['Kernel_Name']]
     with open(O+'/rounds.txt','w') as out:
         for r in rows[idx[-1]:idx[-1]+21]:
             n=r['Kernel_Name'].split('(')[0].replace('void fspt::','')
