@@ -368,3 +368,32 @@ def test_bvh_test_counts_on_random_soups_equal_reference_glsl(seed):
     h = idx >= 0
     assert h.sum() > 100
     assert (np.abs(z[f"s{seed}_hit_t"].reshape(-1)[h] - t[h]) / np.maximum(t[h], 1e-6)).max() < 1e-4
+
+
+def test_d2_d3_variant_scene_matches_glsl():
+    """The same D2 / D3 probes on the 'variant' scene (mesh normals, quads, negative indices, a dielectric and an
+    emissive MTL material, metallic-roughness colours): hit index and t, hit point, barycentrics, uv, interpolated and
+    normal-mapped normals, the four material maps, ior and dielectric per hit triangle."""
+    st = np.load(os.path.join(GOLD, "glsl_stages_variant.npz"))
+    a = scene_from_golden("variant")
+    W, H = int(st["W"]), int(st["H"])
+    rays = np.concatenate([st["rays_pos"][..., :3], st["rays_dir"][..., :3]], -1).reshape(-1, 6)
+    t, idx, _, _ = O.intersect(a, rays)
+    gi, gt = st["hit_index"].reshape(-1), st["hit_t"].reshape(-1)
+    assert np.array_equal(gi, idx)
+    m = gi >= 0
+    assert m.sum() > 1000 and np.max(np.abs(gt[m] - t[m]) / t[m]) <= 1e-6
+    acc = np.zeros((H, W, 4), np.float32)
+    fh = O.trace(a, W, H, st["rays_pos"], st["rays_dir"], 0, 1.0, float(st["env_theta"]), 4, acc, first_hits=True).reshape(H, W)
+    hit = st["hit_index"] >= 0
+    for field, key, cols, tol in [("origin", "shade0", slice(0, 3), 1e-5), ("bary", "shade1", slice(0, 3), 5e-5),
+                                  ("uv", "shade2", slice(0, 2), 1e-5), ("bary_normal", "shade6", slice(0, 3), 1e-5),
+                                  ("mr", "shade2", slice(2, 4), 5e-4), ("diffuse", "shade3", slice(0, 3), 5e-4),
+                                  ("tex_normal", "shade4", slice(0, 3), 1e-3), ("macro_normal", "shade5", slice(0, 3), 1e-3),
+                                  ("emissive", "shade7", slice(0, 3), 5e-4)]:
+        d = np.abs(st[key][..., cols] - fh[field])[hit]
+        assert d.max() <= tol, f"{field}: max abs diff {d.max()}"
+    ti = st["hit_index"][hit]
+    assert np.array_equal(st["shade3"][..., 3][hit], a.mat.reshape(-1, 12)[ti, 9])    # ior
+    assert np.array_equal(st["shade4"][..., 3][hit], a.mat.reshape(-1, 12)[ti, 10])   # dielectric
+    assert (a.mat.reshape(-1, 12)[ti, 10] > 0).any() and (st["shade7"][..., :3][hit] > 0).any()  # refractive, emissive hit

@@ -250,14 +250,16 @@ def probe(g, sel):
     return img
 
 
-def make_glsl():
+def make_glsl(name="small"):
     import glsl_ref as G
     import oracle as O
     cam = dict(S.BUNNY_CAMERA)
+    if name != "small":  # the camera of the converged golden of the same scene
+        cam["P"], cam["I"] = CONVERGED[name][4], CONVERGED[name][5]
     lens = S.lens_features(cam["focal_depth"], cam["aperture"])
     g = G.GlslRef()
     print(g.renderer)
-    arrays = load_scene("small")
+    arrays = load_scene(name)
     g.scene(arrays)
     g._env_theta = cam["env_theta"]
     W, H = 64, 40
@@ -291,8 +293,8 @@ def make_glsl():
     A2 = A.copy(); A2[..., 3] = np.float32(cam["env_theta"])  # envSample uses the envTheta uniform
     g.set_camera(A2, B)
     out["brdf3"] = probe(g, BRDF + 3)
-    print("probes", round(time.time() - t0, 1), "s")
-    np.savez_compressed(os.path.join(GOLD, "glsl_stages_small.npz"), **out)
+    print("probes", round(time.time() - t0, 1), "s", "hits", float((out["hit_index"] >= 0).mean()))
+    np.savez_compressed(os.path.join(GOLD, f"glsl_stages_{name}.npz"), **out)
 
 
 
@@ -488,6 +490,8 @@ if __name__ == "__main__":
             make_js()
         elif w == "glsl":
             make_glsl()
+        elif w.startswith("glsl:"):
+            make_glsl(w.split(":", 1)[1])
         elif w == "converged":
             for name in CONVERGED:
                 subprocess.check_call([sys.executable, "-u", os.path.abspath(__file__), "converged:" + name])
