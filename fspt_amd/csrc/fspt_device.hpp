@@ -95,9 +95,10 @@ struct IntersectP {
 //   near-identical (coherent traversal, broadcast node loads) and neighbouring paths
 //   shade the same triangle/material.
 // Path state lives in HBM as float4 SoA arrays (coalesced 16-byte accesses):
-//   ray_o  ro.xyz, -            ray_d  rd.xyz, -
+//   ray_o  ro.xyz, -
 //   thr    accumulatedReflectance.xyz, weights.y
-//   col    color.xyz, flags (bits: 0-7 bounce, 8-15 iters, 16 primary, 17 hasShadow)
+//   ray_d  rd.xyz, flags (bits: 0-7 bounce, 8-15 iters, 16 primary, 17 hasShadow, 18 colour is +0)
+//   col    color.xyz, -   (only touched while the colour is non-zero)
 //   shd    envDir.xyz, weights.x     pend  reflectance*envThroughput.xyz, -
 //   hit    (t, index) of the extension/primary ray;  shadow_hit  index of the NEE ray
 //   fin    finished sample colour, indexed tick-major [j][w]
@@ -105,7 +106,7 @@ struct IntersectP {
 // ---------------------------------------------------------------------------
 constexpr uint32_t WF_DEAD = 0xFFFFFFFFu;
 constexpr int WF_MAX_BATCH = 128;
-constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17;
+constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17, WF_FLAG_COLZERO = 1u << 18;
 
 struct alignas(16) WfCounts { // one per round, zeroed before the batch
   uint32_t n_ext;  // entries of q_ext for this round   } bumped together by one 64-bit atomic
