@@ -1,36 +1,70 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the path-trace hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scaling weak|strong]
 
-One "step" = one tick of the reference's render loop (main.js:838-857): one
-sample for every pixel of the frame (camera ray -> full path, tracer.fs:436-518)
-accumulated into the running-mean radiance buffer.  N=1 workload = BASELINE
-configs[1]: synthetic 'bunny' scene (69 316 triangles), 1920x1080, depth 8.
-For N>1 (launched by torch.distributed.run, one rank per GPU) the frame grows
-with N (weak scaling: 1920*a x 1080*b, a*b = N), is cut into 32x32 tiles dealt
-round-robin to the ranks (no data-path collective), and ONE RCCL exchange of the
-RGBA32F radiance buffer to rank 0 closes the timed region: a gather of
-each rank's own tiles (default) or a sum-reduce of the full frame (--exchange reduce).
+One "step" = one tick of the reference's render loop (main.js:838-857): one sample for every pixel of the frame
+(camera ray -> full path, tracer.fs:436-518) accumulated into the running-mean radiance buffer.  N=1 workload =
+BASELINE configs[1] ("c2"): synthetic 'bunny' scene (69 316 triangles), 1920x1080, depth 8.
 
-Rank 0 prints ONE JSON line.
+N > 1: one process per GPU over RCCL.  Started by `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in
+the environment) the script is one rank; started plainly with --gpus N > 1 it launches its own N rank processes FIRST
+(child processes, before torch or HIP are touched in the parent) and passes rank 0's JSON line through.  --gpus must
+equal the number of ranks RCCL sees, or the run fails.  The frame is cut into 32x32 tiles dealt round-robin to the
+ranks (no data-path collective); ONE exchange of the RGBA32F radiance buffer to rank 0 closes every timed region
+(SURVEY 8e): a gather of each rank's own tiles (default) or a sum-reduce of the full frame (--exchange reduce).
+  --scaling weak   (default) the frame grows with N (1920*a x 1080*b, a*b = N): fixed work per GPU;
+  --scaling strong the frame is fixed (--width x --height; --config c4 = BASELINE configs[3]: 3840x2160 over the GPUs).
+
+The timed region (exactly K steps between barriers) is run --reps times (default 5) and the MEDIAN is reported
+(box-to-box and run-to-run spread is a few per cent).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+L1_GATHER_PEAK_GBS = 19000.0  # measured: coalesced dwordx4 loads from L1/L2, all CUs (profiles/r01/l1_pipe.json);
+                              # divergent per-lane 64-byte records reach 13 800
+
+# kernel classes of the wavefront pipeline -> kernel symbol (as rocprofv3 prints it) and the resource that bounds it
+KERNELS = {
+    "primary": ("fspt::k_wf_logic<false, true, true>", "hbm"),
+    "trace": ("fspt::k_wf_trace<false>", "l1_gather"),
+    "logic": ("fspt::k_wf_logic<false, false, true>", "hbm"),
+    "resolve": ("fspt::k_wf_resolve", "hbm"),
+}
+# the kernel the roofline block is about: the largest share of GPU time in the committed rocprofv3 kernel statistics
+# of the default workload (profiles/: kernel_stats.csv) - fixed, not re-decided per run
+ROOFLINE_CLASS = "logic"
+
+CONFIGS = {  # BASELINE.json configs[1..4]
+    "c2": {},
+    "c3": {"mesh_n": 289},
+    "c4": {"width": 3840, "height": 2160, "scaling": "strong"},
+    "c5": {"aperture": 0.1, "sun_deg": 0.5, "sun_gain": 400.0},  # DoF + a smaller, brighter sun (more bins)
+}
+
+
+def source_sha():
+    """Hash of the kernel sources: profile-derived numbers are only attached to runs of the code they were measured on."""
+    h = hashlib.sha256()
+    for f in ("fspt_kernels.hip", "fspt_device.hpp", "fspt_math.hpp", "fspt_api.cpp"):
+        h.update(open(os.path.join(ROOT, "fspt_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=15.0):
-    """The oracle (kind 'port': plain-C restatement, OpenMP over rows) timed on
-    this host's cores on a bounded, uniformly tile-sampled part of the SAME
-    frame: shard 0 of S round-robin 32x32-tile shards, S chosen from a probe."""
+    """The oracle (kind 'port': plain-C restatement, OpenMP over rows) timed on this host's cores on a bounded,
+    uniformly tile-sampled part of the SAME frame: shard 0 of S round-robin 32x32-tile shards, S chosen from a probe."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as O
@@ -54,8 +88,7 @@ def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=15.0):
     n_ticks = 1 if n_shards > 1 else max(1, min(256, int(want / (W * H))))
     t, s = run(n_shards, n_ticks)
     if t < 0.6 * budget_s and n_shards == 1:
-        # the probe (a 1/32 tile sample) under-estimates how well the full frame scales over the cores: re-run with
-        # the tick count that fills the budget
+        # the probe (a 1/32 tile sample) under-estimates how well the full frame scales over the cores
         n_ticks = max(n_ticks + 1, min(512, int(n_ticks * 0.8 * budget_s / max(t, 1e-3))))
         t, s = run(n_shards, n_ticks)
     return {"value": round(s / t / 1e6, 5), "unit": "Msamples/s", "cores": cores, "kind": "port",
@@ -63,29 +96,140 @@ def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=15.0):
                       f"{n_shards}-th 32x32 tile of the same {W}x{H} depth-{bounces} frame: {s} samples in {t:.2f} s"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=128)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--reps", type=int, default=5, help="timed regions of exactly --steps steps; the median is reported")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json configs[1..4]")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--mesh-n", type=int, default=76, help="cube-sphere resolution: 12*n^2 triangles (289 -> 1M)")
+    ap.add_argument("--mesh-n", type=int, default=None, help="cube-sphere resolution: 12*n^2 triangles (76 -> 70k, 289 -> 1M)")
     ap.add_argument("--aperture", type=float, default=None)
+    ap.add_argument("--sun-deg", type=float, default=None, help="angular radius of the environment's sun (default 1.5)")
+    ap.add_argument("--sun-gain", type=float, default=None, help="sun radiance / sky radiance scale (default 60)")
+    ap.add_argument("--textured", action="store_true", help="2048^2 image maps on the floor quads (scene/bunny.json:18-41)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "wavefront2"])
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="multi-GPU read-out: gather each rank's own tiles to rank 0 (default) or sum-reduce the full frame")
     ap.add_argument("--batch", type=int, default=128, help="ticks per wavefront batch")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / exchange plumbing only, on CPU over gloo (no GPU, no rendering)")
+    args = ap.parse_args(argv)
+    preset = CONFIGS[args.config]
+    for k, dflt in (("width", 1920), ("height", 1080), ("scaling", "weak"), ("mesh_n", 76), ("aperture", None),
+                    ("sun_deg", 1.5), ("sun_gain", 60.0)):
+        if getattr(args, k) is None:
+            setattr(args, k, preset.get(k, dflt))
+    if args.gpus < 1 or args.steps < 1 or args.reps < 1:
+        raise SystemExit("--gpus, --steps and --reps must be >= 1")
+    return args
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """--gpus N > 1 without a torchrun environment: start N rank processes (children of this one; this process has
+    not imported torch or touched HIP and never execs) and wait for them.  Rank 0 prints the JSON line."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(args.gpus),
+               FSPT_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            r = p.poll()
+            if r is None:
+                continue
+            procs.remove(p)
+            if r != 0:
+                rc = rc or r
+                if deadline is None:
+                    deadline = time.time() + 20.0  # a rank died: the others hang in the rendezvous / a collective
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()  # exactly the processes started above
+            procs = []
+        time.sleep(0.05)
+    if rc:
+        raise SystemExit(f"bench.py: a rank failed (exit code {rc}); --gpus {args.gpus} needs {args.gpus} visible GPUs")
+    return 0
+
+
+def frame_size(args, n_gpus):
+    from fspt_amd import distributed as D
+    if args.scaling == "strong":
+        return args.width, args.height
+    return D.weak_frame(n_gpus, args.width, args.height)
+
+
+def dry_run(args, rank, local_rank, world):
+    """The N-rank plumbing without a GPU: gloo rendezvous, tile ownership, one tile-gather exchange of a synthetic
+    radiance buffer whose pixel values encode their owner, and the JSON line."""
+    import numpy as np
+    import torch
+    from fspt_amd import distributed as D
+    dist = D.init_process_group(backend="gloo") if world > 1 else None
+    seen = dist.get_world_size() if dist is not None else 1
+    if seen != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {seen} ranks")
+    W, H = frame_size(args, world)
+    W, H = max(64, W // 16), max(64, H // 16)  # plumbing check: a small frame of the same tile geometry
+    acc = torch.zeros((H, W, 4), dtype=torch.float32)
+    mask = torch.from_numpy(D.owner_mask(rank, world, W, H))
+    acc[mask] = float(rank + 1)
+    t0 = time.perf_counter()
+    if args.exchange == "gather":
+        D.TileGather(rank, world, W, H, torch.device("cpu")).exchange(acc)
+    else:
+        D.reduce_radiance(acc, dst=0)
+    dt = time.perf_counter() - t0
+    ok = True
+    if rank == 0:
+        want = np.zeros((H, W), np.float32)
+        for r in range(world):
+            want[D.owner_mask(r, world, W, H)] = r + 1
+        ok = bool(np.array_equal(acc[..., 0].numpy(), want))
+        print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "world_size_seen": seen, "backend": "gloo",
+                          "scaling": args.scaling, "frame": [W, H], "exchange": args.exchange, "exchange_ok": ok,
+                          "exchange_s": round(dt, 4), "self_launched": bool(os.environ.get("FSPT_BENCH_SELF_LAUNCHED"))}),
+              flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("dry run: exchanged frame is wrong")
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ..., "
+                         f"or plain `python bench.py --gpus {args.gpus}`, which launches the ranks itself)")
     n_gpus = world
+    if args.dry_run:
+        return dry_run(args, rank, local_rank, world)
 
     import numpy as np
     import torch
@@ -94,14 +238,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libfspt has no CPU path)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     from fspt_amd import distributed as D
     dist = D.init_process_group(backend="nccl", device=torch.device("cuda", local_rank)) if n_gpus > 1 else None
+    world_seen = dist.get_world_size() if dist is not None else 1
+    if world_seen != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but RCCL sees {world_seen} ranks")
 
     t0 = time.perf_counter()
-    arrays = S.bunny_scene(n=args.mesh_n)
+    if args.textured:
+        arrays = S.bunny_scene_textured(n=args.mesh_n, sun_deg=args.sun_deg, sun_gain=args.sun_gain)
+    else:
+        arrays = S.bunny_scene(n=args.mesh_n, sun_deg=args.sun_deg, sun_gain=args.sun_gain)
     build_s = time.perf_counter() - t0
-    W, H = D.weak_frame(n_gpus, args.width, args.height)
+    W, H = frame_size(args, n_gpus)
     cam = dict(S.BUNNY_CAMERA)
     if args.aperture is not None:
         cam["aperture"] = args.aperture
@@ -115,7 +267,7 @@ def main():
     pt.bind_accumulator(accum.data_ptr(), keep=accum)
     pt.seed(1)
     exch = D.TileGather(rank, n_gpus, W, H, accum.device) if (n_gpus > 1 and args.exchange == "gather") else None
-    pt.prepare()  # path-state allocation happens here, never inside the timed region (even with --warmup 0)
+    pt.prepare()  # path-state allocation happens here, never inside a timed region (even with --warmup 0)
 
     def barrier():
         pt.sync()
@@ -128,135 +280,153 @@ def main():
     if args.warmup > 0:
         pt.render(args.warmup)
     barrier()
-    # ---- timed: exactly K steps ----
-    t_start = time.perf_counter()
-    pt.render(args.steps)
-    pt.sync()
-    # the one exchange step of the path (RCCL over xGMI): rank 0 ends up with the whole frame
-    if exch is not None:
-        exch.exchange(accum)
-    else:
-        D.reduce_radiance(accum, dst=0)
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    kernel_ms, launches = pt.last_kernel_ms()
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # ---- timed: --reps regions of exactly K steps each, every one closed by the path's one exchange step ----
+    times, kernel_ms_all, stages_all = [], [], []
+    for _ in range(args.reps):
+        barrier()
+        t_start = time.perf_counter()
+        pt.render(args.steps)
+        pt.sync()
+        if exch is not None:
+            exch.exchange(accum)  # RCCL over xGMI: rank 0 ends up with the whole frame
+        else:
+            D.reduce_radiance(accum, dst=0)
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        times.append(elapsed)
+        kernel_ms_all.append(pt.last_kernel_ms())
+        stages_all.append(pt.last_stage_ms() if args.pipeline.startswith("wavefront") else None)
+    order = sorted(range(args.reps), key=lambda i: times[i])
+    med = order[(args.reps - 1) // 2]  # the median region (lower median for an even count): its own stage timings are reported
+    elapsed = times[med]
+    kernel_ms, launches = kernel_ms_all[med]
+    stages = stages_all[med]
 
     total_samples = float(W) * H * args.steps
     value = total_samples / elapsed / 1e6
 
-    # ---- stage timing of the TIMED region (HIP events recorded on the target's stream around
-    #      every kernel launch) + algorithmic work (counting variant, outside the timed region) ----
     if rank == 0:
-        stages = pt.last_stage_ms() if args.pipeline.startswith("wavefront") else None
-        pt.enable_counters(True)
-        L = fspt_amd._lib
-        L.check(L.lib().fspt_counters_reset(pt._t))
-        pt.render(1)
-        cnt = pt.counters()
-        pt.enable_counters(False)
-        bps = fspt_amd.bytes_per_sample(cnt)
-        spt = cnt["samples"]  # samples per tick on this rank
-        per_sample = {k: round(v / max(1, spt), 4) for k, v in cnt.items() if k != "samples"}
-        if stages is not None:
-            # The same counters for the camera rays alone (depth 0: no shading, no secondary rays) split the algorithmic
-            # bytes of SURVEY 8d (60 S + 144 L + 280 H + 16 E + 64 per sample, reference layout) over the kernels:
-            #   primary launch (ray generation + camera ray traversal + its shading): 60 S0 + 144 L0 + 280 H1 + 16 E0 + 32
-            #   k_wf_trace  (rounds >= 1: extension and shadow rays)               : 60 (S - S0) + 144 (L - L0)
-            #   k_wf_logic  (rounds >= 2)                                          : 280 (H - H1) + 16 (E - E0)
-            #   k_wf_resolve (running mean)                                        : 32
-            nb_keep = pt.num_bounces
-            pt.num_bounces = 0
-            pt.enable_counters(True)
-            L.check(L.lib().fspt_counters_reset(pt._t))
-            pt.render(1)
-            c0 = pt.counters()
-            pt.enable_counters(False)
-            pt.num_bounces = nb_keep
-            h1 = (c0["samples"] - c0["env_lookups"]) if args.bounces >= 1 else 0  # camera rays that hit and get shaded
-            alg = {"primary": 60.0 * c0["steps"] + 144.0 * c0["leaves"] + 280.0 * h1 + 16.0 * c0["env_lookups"] + 32.0 * spt,
-                   "trace": 60.0 * (cnt["steps"] - c0["steps"]) + 144.0 * (cnt["leaves"] - c0["leaves"]),
-                   "logic": 280.0 * (cnt["shades"] - h1) + 16.0 * (cnt["env_lookups"] - c0["env_lookups"]),
-                   "resolve": 32.0 * spt}
-            names = {"primary": "fspt::k_wf_logic<false, true, true>", "trace": "fspt::k_wf_trace<false>",
-                     "logic": "fspt::k_wf_logic<false, false, true>", "resolve": "fspt::k_wf_resolve"}
-            kernels = {}
-            for k, (ms, n) in stages.items():
-                kernels[k] = {"kernel": names[k], "launches": n, "ms_per_step": round(ms / args.steps, 4),
-                              "avg_launch_ms": round(ms / max(1, n), 4), "alg_bytes_per_step": round(alg[k]),
-                              "achieved_GBps": round(alg[k] * args.steps / (ms / 1e3) / 1e9, 1) if ms > 0 else None}
-            # the roofline block is about the kernel class that takes the largest share of the timed region
-            dom = max(("primary", "trace", "logic"), key=lambda k: stages[k][0])
-            d_ms, d_n = stages[dom]
-            dom_bytes = alg[dom] * args.steps
-            achieved = dom_bytes / (d_ms / 1e3) / 1e9
-            avg_launch_ms = d_ms / max(1, d_n)
-            kernel = names[dom]
-            extra = {"launches": d_n, "bytes_per_launch": round(dom_bytes / max(1, d_n)), "kernels": kernels,
-                     "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stages.items()},
-                     "stage_launches": {k: v[1] for k, v in stages.items()},
-                     "pipeline_GBps": round(bps * spt * args.steps / (kernel_ms / 1e3) / 1e9, 2)}
-        else:
-            dom = None
-            avg_launch_ms = kernel_ms / max(1, launches)
-            achieved = bps * spt / (avg_launch_ms / 1e3) / 1e9
-            kernel = "fspt::k_trace<true,false>"
-            extra = {"launches": launches}
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
-                    "avg_launch_ms": round(avg_launch_ms, 4), "bytes_per_sample": round(bps, 1),
-                    "per_sample": per_sample}
-        roofline.update(extra)
-        # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (bench.py cannot run the
-        # profiler on itself): only reported for the exact workload those passes measured
-        tpath = os.path.join(ROOT, "profiles", "r01", "final_hbm_traffic.json")
-        key = {76: "c2_70k", 289: "c3_1M"}.get(args.mesh_n)
-        if (stages is not None and key and os.path.exists(tpath) and n_gpus == 1 and args.steps == args.batch == 128
-                and (args.width, args.height, args.bounces) == (1920, 1080, 8)):
-            tall = json.load(open(tpath)).get(key, {})
-            for k in kernels:
-                tj = tall.get(names[k].replace("fspt::", ""))
-                if tj:
-                    kernels[k]["hbm_traffic_per_launch"] = round(tj["hbm_bytes_per_launch_corrected"])
-            if "hbm_traffic_per_launch" in kernels[dom]:
-                roofline["traffic"] = kernels[dom]["hbm_traffic_per_launch"]
-                roofline["traffic_source"] = "profiles/r01/final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch)"
-            # what the kernels queue on besides HBM: the CU's vector-memory pipeline (TA address / TD data-return
-            # units of the L1), DESIGN.md 7
-            lpath = os.path.join(ROOT, "profiles", "r01", "l1_pipe.json")
-            if key == "c2_70k" and os.path.exists(lpath):
-                lj = json.load(open(lpath))
-                for k in kernels:
-                    kj = lj["kernels"].get(names[k].replace("fspt::", ""))
-                    if kj:
-                        kernels[k]["vmem_pipe_busy"] = {"TA": kj["TA_busy"], "TD": kj["TD_busy"]}
-                if "vmem_pipe_busy" in kernels[dom]:
-                    roofline["vmem_pipe"] = {"TA_busy": kernels[dom]["vmem_pipe_busy"]["TA"], "TD_busy": kernels[dom]["vmem_pipe_busy"]["TD"],
-                                             "l1_gather_peak_GBps": lj["l1_gather_GBps"]["divergent_64B_records"],
-                                             "source": "profiles/r01/l1_pipe.json (rocprofv3 --pmc TA_TA_BUSY / TD_TD_BUSY; tools/microbench/gather2)"}
-        out = {
-            "metric": "Msamples/s at 1920x1080 depth 8 (bunny, 70k tri)",
-            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"bunny-synthetic {arrays.n_tris} tri, {W}x{H}, depth {args.bounces}, "
-                                   f"1 spp/step, aperture {cam['aperture']}",
-                       "scene_bytes": arrays.nbytes(), "bvh_nodes": arrays.n_nodes, "bvh_depth": arrays.depth,
-                       "env_bins": int(arrays.bins.size // 4), "sharding": f"32x32 tiles round-robin over {n_gpus}", "exchange": (args.exchange if n_gpus > 1 else "none"), "pipeline": args.pipeline, "batch_ticks": args.batch,
-                       "scene_build_s": round(build_s, 2)},
-            "roofline": roofline,
-        }
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(arrays, W, H, cam, lens, args.bounces)
+        out = report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed, times, kernel_ms, launches,
+                     stages, build_s)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     pt.close()
+    return 0
+
+
+def count_work(pt, mode, bounces=None):
+    """One extra tick with the counting kernel variants (outside every timed region).  mode 1 = the reference's work
+    (shadow rays traced to the closest hit like tracer.fs:501: equals the oracle's counters), mode 2 = the work the
+    timed kernels really do (NEE shadow rays stop at the first hit)."""
+    import fspt_amd
+    L = fspt_amd._lib
+    keep = pt.num_bounces
+    if bounces is not None:
+        pt.num_bounces = bounces
+    pt.enable_counters(mode)
+    L.check(L.lib().fspt_counters_reset(pt._t))
+    pt.render(1)
+    c = pt.counters()
+    pt.enable_counters(0)
+    pt.num_bounces = keep
+    return c
+
+
+def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed, times, kernel_ms, launches, stages, build_s):
+    import fspt_amd
+    ref = count_work(pt, 1)   # reference algorithm (SURVEY 8d's S, L, H, E)
+    bps = fspt_amd.bytes_per_sample(ref)
+    spt = ref["samples"]      # samples per step on this rank
+    per_sample = {k: round(v / max(1, spt), 4) for k, v in ref.items() if k != "samples"}
+    steps = args.steps
+    sha = source_sha()
+    roofline = None
+    if stages is not None:
+        act = count_work(pt, 2)               # the timed kernels' own traversal work (any-hit shadow rays)
+        ref0 = count_work(pt, 1, bounces=0)   # camera rays alone: splits the per-sample terms over the kernels
+        h1 = (ref0["samples"] - ref0["env_lookups"]) if args.bounces >= 1 else 0  # camera rays that hit and get shaded
+        # Algorithmic bytes per step of each kernel class on the reference layout (SURVEY 8d: 60 S + 144 L + 280 H + 16 E
+        # + 64 per sample), the traversal terms counted on the TIMED variant:
+        #   primary (ray generation + camera-ray traversal + its shading): 60 S0 + 144 L0 + 280 H1 + 16 E0 + 32
+        #   trace   (rounds >= 1: extension + any-hit shadow rays)       : 60 (S' - S0) + 144 (L' - L0)
+        #   logic   (rounds >= 2)                                        : 280 (H - H1) + 16 (E - E0)
+        #   resolve (running mean)                                       : 32
+        alg = {"primary": 60.0 * ref0["steps"] + 144.0 * ref0["leaves"] + 280.0 * h1 + 16.0 * ref0["env_lookups"] + 32.0 * spt,
+               "trace": 60.0 * (act["steps"] - ref0["steps"]) + 144.0 * (act["leaves"] - ref0["leaves"]),
+               "logic": 280.0 * (ref["shades"] - h1) + 16.0 * (ref["env_lookups"] - ref0["env_lookups"]),
+               "resolve": 32.0 * spt}
+        # rocprofv3 PMC traffic of the same kernels (bytes per sample, per kernel), if it was measured on THIS code
+        prof, prof_path = None, os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        wl = f"{args.config}{'_tex' if args.textured else ''}"
+        if os.path.exists(prof_path):
+            pj = json.load(open(prof_path))
+            if pj.get("source_sha") == sha and wl in pj.get("workloads", {}):
+                prof = pj["workloads"][wl]
+        kernels = {}
+        for k, (ms, n) in stages.items():
+            name, bound = KERNELS[k]
+            peak = HBM_PEAK_GBS if bound == "hbm" else L1_GATHER_PEAK_GBS
+            gbps = alg[k] * steps / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+            kj = {"kernel": name, "launches": n, "ms_per_step": round(ms / steps, 4), "avg_launch_ms": round(ms / max(1, n), 4),
+                  "alg_bytes_per_step": round(alg[k]), "alg_GBps": round(gbps, 1), "bound": bound, "peak_GBps": peak,
+                  "traffic_bytes_per_launch": None, "traffic_GBps": None}
+            if prof and name.replace("fspt::", "") in prof["kernels"]:
+                tps = prof["kernels"][name.replace("fspt::", "")]["hbm_bytes_per_sample"]
+                tb = tps * spt * steps
+                kj["traffic_bytes_per_launch"] = round(tb / max(1, n))
+                kj["traffic_GBps"] = round(tb / (ms / 1e3) / 1e9, 1) if ms > 0 else None
+            # fraction of the bounding resource's peak: HBM kernels are priced on what they really move when the counters
+            # are available (cache-resident scene data never has to come from HBM), else on the algorithmic bytes
+            num = kj["traffic_GBps"] if (bound == "hbm" and kj["traffic_GBps"] is not None) else gbps
+            kj["frac"] = round(num / peak, 4)
+            kernels[k] = kj
+        dom = kernels[ROOFLINE_CLASS]
+        d_ms, d_n = stages[ROOFLINE_CLASS]
+        roofline = {"bound": dom["bound"], "achieved": dom["alg_GBps"], "peak": dom["peak_GBps"], "unit": "GB/s",
+                    "frac": round(dom["alg_GBps"] / dom["peak_GBps"], 5),
+                    "traffic": dom["traffic_bytes_per_launch"], "kernel": dom["kernel"], "avg_launch_ms": dom["avg_launch_ms"],
+                    "launches": d_n, "bytes_per_launch": round(alg[ROOFLINE_CLASS] * steps / max(1, d_n)),
+                    "achieved_is": "algorithmic bytes of this kernel (280 H + 16 E, reference layout) / its HIP-event time",
+                    "traffic_frac": dom["frac"] if dom["traffic_GBps"] is not None else None,
+                    "traffic_source": (f"profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; source {sha})"
+                                       if dom["traffic_bytes_per_launch"] is not None else None),
+                    "bytes_per_sample": round(bps, 1), "per_sample": per_sample,
+                    "per_sample_timed_variant": {k: round(act[k] / max(1, spt), 4) for k in ("rays", "steps", "leaves")},
+                    "kernels": kernels,
+                    "pipeline_alg_GBps": round(sum(alg.values()) * steps / (kernel_ms / 1e3) / 1e9, 1)}
+    else:
+        avg_launch_ms = kernel_ms / max(1, launches)
+        achieved = bps * spt / (avg_launch_ms / 1e3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "fspt::k_trace<true, false>",
+                    "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches, "bytes_per_sample": round(bps, 1),
+                    "per_sample": per_sample}
+    tri_k = f"{arrays.n_tris / 1e3:.0f}k" if arrays.n_tris < 1e6 else f"{arrays.n_tris / 1e6:.1f}M"
+    out = {
+        "metric": f"Msamples/s at {W}x{H} depth {args.bounces} (bunny, {tri_k} tri)",
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "reps": args.reps, "rep_ms_per_step": [round(t * 1e3 / args.steps, 4) for t in times],
+        "config": {"workload": f"{args.config}: bunny-synthetic {arrays.n_tris} tri{' + 2048^2 image maps' if args.textured else ''}, "
+                               f"{W}x{H}, depth {args.bounces}, 1 spp/step, aperture {cam['aperture']}, sun {args.sun_deg} deg x{args.sun_gain:g}",
+                   "scene_bytes": arrays.nbytes(), "bvh_nodes": arrays.n_nodes, "bvh_depth": arrays.depth,
+                   "env_bins": int(arrays.bins.size // 4), "atlas": f"{arrays.atlas_res}^2 x {arrays.atlas_layers}",
+                   "sharding": f"32x32 tiles round-robin over {n_gpus}", "world_size_seen": world_seen,
+                   "exchange": (args.exchange if n_gpus > 1 else "none"), "pipeline": args.pipeline,
+                   "batch_ticks": args.batch, "scene_build_s": round(build_s, 2), "source_sha": sha},
+        "roofline": roofline,
+    }
+    if n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(arrays, W, H, cam, lens, args.bounces)
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

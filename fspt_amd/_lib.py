@@ -108,6 +108,8 @@ SIGNATURES = {
     "fspt_target_set_pipeline": (C.c_int, [_VP, C.c_int, C.c_uint32]),
     "fspt_last_stage_ms": (C.c_int, [_VP, _F, _U32]),
     "fspt_target_prepare": (C.c_int, [_VP]),
+    "fspt_target_set_memory_limit": (C.c_int, [_VP, C.c_uint64]),
+    "fspt_target_path_state_bytes": (C.c_int, [_VP, C.POINTER(C.c_uint64), _U32]),
     "fspt_builder_create": (C.c_int, [C.POINTER(_VP)]),
     "fspt_builder_destroy": (C.c_int, [_VP]),
     "fspt_builder_add_obj": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(PropDesc)]),

@@ -75,6 +75,8 @@ struct fspt_target {
     hipEvent_t resolved = nullptr; // this lane's most recent resolve has finished
   } lanes[2];
   uint32_t n_lanes = 1; // 2 = pipeline code 2: measured +3 % at 64+ ticks, -17 % at 8 ticks (profiles/r01)
+  uint32_t ticks_seen = 0;   // largest n_ticks of any call so far: path state is sized for min(batch_ticks, ticks_seen)
+  uint64_t mem_limit = 0;    // fspt_target_set_memory_limit: cap on the path-state bytes of this target (0 = none)
   hipEvent_t ev_start = nullptr;
   // per-launch stage timing (HIP events on the target's stream)
   std::vector<hipEvent_t> ev_pool;
@@ -434,27 +436,39 @@ static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
   p.n_owned_tiles = (n_tiles > t->shard) ? (n_tiles - t->shard + t->n_shards - 1) / t->n_shards : 0;
 }
 
-static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots) {
-  if (ln.slots >= slots && ln.counts) return FSPT_OK;
-  HIP_TRY(hipStreamSynchronize(ln.stream));
-  for (void *&m : ln.mem) { if (m) { HIP_TRY(hipFree(m)); m = nullptr; } }
-  // ray_o ray_d thr col shd pend (float4) | hit (float2) | shadow_hit (int) | q_ext[2] q_shd[2] (u32) | fin (float4)
-  const size_t sz[13] = {16, 16, 16, 16, 16, 16, 8, 4, 4, 4, 4, 4, 16};
+// bytes per path slot of every path-state array (fspt_device.hpp: WfP)
+// ray_o ray_d thr col shd pend (float4) | hit (float2) | shadow_hit (int) | q_ext[2] q_shd[2] (u32) | fin (float4)
+static const size_t WF_ARRAY_BYTES[13] = {16, 16, 16, 16, 16, 16, 8, 4, 4, 4, 4, 4, 16};
+static size_t wf_slot_bytes() {
+  size_t b = 0;
+  for (size_t x : WF_ARRAY_BYTES) b += x;
+  return b;
+}
+
+static void wf_release(fspt_target::WfLane &ln) {
+  if (ln.stream) hipStreamSynchronize(ln.stream);
+  for (void *&m : ln.mem) { if (m) { hipFree(m); m = nullptr; } }
   ln.slots = 0;
-  // test hook: pretend allocations above this many slots run out of memory (exercises the batch-halving retry)
-  const char *lim = getenv("FSPT_WF_ALLOC_LIMIT_SLOTS");
-  const uint64_t limit = lim ? strtoull(lim, nullptr, 10) : ~0ull;
+}
+
+// Path state of one lane for `slots` path slots.  `budget_slots` = what fspt_target_set_memory_limit leaves this lane;
+// exceeding it is reported exactly like the device running out of memory (FSPT_E_NOMEM: the caller shrinks the batch).
+static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots, uint64_t budget_slots) {
+  (void)t;
+  if (ln.slots >= slots && ln.counts) return FSPT_OK;
+  wf_release(ln);
   for (int i = 0; i < 13; ++i) {
-    hipError_t e = slots > limit ? hipErrorOutOfMemory : hipMalloc(&ln.mem[i], (size_t)slots * sz[i]);
+    hipError_t e = slots > budget_slots ? hipErrorOutOfMemory : hipMalloc(&ln.mem[i], (size_t)slots * WF_ARRAY_BYTES[i]);
     if (e == hipErrorOutOfMemory) {
-      // not enough free HBM for this batch size: give everything back, the caller retries with half the batch
+      // not enough free HBM (or over the target's memory limit) for this batch size: give everything back
       (void)hipGetLastError();
-      for (void *&m : ln.mem) { if (m) { hipFree(m); m = nullptr; } }
-      fspt_set_error("path state for %u slots does not fit the free device memory", slots);
+      wf_release(ln);
+      fspt_set_error("path state for %u slots (%zu bytes) does not fit %s", slots, (size_t)slots * wf_slot_bytes(),
+                     slots > budget_slots ? "the target's memory limit" : "the free device memory");
       return FSPT_E_NOMEM;
     }
     HIP_TRY(e);
-    HIP_TRY(hipMemsetAsync(ln.mem[i], 0, (size_t)slots * sz[i], ln.stream)); // touch every page once, now
+    HIP_TRY(hipMemsetAsync(ln.mem[i], 0, (size_t)slots * WF_ARRAY_BYTES[i], ln.stream)); // touch every page once, now
   }
   if (!ln.counts) HIP_TRY(hipMalloc((void **)&ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2)));
   HIP_TRY(hipStreamSynchronize(ln.stream));
@@ -462,35 +476,44 @@ static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots) {
   return FSPT_OK;
 }
 
-static void wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &lanes, uint32_t &per_lane);
-
-// Plan the batch and make sure every lane's path state is allocated; when the device is short of memory the
-// configured batch is halved until it fits (results do not depend on the batch size).
-static int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &n_lanes, uint32_t &per_lane) {
-  while (true) {
-    wf_plan(t, work_total, n_ticks, n_lanes, per_lane);
-    if ((uint64_t)per_lane * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
-    int rc = FSPT_OK;
-    for (uint32_t l = 0; l < n_lanes && rc == FSPT_OK; ++l) rc = wf_ensure(t, t->lanes[l], (uint32_t)(per_lane * work_total));
-    if (rc != FSPT_E_NOMEM) return rc;
-    if (per_lane <= 1) return rc;
-    t->batch_ticks = per_lane * n_lanes / 2;
-    if (t->batch_ticks < 1) t->batch_ticks = 1;
-  }
-}
-
-// ticks per lane and number of lanes for a call of n_ticks (0 = the configured steady state)
-static void wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &lanes, uint32_t &per_lane) {
+// ticks per lane and number of lanes for a call of n_ticks (0 = the configured steady state, fspt_target_prepare).
+// Path state is sized for the largest call seen so far, not for the configured batch: a host that only ever calls
+// fspt_trace (one tick at a time, like main.js:842-843) holds one tick of path state, not 128.
+static void wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t n_lanes_max, uint32_t &lanes,
+                    uint32_t &per_lane) {
   // the configured batch is the number of ticks in flight over all lanes (each lane at most WF_MAX_BATCH)
   uint32_t batch = t->batch_ticks;
+  if (n_ticks) {
+    uint32_t want = n_ticks > t->ticks_seen ? n_ticks : t->ticks_seen;
+    if (batch > want) batch = want;
+  }
   uint64_t fit = WF_SLOT_BUDGET / work_total;
   if (fit < 1) fit = 1;
   if (batch > fit) batch = (uint32_t)fit;
   if (batch < 1) batch = 1;
-  lanes = (t->n_lanes >= 2 && batch >= 2) ? 2u : 1u;
+  lanes = (n_lanes_max >= 2 && batch >= 2) ? 2u : 1u;
   per_lane = batch / lanes;
   if (per_lane > (uint32_t)fspt::WF_MAX_BATCH) per_lane = fspt::WF_MAX_BATCH;
-  (void)n_ticks;
+}
+
+// Plan the batch and make sure every lane's path state is allocated.  When the device is short of memory (or the
+// target's memory limit is lower) ALL lanes are released and the batch is halved until it fits; a two-lane target
+// falls back to one lane before giving up (results do not depend on the batch size or the lane count).
+static int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &n_lanes, uint32_t &per_lane) {
+  if (n_ticks > t->ticks_seen) t->ticks_seen = n_ticks;
+  uint32_t lanes_max = t->n_lanes;
+  while (true) {
+    wf_plan(t, work_total, n_ticks, lanes_max, n_lanes, per_lane);
+    if ((uint64_t)per_lane * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
+    const uint64_t budget = t->mem_limit ? t->mem_limit / wf_slot_bytes() / n_lanes : ~0ull;
+    int rc = FSPT_OK;
+    for (uint32_t l = 0; l < n_lanes && rc == FSPT_OK; ++l) rc = wf_ensure(t, t->lanes[l], (uint32_t)(per_lane * work_total), budget);
+    if (rc != FSPT_E_NOMEM) return rc;
+    for (auto &ln : t->lanes) wf_release(ln); // a lane that did fit must not keep memory the smaller retry needs
+    if (per_lane * n_lanes <= 1) return rc;   // one tick on one lane does not fit: give up (message set by wf_ensure)
+    if (per_lane <= 1) { lanes_max = 1; continue; }
+    t->batch_ticks = per_lane * n_lanes / 2;
+  }
 }
 
 static int ev_begin(fspt_target *t, int kind, hipStream_t stream) {
@@ -601,10 +624,16 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
   return FSPT_OK;
 }
 
+// Every path ends after MAX_PATH_ITERS loop iterations (the cap on tracer.fs:488's `i--`), and `i` never exceeds the
+// iteration count: a larger NUM_BOUNCES cannot change any sample.  Clamping keeps the per-round tables
+// (WfCounts[WF_ROUNDS_MAX + 2], the 8-bit bounce field of the path flags) in range for any caller value.
+static uint32_t clamp_bounces(uint32_t nb) { return nb > (uint32_t)FSPT_MAX_BOUNCES ? (uint32_t)FSPT_MAX_BOUNCES : nb; }
+
 int fspt_trace(fspt_target *t, uint32_t tick, float rand_base, float env_theta, uint32_t num_bounces) {
   if (!t) { fspt_set_error("fspt_trace: NULL target"); return FSPT_E_INVALID; }
   if (!t->rays_valid) { fspt_set_error("fspt_trace: call fspt_camera or fspt_set_rays first"); return FSPT_E_STATE; }
   HIP_TRY(hipSetDevice(t->scene->device));
+  num_bounces = clamp_bounces(num_bounces);
   if (t->pipeline == 1) {
     fspt_camera_params cp{};
     cp.env_theta = env_theta; cp.num_bounces = num_bounces;
@@ -644,10 +673,13 @@ int fspt_trace_test(fspt_target *t, uint32_t tick) {
   return FSPT_OK;
 }
 
-int fspt_render(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks, uint64_t seed) {
-  if (!t || !cam) { fspt_set_error("fspt_render: NULL argument"); return FSPT_E_INVALID; }
+int fspt_render(fspt_target *t, const fspt_camera_params *cam_in, uint32_t first_tick, uint32_t n_ticks, uint64_t seed) {
+  if (!t || !cam_in) { fspt_set_error("fspt_render: NULL argument"); return FSPT_E_INVALID; }
   if (n_ticks == 0) return FSPT_OK;
   HIP_TRY(hipSetDevice(t->scene->device));
+  fspt_camera_params cam_c = *cam_in;
+  cam_c.num_bounces = clamp_bounces(cam_c.num_bounces);
+  const fspt_camera_params *cam = &cam_c;
   t->ev_used = 0; t->ev_overflow = false;
   if (t->pipeline == 1) {
     std::vector<float> rbc(n_ticks), rbt(n_ticks);
@@ -756,6 +788,21 @@ int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks)
   t->pipeline = pipeline == 2 ? 1 : pipeline;
   t->n_lanes = pipeline == 2 ? 2u : 1u;
   if (batch_ticks) t->batch_ticks = batch_ticks;
+  return FSPT_OK;
+}
+
+int fspt_target_set_memory_limit(fspt_target *t, uint64_t bytes) {
+  if (!t) { fspt_set_error("fspt_target_set_memory_limit: NULL target"); return FSPT_E_INVALID; }
+  t->mem_limit = bytes;
+  return FSPT_OK;
+}
+
+int fspt_target_path_state_bytes(fspt_target *t, uint64_t *bytes, uint32_t *batch_ticks) {
+  if (!t || !bytes) { fspt_set_error("fspt_target_path_state_bytes: NULL argument"); return FSPT_E_INVALID; }
+  uint64_t b = 0;
+  for (auto &ln : t->lanes) b += (uint64_t)ln.slots * wf_slot_bytes();
+  *bytes = b;
+  if (batch_ticks) *batch_ticks = t->batch_ticks;
   return FSPT_OK;
 }
 

@@ -18,6 +18,7 @@
  *   readRadiance(target, Float32Array(W*H*4))                        (what draw.fs:87 reads)
  *   draw(target, exposure, saturation, denoise, maxSigma, Uint8Array(W*H*4))   (drawQuad, main.js:809-824)
  *   setShard(target, shard, nShards, tile) / setPipeline(target, pipeline, batch)
+ *   setMemoryLimit(target, bytes) / pathStateBytes(target) -> {bytes, batchTicks} / prepare(target)
  *   enableCounters(target, on) / counters(target) -> object
  *   builderCreate / builderParseObj / builderCommit / builderNormalize / builderBuild / builderAutofocus /
  *   builderDestroy                                                   (native obj_loader.js + bvh.js, 1:1 fspt_builder_*)
@@ -99,6 +100,18 @@ static int prop_f64(napi_env env, napi_value obj, const char *name, double dflt,
   napi_typeof(env, v, &vt);
   if (vt == napi_undefined || vt == napi_null) { *out = dflt; return 0; }
   return get_f64(env, v, out);
+}
+/* NUM_BOUNCES from JS: a finite integer in [0, FSPT_MAX_BOUNCES].  A plain uint32 conversion would turn -1 into
+ * 4294967295 and 2.5 into 2 silently; anything outside the range is a caller bug, reported as a RangeError. */
+static int get_bounces(napi_env env, napi_value v, uint32_t *out) {
+  double d;
+  if (get_f64(env, v, &d)) return -1;
+  if (!(d >= 0.0 && d <= (double)FSPT_MAX_BOUNCES) || d != (double)(uint32_t)d) {
+    napi_throw_range_error(env, NULL, "fspt_napi: numBounces must be an integer in [0, 64]");
+    return -1;
+  }
+  *out = (uint32_t)d;
+  return 0;
 }
 static int float_list(napi_env env, napi_value arr, float *out, uint32_t n) {
   for (uint32_t i = 0; i < n; ++i) {
@@ -208,16 +221,17 @@ static napi_value TraceTest(napi_env env, napi_callback_info info) {
 }
 static napi_value Trace(napi_env env, napi_callback_info info) {
   napi_value a[5]; void *h; uint32_t tick, nb; double rb, theta;
-  if (get_args(env, info, 5, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 5, a)) return NULL;
+  /* scalars first: a bad numBounces is reported as such even when the handle is bad too */
+  if (get_f64(env, a[2], &rb) || get_f64(env, a[3], &theta) || get_bounces(env, a[4], &nb)) return NULL;
+  if (unwrap(env, a[0], &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &tick));
-  if (get_f64(env, a[2], &rb) || get_f64(env, a[3], &theta)) return NULL;
-  NAPI_OK(napi_get_value_uint32(env, a[4], &nb));
   FSPT_OK_OR_THROW(fspt_trace((fspt_target *)h, tick, (float)rb, (float)theta, nb));
   return undefined(env);
 }
 static napi_value Render(napi_env env, napi_callback_info info) {
   napi_value a[5], v; void *h; uint32_t first, n; double seed, d;
-  if (get_args(env, info, 5, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 5, a)) return NULL;
   fspt_camera_params cp;
   memset(&cp, 0, sizeof(cp));
   if (prop(env, a[1], "P", &v) || float_list(env, v, cp.P, 3)) return NULL;
@@ -225,7 +239,13 @@ static napi_value Render(napi_env env, napi_callback_info info) {
   if (prop(env, a[1], "lens", &v) || float_list(env, v, cp.lens, 2)) return NULL;
   if (prop_f64(env, a[1], "fovScale", 0.5, &d)) return NULL; cp.fov_scale = (float)d;
   if (prop_f64(env, a[1], "envTheta", 0.0, &d)) return NULL; cp.env_theta = (float)d;
-  if (prop_f64(env, a[1], "numBounces", 4.0, &d)) return NULL; cp.num_bounces = (uint32_t)d;
+  {
+    napi_value nbv; napi_valuetype nbt = napi_undefined;
+    cp.num_bounces = 4; /* tracer.fs:9 */
+    if (napi_get_named_property(env, a[1], "numBounces", &nbv) == napi_ok) napi_typeof(env, nbv, &nbt);
+    if (nbt != napi_undefined && nbt != napi_null && get_bounces(env, nbv, &cp.num_bounces)) return NULL;
+  }
+  if (unwrap(env, a[0], &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[2], &first));
   NAPI_OK(napi_get_value_uint32(env, a[3], &n));
   /* seed: BigInt (full 64-bit xorshift state) or a number < 2^53 */
@@ -299,6 +319,30 @@ static napi_value SetPipeline(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_get_value_int32(env, a[1], &p));
   NAPI_OK(napi_get_value_uint32(env, a[2], &b));
   FSPT_OK_OR_THROW(fspt_target_set_pipeline((fspt_target *)h, p, b));
+  return undefined(env);
+}
+static napi_value SetMemoryLimit(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h; double bytes;
+  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h) || get_f64(env, a[1], &bytes)) return NULL;
+  if (!(bytes >= 0.0 && bytes < 1.8e19)) { napi_throw_range_error(env, NULL, "fspt_napi: memory limit must be >= 0 bytes"); return NULL; }
+  FSPT_OK_OR_THROW(fspt_target_set_memory_limit((fspt_target *)h, (uint64_t)bytes));
+  return undefined(env);
+}
+static napi_value PathStateBytes(napi_env env, napi_callback_info info) {
+  napi_value a[1], o, v; void *h; uint64_t bytes = 0; uint32_t batch = 0;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  FSPT_OK_OR_THROW(fspt_target_path_state_bytes((fspt_target *)h, &bytes, &batch));
+  NAPI_OK(napi_create_object(env, &o));
+  NAPI_OK(napi_create_double(env, (double)bytes, &v));
+  NAPI_OK(napi_set_named_property(env, o, "bytes", v));
+  NAPI_OK(napi_create_uint32(env, batch, &v));
+  NAPI_OK(napi_set_named_property(env, o, "batchTicks", v));
+  return o;
+}
+static napi_value Prepare(napi_env env, napi_callback_info info) {
+  napi_value a[1]; void *h;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  FSPT_OK_OR_THROW(fspt_target_prepare((fspt_target *)h));
   return undefined(env);
 }
 static napi_value EnableCounters(napi_env env, napi_callback_info info) {
@@ -573,6 +617,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"traceTest", TraceTest}, {"render", Render}, {"clear", Clear},
       {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline},
+      {"setMemoryLimit", SetMemoryLimit}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare},
       {"enableCounters", EnableCounters}, {"counters", GetCounters}, {"builderCreate", BuilderCreate}, {"builderDestroy", BuilderDestroy},
       {"builderParseObj", BuilderParseObj}, {"builderCommit", BuilderCommit}, {"builderNormalize", BuilderNormalize},
       {"builderBuild", BuilderBuild}, {"builderAutofocus", BuilderAutofocus}, {"envBins", EnvBins},

@@ -320,6 +320,10 @@ class PathTracer {
   setViewport(w, h) { addon.setViewport(this._target, w || 0, h || 0); }
   setShard(shard, nShards, tile) { addon.setShard(this._target, shard, nShards, tile || 32); }
   setPipeline(name, batch) { addon.setPipeline(this._target, name === 'megakernel' ? 0 : (name === 'wavefront2' ? 2 : 1), batch || 0); }
+  /** cap / query the wavefront path state (include/fspt.h: fspt_target_set_memory_limit) and pre-allocate it */
+  setMemoryLimit(bytes) { addon.setMemoryLimit(this._target, bytes || 0); }
+  pathStateBytes() { return addon.pathStateBytes(this._target); }
+  prepare() { addon.prepare(this._target); }
   enableCounters(on) { addon.enableCounters(this._target, !!on); }
   counters() { return addon.counters(this._target); }
   close() { if (this._target) { addon.targetDestroy(this._target); addon.sceneDestroy(this._scene); this._target = null; } }

@@ -116,13 +116,25 @@ class PathTracer:
         """Allocate the pipeline's path-state buffers now (not lazily inside the first render)."""
         L.check(L.lib().fspt_target_prepare(self._t))
 
+    def set_memory_limit(self, nbytes):
+        """Cap the wavefront path state of this target (bytes, 0 = none); a batch that does not fit is halved."""
+        L.check(L.lib().fspt_target_set_memory_limit(self._t, int(nbytes)))
+
+    def path_state_bytes(self):
+        """(bytes of path state currently allocated, batch size in use)."""
+        b = C.c_uint64(); n = C.c_uint32()
+        L.check(L.lib().fspt_target_path_state_bytes(self._t, C.byref(b), C.byref(n)))
+        return b.value, n.value
+
     def last_stage_ms(self):
         ms = (C.c_float * 4)(); n = (C.c_uint32 * 4)()
         L.check(L.lib().fspt_last_stage_ms(self._t, ms, n))
         return {k: (ms[i], n[i]) for i, k in enumerate(("primary", "trace", "logic", "resolve"))}
 
     def enable_counters(self, on=True):
-        L.check(L.lib().fspt_enable_counters(self._t, 1 if on else 0))
+        """0 / False: off.  1 / True: count the reference algorithm's work (equals the oracle's counters).
+        2: count what the production kernels really do (NEE shadow rays stop at the first hit)."""
+        L.check(L.lib().fspt_enable_counters(self._t, int(on)))
 
     # ---- the reference's draw calls ------------------------------------------
     def drawCamera(self, randBase):

@@ -133,6 +133,10 @@ int fspt_read_rays(fspt_target *target, float *pos, float *dir);
  * run-time argument (reference value 4).                                     */
 int fspt_trace(fspt_target *target, uint32_t tick, float rand_base,
                float env_theta, uint32_t num_bounces);
+/* The refraction branch does not advance the bounce counter (tracer.fs:488 `i--`), so the reference's loop is
+ * unbounded; libfspt ends every path after FSPT_MAX_BOUNCES loop iterations.  A num_bounces above
+ * that therefore cannot change any sample: fspt_trace / fspt_render treat it as FSPT_MAX_BOUNCES. */
+#define FSPT_MAX_BOUNCES 64
 
 /* drawTracer in the reference's `mode=test` (main.js:879-883 swaps tracer.fs for bvh_test.fs): every
  * pixel's camera ray is traced once and the number of traversal-loop iterations x 0.001 is folded into
@@ -173,8 +177,16 @@ int fspt_target_set_viewport(fspt_target *target, uint32_t w, uint32_t h);
  *   pipeline 2 "wavefront, two lanes": pipeline 1 with the batch split in two halves that run
  *              concurrently on two HIP streams (separate path state, resolves chained in tick order). */
 int fspt_target_set_pipeline(fspt_target *target, int pipeline, uint32_t batch_ticks);
+/* Wavefront path state lives in device memory: 140 bytes per (pixel, tick) of a batch.  It is sized for the largest
+ * n_ticks any call on this target has asked for so far (at most batch_ticks; fspt_trace = 1 tick = 0.29 GB at
+ * 1920x1080, a 128-tick fspt_render = 37 GB) and grows when a longer call arrives.  fspt_target_set_memory_limit caps
+ * it (bytes; 0 = no cap): a batch that does not fit the cap - or the free device memory - is halved until it does,
+ * which only costs speed (results do not depend on the batch size).  FSPT_E_NOMEM when even one tick does not fit. */
+int fspt_target_set_memory_limit(fspt_target *target, uint64_t bytes);
+/* Path-state bytes currently allocated by this target and the batch size in use (after any halving). */
+int fspt_target_path_state_bytes(fspt_target *target, uint64_t *bytes, uint32_t *batch_ticks);
 /* Allocate (and touch) the pipeline's path-state buffers for the current resolution / shard / batch now,
- * instead of lazily inside the first fspt_trace / fspt_render.  Blocking. */
+ * (sized for the full configured batch_ticks) instead of lazily inside the first fspt_trace / fspt_render.  Blocking. */
 int fspt_target_prepare(fspt_target *target);
 /* Per-kernel-class timing of the most recent fspt_trace / fspt_render (wavefront pipeline):
  * summed HIP-event durations and launch counts for {primary, trace, logic, resolve}: primary = the first launch of

@@ -31,6 +31,17 @@ if (mode === 'exports') {
   const s = F.loadBlob(job.blob_in);
   F.saveBlob(job.blob_out, s);
   out.n_tris = s.tri.length / 9; out.leafSize = s.leafSize; out.atlasLayers = s.atlasLayers;
+} else if (mode === 'bounces_range') {
+  // NUM_BOUNCES outside [0, 64] or not an integer: RangeError at the N-API boundary, before any device call
+  out.errors = {};
+  const cam = { P: [0, 0, 0], I: [0, 0, -1], lens: [0.5, 0.02] };
+  for (const nb of job.values) {
+    const v = nb === 'nan' ? NaN : nb;
+    for (const [name, fn] of [['trace', () => F.addon.trace(null, 0, 0, 0, v)],
+                              ['render', () => F.addon.render(null, Object.assign({ numBounces: v }, cam), 0, 1, 1)]]) {
+      try { fn(); out.errors[name + ':' + nb] = 'no error'; } catch (e) { out.errors[name + ':' + nb] = e.name + ': ' + e.message; }
+    }
+  }
 } else if (mode === 'nogpu') {
   const s = F.buildScene(job.props, job.objs, env, 4);
   try { new F.PathTracer(s, 16, 16, 0); out.error = null; } catch (e) { out.error = String(e.message); }

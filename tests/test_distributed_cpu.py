@@ -80,3 +80,49 @@ def test_weak_frame_keeps_per_gpu_pixels():
     for n in (1, 2, 4, 8):
         w, h = D.weak_frame(n, 1920, 1080)
         assert w * h == n * 1920 * 1080
+
+
+def _run_bench(argv, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, [json.loads(l) for l in lines]
+
+
+@pytest.mark.parametrize("exchange", ["gather", "reduce"])
+def test_bench_self_launches_n_ranks(exchange):
+    """`python bench.py --gpus 2` (no torchrun) used to run ONE rank and print n_gpus 1.  It now starts
+    its own 2 rank processes; --dry-run exercises exactly that launcher, the rendezvous and the read-out exchange on
+    CPU over gloo (no rendering).  One JSON line, n_gpus == the ranks the process group saw."""
+    p, out = _run_bench(["--gpus", "2", "--dry-run", "--exchange", exchange, "--config", "c4"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(out) == 1
+    j = out[0]
+    assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["self_launched"] and j["exchange_ok"]
+    assert j["scaling"] == "strong" and j["frame"] == [3840 // 16, 2160 // 16]  # C4: the frame does not grow with N
+
+
+def test_bench_under_torchrun_and_rank_mismatch():
+    """The driver's form (python -m torch.distributed.run ... bench.py --gpus N): bench.py is one rank and does not
+    launch anything; a --gpus that disagrees with the world size fails loudly instead of running fewer GPUs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    import json
+    out = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(out) == 1 and out[0]["n_gpus"] == 2 and out[0]["world_size_seen"] == 2 and not out[0]["self_launched"]
+    assert out[0]["scaling"] == "weak" and out[0]["frame"] == [2 * 1920 // 16, 1080 // 16]
+    # WORLD_SIZE says 2 ranks, --gpus says 4
+    p, out = _run_bench(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in p.stderr and not out

@@ -82,6 +82,17 @@ def test_js_full_scene_build_matches_reference_js():
     assert (got != nat.atlas).mean() < 1e-3
 
 
+def test_js_num_bounces_is_range_checked():
+    """a JS double went straight into uint32 (-1 -> 4294967295).  Now: integers in [0, 64] only."""
+    out = run_node("bounces_range", {"values": [-1, 65, 2.5, "nan", 10 ** 10, 64, 0]})
+    for nb in (-1, 65, 2.5, "nan", 10 ** 10):
+        for fn in ("trace", "render"):
+            assert out["errors"][f"{fn}:{nb}"].startswith("RangeError"), (fn, nb, out["errors"])
+    for nb in (64, 0):  # in range: the next check (the null handle) is what fails
+        for fn in ("trace", "render"):
+            assert out["errors"][f"{fn}:{nb}"].startswith("TypeError"), (fn, nb, out["errors"])
+
+
 def test_js_host_fails_loudly_without_gpu():
     from fspt_amd import _lib as L
     if L.lib().fspt_device_count() > 0:

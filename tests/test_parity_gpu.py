@@ -185,6 +185,27 @@ def test_refractive_scene_bitwise(pipeline):
         assert pt.last_stage_ms()["logic"][1] > 4
 
 
+@pytest.mark.parametrize("pipeline", PIPELINES)
+@pytest.mark.parametrize("bounces", [64, 100, 0xFFFFFFFF])
+def test_num_bounces_beyond_the_iteration_cap(small_scene, camera, pipeline, bounces):
+    """num_bounces was never validated; >= 69 indexed the per-round tables out of range and 0xFFFFFFFF
+    (JS -1) wrapped the round loop.  Every path ends after 64 loop iterations, so any larger count is the same render
+    as 64 (include/fspt.h: FSPT_MAX_BOUNCES) - through both entry points, on both pipelines."""
+    W, H = 64, 40
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"],
+             min(bounces, 100), 0, 2, 5, want)
+    pt = make_pt(small_scene, W, H, camera, bounces, pipeline)
+    pt.seed(5)
+    pt.render(2)
+    assert np.array_equal(pt.readRadiance(), want)
+    pt.clear()
+    pt.seed(5)
+    pt.tick(); pt.tick()  # fspt_camera + fspt_trace
+    assert np.array_equal(pt.readRadiance(), want)
+    pt.close()
+
+
 def test_stage_timing(small_scene, camera):
     pt = make_pt(small_scene, 64, 48, camera, 4, "wavefront", 2)
     pt.render(4)
@@ -641,24 +662,43 @@ def test_fuzz_random_scenes_bitwise(seed):
         pt.close()
 
 
-def test_batch_is_halved_when_path_state_does_not_fit(small_scene, camera, monkeypatch):
-    """Out of device memory for the configured batch (simulated through the allocation hook): the wavefront
-    pipeline halves its batch until the path state fits; the result does not depend on the batch size."""
+def test_batch_is_halved_when_path_state_does_not_fit(small_scene, camera):
+    """Path state over the target's memory limit is handled exactly like running out of device memory: every lane
+    is released and the batch halved until it fits (two lanes fall back to one); the result does not depend on the
+    batch size.  Also: path state is sized for the calls actually made (a one-tick call holds one tick of state)."""
     W, H = 96, 64
     want = np.zeros((H, W, 4), np.float32)
     O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
              0, 9, 31, want)
     work_total = 3 * 2 * 1024  # 32x32 tiles covering 96x64
-    monkeypatch.setenv("FSPT_WF_ALLOC_LIMIT_SLOTS", str(3 * work_total))
     pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
-    pt.prepare()
+    slot = None
+    pt.render(1)
+    nbytes, batch = pt.path_state_bytes()
+    assert batch == 128 and nbytes % work_total == 0  # lazily sized: ONE tick of path state, not 128
+    slot = nbytes // work_total
+    assert 64 <= slot <= 256
+    pt.close()
+    for pipeline, n_primary in (("wavefront", 5), ("wavefront2", 9)):
+        pt = make_pt(small_scene, W, H, camera, 4, pipeline, 128)
+        pt.set_memory_limit(3 * work_total * slot)  # room for 3 ticks: 128 -> 64 -> ... -> 2 fit (two lanes: 1 + 1)
+        pt.prepare()
+        assert pt.path_state_bytes() == (2 * work_total * slot, 2)
+        pt.seed(31)
+        pt.render(9)
+        assert np.array_equal(pt.readRadiance(), want), pipeline
+        assert pt.last_stage_ms()["primary"][1] == n_primary  # 9 ticks in batches of 2 / of 1 per lane
+        pt.close()
+    # two lanes, room for one tick only: falls back to a single lane of one tick
+    pt = make_pt(small_scene, W, H, camera, 4, "wavefront2", 128)
+    pt.set_memory_limit(work_total * slot + slot // 2)
     pt.seed(31)
     pt.render(9)
     assert np.array_equal(pt.readRadiance(), want)
-    st = pt.last_stage_ms()
-    assert st["primary"][1] == 5  # 9 ticks in batches of 2 (128 -> 64 -> ... -> 2 slots-per-pixel fit the limit)
-    monkeypatch.setenv("FSPT_WF_ALLOC_LIMIT_SLOTS", "10")
+    assert pt.path_state_bytes() == (work_total * slot, 1)
+    pt.close()
     pt2 = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
+    pt2.set_memory_limit(10 * slot)
     with pytest.raises(L.FsptError) as ei:
         pt2.render(1)
     assert ei.value.code == -4
