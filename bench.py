@@ -37,10 +37,11 @@ L1_GATHER_PEAK_GBS = 19000.0  # measured: coalesced dwordx4 loads from L1/L2, al
 
 # kernel classes of the wavefront pipeline -> kernel symbol (as rocprofv3 prints it) and the resource that bounds it
 KERNELS = {
-    "primary": ("fspt::k_wf_logic<false, true, true>", "hbm"),
-    "trace": ("fspt::k_wf_trace<false>", "l1_gather"),
-    "logic": ("fspt::k_wf_logic<false, false, true>", "hbm"),
+    "primary": ("fspt::k_wf_primary<false, true>", "hbm"),
+    "trace": ("fspt::k_wf_trace<false, true>", "l1_gather"),
+    "logic": ("fspt::k_wf_logic<false, true>", "hbm"),
     "resolve": ("fspt::k_wf_resolve", "hbm"),
+    "tail": ("fspt::k_wf_tail<false, true>", "l1_gather"),
 }
 # the kernel the roofline block is about: the largest share of GPU time in the committed rocprofv3 kernel statistics
 # of the default workload (profiles/: kernel_stats.csv) - fixed, not re-decided per run
@@ -360,7 +361,7 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
         alg = {"primary": 60.0 * ref0["steps"] + 144.0 * ref0["leaves"] + 280.0 * h1 + 16.0 * ref0["env_lookups"] + 32.0 * spt,
                "trace": 60.0 * (act["steps"] - ref0["steps"]) + 144.0 * (act["leaves"] - ref0["leaves"]),
                "logic": 280.0 * (ref["shades"] - h1) + 16.0 * (ref["env_lookups"] - ref0["env_lookups"]),
-               "resolve": 32.0 * spt}
+               "resolve": 32.0 * spt, "tail": 0.0}  # tail: its share of the trace / logic terms is not separated
         # rocprofv3 PMC traffic of the same kernels (bytes per sample, per kernel), if it was measured on THIS code
         prof, prof_path = None, os.path.join(ROOT, "profiles", "hbm_traffic.json")
         wl = f"{args.config}{'_tex' if args.textured else ''}"

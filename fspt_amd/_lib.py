@@ -108,8 +108,20 @@ SIGNATURES = {
     "fspt_target_set_pipeline": (C.c_int, [_VP, C.c_int, C.c_uint32]),
     "fspt_last_stage_ms": (C.c_int, [_VP, _F, _U32]),
     "fspt_target_prepare": (C.c_int, [_VP]),
+    "fspt_target_set_tail": (C.c_int, [_VP, C.c_int]),
     "fspt_target_set_memory_limit": (C.c_int, [_VP, C.c_uint64]),
     "fspt_target_path_state_bytes": (C.c_int, [_VP, C.POINTER(C.c_uint64), _U32]),
+    "fspt_multi_create": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
+    "fspt_multi_destroy": (C.c_int, [_VP]),
+    "fspt_multi_target": (C.c_int, [_VP, C.c_uint32, C.POINTER(_VP)]),
+    "fspt_multi_camera": (C.c_int, [_VP, _F, _F, C.c_float, _F, C.c_float]),
+    "fspt_multi_trace": (C.c_int, [_VP, C.c_uint32, C.c_float, C.c_float, C.c_uint32]),
+    "fspt_multi_render": (C.c_int, [_VP, C.POINTER(CameraParams), C.c_uint32, C.c_uint32, C.c_uint64]),
+    "fspt_multi_clear": (C.c_int, [_VP]),
+    "fspt_multi_sync": (C.c_int, [_VP]),
+    "fspt_multi_read_radiance": (C.c_int, [_VP, _F]),
+    "fspt_multi_draw": (C.c_int, [_VP, C.c_float, C.c_float, C.c_int, C.c_float, C.POINTER(C.c_uint8)]),
+    "fspt_multi_last_gather_bytes": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "fspt_builder_create": (C.c_int, [C.POINTER(_VP)]),
     "fspt_builder_destroy": (C.c_int, [_VP]),
     "fspt_builder_add_obj": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(PropDesc)]),

@@ -44,6 +44,7 @@ struct fspt_scene {
   bool has_dielectric = false; // some triangle can refract (tracer.fs:481-488: unbounded path length)
 };
 
+static const int WF_ARRAYS = 15;
 struct fspt_target {
   fspt_scene *scene = nullptr;
   uint32_t W = 0, H = 0;
@@ -54,7 +55,7 @@ struct fspt_target {
   uint32_t *work_counters = nullptr; // ring of zeroed work counters, one per launch
   uint32_t n_work_counters = 0;
   unsigned long long *counters = nullptr; // 6 x u64 on device
-  bool count = false;
+  int count = 0; // fspt_enable_counters: 0 off, 1 the reference's work, 2 the production kernels' work
   uint32_t shard = 0, n_shards = 1, tile = 32;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -68,13 +69,20 @@ struct fspt_target {
   // Two lanes = two independent batches in flight on two HIP streams: while one batch sits in a latency-bound
   // kernel or in the tail of a late round, the other batch's kernels fill the idle SIMDs.
   struct WfLane {
-    void *mem[13] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *mem[WF_ARRAYS] = {};
     fspt::WfCounts *counts = nullptr;
+    fspt::WfCounts *counts_host = nullptr; // pinned copy of the last batch's per-round counts (tail heuristic)
+    hipEvent_t counts_ready = nullptr;
+    bool counts_pending = false;
+    uint32_t counts_slots = 0;             // slots of the batch the copy describes
     uint32_t slots = 0;        // allocated path slots
     hipStream_t stream = nullptr;
     hipEvent_t resolved = nullptr; // this lane's most recent resolve has finished
   } lanes[2];
   uint32_t n_lanes = 1; // 2 = pipeline code 2: measured +3 % at 64+ ticks, -17 % at 8 ticks (profiles/r01)
+  int tail_round = -1;       // fspt_target_set_tail: -1 adaptive, 0 never, r >= 1 after round r
+  float live_frac[80] = {};  // live paths after round r / slots of the batch, from the most recent finished batch
+  bool live_known = false;
   uint32_t ticks_seen = 0;   // largest n_ticks of any call so far: path state is sized for min(batch_ticks, ticks_seen)
   uint64_t mem_limit = 0;    // fspt_target_set_memory_limit: cap on the path-state bytes of this target (0 = none)
   hipEvent_t ev_start = nullptr;
@@ -211,8 +219,9 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     int32_t lr[4] = {ref[l], ref[r], 0, 0};
     std::memcpy(n + 12, lr, 16);
   }
-  if (max_depth + 1 > 64) {
-    // the reference's stack is int[64] (tracer.fs:368)
+  if (max_depth + 1 > 64 || max_depth + 1 > fspt::wf_max_stack_entries()) {
+    // the reference's stack is int[64] (tracer.fs:368); here one entry per level, in LDS (all 64 fit: 128 KB of the CU's
+    // 160 KB under the 512-thread primary launch)
     fspt_set_error("BVH depth %u exceeds the traversal stack (64)", max_depth);
     return FSPT_E_INVALID;
   }
@@ -311,7 +320,7 @@ int fspt_scene_depth(const fspt_scene *s, uint32_t *depth) {
 static const uint32_t WORK_RING = 4096;
 static const uint32_t WF_ROUNDS_MAX = fspt::MAX_PATH_ITERS + 4;
 static const uint32_t EV_PAIRS = 4096;
-static const uint64_t WF_SLOT_BUDGET = 576ull << 20; // path slots, 140 B each (up to 84 GB of the 288 GB HBM: a 4K frame x 64 ticks)
+static const uint64_t WF_SLOT_BUDGET = 448ull << 20; // path slots, 220 B each (up to 103 GB of the 288 GB HBM: a 4K frame x 56 ticks)
 
 int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **out) {
   if (!scene || !out || W == 0 || H == 0) { fspt_set_error("fspt_target_create: bad argument"); return FSPT_E_INVALID; }
@@ -356,6 +365,8 @@ int fspt_target_destroy(fspt_target *t) {
   for (auto &ln : t->lanes) {
     for (void *m : ln.mem) hipFree(m);
     hipFree(ln.counts);
+    if (ln.counts_host) hipHostFree(ln.counts_host);
+    if (ln.counts_ready) hipEventDestroy(ln.counts_ready);
     if (ln.resolved) hipEventDestroy(ln.resolved);
     if (ln.stream) hipStreamDestroy(ln.stream);
   }
@@ -437,8 +448,8 @@ static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
 }
 
 // bytes per path slot of every path-state array (fspt_device.hpp: WfP)
-// ray_o ray_d thr col shd pend (float4) | hit (float2) | shadow_hit (int) | q_ext[2] q_shd[2] (u32) | fin (float4)
-static const size_t WF_ARRAY_BYTES[13] = {16, 16, 16, 16, 16, 16, 8, 4, 4, 4, 4, 4, 16};
+// two state sets of A B C E D P (float4) | hit (float2) | shadow_hit (int) | fin (float4)   = 220 bytes per slot
+static const size_t WF_ARRAY_BYTES[WF_ARRAYS] = {16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 8, 4, 16};
 static size_t wf_slot_bytes() {
   size_t b = 0;
   for (size_t x : WF_ARRAY_BYTES) b += x;
@@ -457,7 +468,7 @@ static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots, ui
   (void)t;
   if (ln.slots >= slots && ln.counts) return FSPT_OK;
   wf_release(ln);
-  for (int i = 0; i < 13; ++i) {
+  for (int i = 0; i < WF_ARRAYS; ++i) {
     hipError_t e = slots > budget_slots ? hipErrorOutOfMemory : hipMalloc(&ln.mem[i], (size_t)slots * WF_ARRAY_BYTES[i]);
     if (e == hipErrorOutOfMemory) {
       // not enough free HBM (or over the target's memory limit) for this batch size: give everything back
@@ -471,6 +482,8 @@ static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots, ui
     HIP_TRY(hipMemsetAsync(ln.mem[i], 0, (size_t)slots * WF_ARRAY_BYTES[i], ln.stream)); // touch every page once, now
   }
   if (!ln.counts) HIP_TRY(hipMalloc((void **)&ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2)));
+  if (!ln.counts_host) HIP_TRY(hipHostMalloc((void **)&ln.counts_host, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), hipHostMallocDefault));
+  if (!ln.counts_ready) HIP_TRY(hipEventCreateWithFlags(&ln.counts_ready, hipEventDisableTiming));
   HIP_TRY(hipStreamSynchronize(ln.stream));
   ln.slots = slots;
   return FSPT_OK;
@@ -531,6 +544,28 @@ static int ev_begin(fspt_target *t, int kind, hipStream_t stream) {
 }
 static void ev_end(fspt_target *t, int i, hipStream_t stream) { if (i >= 0) hipEventRecord(t->ev_pool[2 * i + 1], stream); }
 
+// Live-path statistics of the most recent finished batch (copied to pinned memory behind the batch, never waited for).
+static void wf_collect_counts(fspt_target *t, fspt_target::WfLane &ln) {
+  if (!ln.counts_pending || hipEventQuery(ln.counts_ready) != hipSuccess) return;
+  ln.counts_pending = false;
+  if (!ln.counts_slots) return;
+  for (uint32_t r = 0; r < WF_ROUNDS_MAX + 2 && r < 80; ++r) t->live_frac[r] = (float)ln.counts_host[r].n_ext / (float)ln.counts_slots;
+  t->live_known = true;
+}
+
+// The round after which the tail kernel takes over (> last: never).  Adaptive: the first round that is expected to
+// leave fewer live paths than one trace launch needs to fill the machine - below that a round costs its latency floor
+// whatever the path count (profiles/r02), and running the survivors to completion in one kernel is cheaper.
+static const uint32_t WF_TAIL_PATHS = 160u * 1024u;
+static uint32_t wf_tail_round(const fspt_target *t, uint64_t slots, uint32_t last) {
+  if (t->tail_round == 0) return last + 1;
+  if (t->tail_round > 0) return (uint32_t)t->tail_round;
+  if (!t->live_known) return last + 1;
+  for (uint32_t r = 1; r < last && r < 80; ++r)
+    if ((double)t->live_frac[r] * (double)slots < (double)WF_TAIL_PATHS) return r;
+  return last + 1;
+}
+
 // n_ticks ticks through the wavefront pipeline.  rays_from_buffers: two-call form (n_ticks == 1).
 static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
                             const float *rb_cam, const float *rb_trace, bool rays_from_buffers) {
@@ -538,8 +573,8 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
   fill_trace_params(t, tp);
   const uint32_t work_total = tp.n_owned_tiles * tp.tile * tp.tile;
   if (work_total == 0) return FSPT_OK;
-  // path-state buffers are sized for the CONFIGURED batch at first use (not for this call's tick count):
-  // a short warm-up call must not cause a reallocation inside a later, longer call
+  // path state: sized for the largest call so far (fspt_target_prepare sizes it for the configured batch up front, so
+  // that a short warm-up call does not cause a reallocation inside a later, longer call)
   uint32_t n_lanes, per_lane;
   int rc = wf_plan_and_ensure(t, work_total, n_ticks, n_lanes, per_lane);
   if (rc) return rc;
@@ -574,44 +609,46 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     hipStream_t st = ln.stream;
     auto launch = [&](int kind) -> int {
       int e = ev_begin(t, kind, st);
-      hipError_t err = fspt::launch_wf(kind, p, gen, t->count, cus, st);
+      hipError_t err = fspt::launch_wf(kind, p, t->count, cus, st);
       ev_end(t, e, st);
       if (err != hipSuccess) { fspt_set_error("wavefront launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
       return FSPT_OK;
     };
-    p.ray_o = (float4 *)ln.mem[0]; p.ray_d = (float4 *)ln.mem[1]; p.thr = (float4 *)ln.mem[2];
-    p.col = (float4 *)ln.mem[3]; p.shd = (float4 *)ln.mem[4]; p.pend = (float4 *)ln.mem[5];
-    p.hit = (float2 *)ln.mem[6]; p.shadow_hit = (int *)ln.mem[7];
-    p.q_ext[0] = (uint32_t *)ln.mem[8]; p.q_ext[1] = (uint32_t *)ln.mem[9];
-    p.q_shd[0] = (uint32_t *)ln.mem[10]; p.q_shd[1] = (uint32_t *)ln.mem[11];
-    p.fin = (float4 *)ln.mem[12];
+    for (int k = 0; k < 2; ++k) {
+      fspt::WfSet &ws = p.set[k];
+      ws.A = (float4 *)ln.mem[6 * k + 0]; ws.B = (float4 *)ln.mem[6 * k + 1]; ws.C = (float4 *)ln.mem[6 * k + 2];
+      ws.E = (float4 *)ln.mem[6 * k + 3]; ws.D = (float4 *)ln.mem[6 * k + 4]; ws.P = (float4 *)ln.mem[6 * k + 5];
+    }
+    p.hit = (float2 *)ln.mem[12]; p.shadow_hit = (int *)ln.mem[13];
+    p.fin = (float4 *)ln.mem[14];
     p.counts = ln.counts;
     uint32_t nbt = n_ticks - done < batch ? n_ticks - done : batch;
     p.n_batch = nbt;
     p.first_tick = first_tick + done;
     for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
+    // the previous batch's live-path counts, if their copy has landed: where the tail kernel takes over
+    wf_collect_counts(t, ln);
     HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
     p.gen_rays = gen ? 1u : 0u;
-    // round 1 = the primary launch (ray generation + primary traversal + its shading); round r >= 2: logic consumes
-    // the results of trace r-1 and shades bounce r-1; after round nb+1 every path has finished unless a refraction
-    // kept `i` from advancing (tracer.fs:488)
-    uint32_t r = 1;
-    for (; r <= nb + 1; ++r) {
+    // Round 1 = the primary launch (ray generation + primary traversal + its shading); round r >= 2: logic consumes the
+    // results of trace r-1 and shades bounce r-1.  After round nb+1 every path has finished unless a refraction kept `i`
+    // from advancing (tracer.fs:488).  After round `tail` the tail kernel runs whatever is still alive to completion.
+    const uint32_t last = nb + 1;
+    uint32_t tail = wf_tail_round(t, (uint64_t)nbt * work_total, last);
+    if (t->scene->has_dielectric && tail > last) tail = last; // refraction: paths may outlive `last` rounds
+    for (uint32_t r = 1; r <= last && r <= tail; ++r) {
       p.round = r;
       if ((rc = launch(r == 1 ? fspt::WF_K_PRIMARY : fspt::WF_K_LOGIC))) return rc;
-      if (r <= nb || t->scene->has_dielectric) { if ((rc = launch(fspt::WF_K_TRACE))) return rc; }
+      if (r < last && r < tail) { if ((rc = launch(fspt::WF_K_TRACE))) return rc; }
     }
-    if (t->scene->has_dielectric) {
-      for (; r < WF_ROUNDS_MAX; ++r) {
-        fspt::WfCounts c;
-        HIP_TRY(hipMemcpyAsync(&c, ln.counts + (r - 1), sizeof(c), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (c.n_ext == 0) break;
-        p.round = r;
-        if ((rc = launch(fspt::WF_K_LOGIC))) return rc;
-        if ((rc = launch(fspt::WF_K_TRACE))) return rc;
-      }
+    if (tail <= last && (tail < last || t->scene->has_dielectric)) {
+      p.round = tail;
+      if ((rc = launch(fspt::WF_K_TAIL))) return rc;
     }
+    HIP_TRY(hipMemcpyAsync(ln.counts_host, ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(ln.counts_ready, st));
+    ln.counts_pending = true;
+    ln.counts_slots = nbt * work_total;
     // the running mean is order-dependent (tracer.fs:517): resolves run in tick order across the lanes
     if (prev) HIP_TRY(hipStreamWaitEvent(st, prev->resolved, 0));
     if ((rc = launch(fspt::WF_K_RESOLVE))) return rc;
@@ -652,7 +689,7 @@ int fspt_trace(fspt_target *t, uint32_t tick, float rand_base, float env_theta, 
   HIP_TRY(hipMemsetAsync(t->work_counters, 0, 4, t->stream));
   p.work_counter = t->work_counters;
   HIP_TRY(hipEventRecord(t->ev0, t->stream));
-  HIP_TRY(fspt::launch_trace(p, false, t->count, t->scene->num_cus, t->stream));
+  HIP_TRY(fspt::launch_trace(p, false, t->count != 0, t->scene->num_cus, t->stream));
   HIP_TRY(hipEventRecord(t->ev1, t->stream));
   t->timed = true; t->last_launches = 1;
   return FSPT_OK;
@@ -709,7 +746,7 @@ int fspt_render(fspt_target *t, const fspt_camera_params *cam_in, uint32_t first
       p.rand_base = fspt_rand_base_next(&st);
       p.tick = first_tick + done + k;
       p.work_counter = t->work_counters + k;
-      HIP_TRY(fspt::launch_trace(p, true, t->count, t->scene->num_cus, t->stream));
+      HIP_TRY(fspt::launch_trace(p, true, t->count != 0, t->scene->num_cus, t->stream));
     }
     done += batch;
   }
@@ -791,6 +828,13 @@ int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks)
   return FSPT_OK;
 }
 
+int fspt_target_set_tail(fspt_target *t, int round) {
+  if (!t) { fspt_set_error("fspt_target_set_tail: NULL target"); return FSPT_E_INVALID; }
+  if (round < -1 || round > FSPT_MAX_BOUNCES + 1) { fspt_set_error("fspt_target_set_tail: round must be -1 (adaptive), 0 (never) or 1..%d", FSPT_MAX_BOUNCES + 1); return FSPT_E_INVALID; }
+  t->tail_round = round;
+  return FSPT_OK;
+}
+
 int fspt_target_set_memory_limit(fspt_target *t, uint64_t bytes) {
   if (!t) { fspt_set_error("fspt_target_set_memory_limit: NULL target"); return FSPT_E_INVALID; }
   t->mem_limit = bytes;
@@ -818,16 +862,16 @@ int fspt_target_prepare(fspt_target *t) {
   return wf_plan_and_ensure(t, work_total, 0, n_lanes, per_lane);
 }
 
-int fspt_last_stage_ms(fspt_target *t, float ms[4], uint32_t launches[4]) {
+int fspt_last_stage_ms(fspt_target *t, float ms[5], uint32_t launches[5]) {
   if (!t || !ms || !launches) { fspt_set_error("fspt_last_stage_ms: NULL argument"); return FSPT_E_INVALID; }
   HIP_TRY(hipSetDevice(t->scene->device));
   HIP_TRY(hipStreamSynchronize(t->stream));
-  for (int k = 0; k < 4; ++k) { ms[k] = 0.0f; launches[k] = 0; }
+  for (int k = 0; k < fspt::WF_K_KINDS; ++k) { ms[k] = 0.0f; launches[k] = 0; }
   for (uint32_t i = 0; i < t->ev_used; ++i) {
     float e = 0.0f;
     HIP_TRY(hipEventElapsedTime(&e, t->ev_pool[2 * i], t->ev_pool[2 * i + 1]));
     int k = t->ev_kind[i];
-    if (k >= 0 && k < 4) { ms[k] += e; launches[k]++; }
+    if (k >= 0 && k < fspt::WF_K_KINDS) { ms[k] += e; launches[k]++; }
   }
   if (t->ev_overflow) { fspt_set_error("stage timing: more than %u launches, timing truncated", EV_PAIRS); return FSPT_E_STATE; }
   return FSPT_OK;
@@ -835,7 +879,7 @@ int fspt_last_stage_ms(fspt_target *t, float ms[4], uint32_t launches[4]) {
 
 int fspt_enable_counters(fspt_target *t, int enable) {
   if (!t) { fspt_set_error("fspt_enable_counters: NULL target"); return FSPT_E_INVALID; }
-  t->count = enable != 0;
+  t->count = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
   return FSPT_OK;
 }
 
@@ -854,6 +898,159 @@ int fspt_get_counters(fspt_target *t, fspt_counters *out) {
   HIP_TRY(hipStreamSynchronize(t->stream));
   out->samples = v[0]; out->rays = v[1]; out->steps = v[2]; out->leaves = v[3]; out->shades = v[4];
   out->env_lookups = v[5];
+  return FSPT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// one frame over several devices (include/fspt.h: fspt_multi_*)
+// ---------------------------------------------------------------------------
+struct fspt_multi {
+  uint32_t W = 0, H = 0;
+  std::vector<int> devices;
+  std::vector<fspt_scene *> scenes;
+  std::vector<fspt_target *> targets;
+  std::vector<float4 *> packed;   // per target: its own pixels in work-index order (on its device)
+  std::vector<float4 *> staging;  // per target: the same, on devices[0]
+  std::vector<hipEvent_t> arrived;
+  uint64_t gather_bytes = 0;
+};
+
+static void multi_pack_params(fspt_target *t, fspt::TilePackP &q) {
+  fspt::TraceP tp{};
+  fill_trace_params(t, tp);
+  q.W = t->W; q.H = t->H; q.vw = t->W; q.vh = t->H; // the read-out moves whole tiles, whatever the viewport
+  q.shard = tp.shard; q.n_shards = tp.n_shards; q.tile = tp.tile; q.tiles_x = tp.tiles_x; q.tiles_y = tp.tiles_y;
+  q.n_owned_tiles = tp.n_owned_tiles;
+}
+
+int fspt_multi_destroy(fspt_multi *m) {
+  if (!m) return FSPT_OK;
+  for (size_t i = 0; i < m->targets.size(); ++i) {
+    if (m->targets[i]) { hipSetDevice(m->devices[i]); hipStreamSynchronize(m->targets[i]->stream); }
+  }
+  for (size_t i = 0; i < m->devices.size(); ++i) {
+    if (i < m->packed.size() && m->packed[i]) { hipSetDevice(m->devices[i]); hipFree(m->packed[i]); }
+    if (i < m->staging.size() && m->staging[i]) { hipSetDevice(m->devices[0]); hipFree(m->staging[i]); }
+    if (i < m->arrived.size() && m->arrived[i]) { hipSetDevice(m->devices[i]); hipEventDestroy(m->arrived[i]); }
+  }
+  for (fspt_target *t : m->targets) fspt_target_destroy(t);
+  for (fspt_scene *s : m->scenes) fspt_scene_destroy(s);
+  delete m;
+  return FSPT_OK;
+}
+
+int fspt_multi_create(const fspt_scene_desc *desc, const int *devices, uint32_t n_devices, uint32_t W, uint32_t H, fspt_multi **out) {
+  if (!desc || !devices || !out || n_devices == 0 || n_devices > 64) { fspt_set_error("fspt_multi_create: bad argument (1..64 devices)"); return FSPT_E_INVALID; }
+  *out = nullptr;
+  fspt_multi *m = new fspt_multi();
+  m->W = W; m->H = H;
+  m->devices.assign(devices, devices + n_devices);
+  m->packed.assign(n_devices, nullptr); m->staging.assign(n_devices, nullptr); m->arrived.assign(n_devices, nullptr);
+  int rc = FSPT_OK;
+  for (uint32_t i = 0; i < n_devices && rc == FSPT_OK; ++i) {
+    // one scene copy per DISTINCT device (a device listed twice shares it)
+    fspt_scene *s = nullptr;
+    for (uint32_t j = 0; j < i; ++j) if (devices[j] == devices[i]) { s = m->targets[j]->scene; break; }
+    if (!s) { rc = fspt_scene_create(desc, devices[i], &s); if (rc == FSPT_OK) m->scenes.push_back(s); }
+    fspt_target *t = nullptr;
+    if (rc == FSPT_OK) rc = fspt_target_create(s, W, H, &t);
+    if (rc == FSPT_OK) { m->targets.push_back(t); rc = fspt_target_set_shard(t, i, n_devices, 32); }
+    if (rc == FSPT_OK && i > 0) {
+      fspt::TilePackP q{};
+      multi_pack_params(t, q);
+      const size_t bytes = (size_t)q.n_owned_tiles * q.tile * q.tile * sizeof(float4);
+      hipError_t e = hipSetDevice(devices[i]);
+      if (e == hipSuccess) e = hipMalloc((void **)&m->packed[i], bytes ? bytes : 16);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&m->arrived[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipSetDevice(devices[0]);
+      if (e == hipSuccess) e = hipMalloc((void **)&m->staging[i], bytes ? bytes : 16);
+      if (e == hipSuccess && devices[i] != devices[0]) {
+        // direct xGMI copies when the devices can reach each other; hipMemcpyPeerAsync stages through the host otherwise
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can) {
+          hipError_t pe = hipDeviceEnablePeerAccess(devices[i], 0);
+          if (pe != hipSuccess) (void)hipGetLastError(); // already enabled
+        }
+      }
+      if (e != hipSuccess) { fspt_set_error("fspt_multi_create: %s", hipGetErrorString(e)); rc = FSPT_E_HIP; }
+    }
+  }
+  if (rc != FSPT_OK) { fspt_multi_destroy(m); return rc; }
+  *out = m;
+  return FSPT_OK;
+}
+
+int fspt_multi_target(fspt_multi *m, uint32_t i, fspt_target **out) {
+  if (!m || !out || i >= m->targets.size()) { fspt_set_error("fspt_multi_target: bad argument"); return FSPT_E_INVALID; }
+  *out = m->targets[i];
+  return FSPT_OK;
+}
+
+#define MULTI_EACH(call)                                                     \
+  do {                                                                       \
+    if (!m) { fspt_set_error("fspt_multi: NULL handle"); return FSPT_E_INVALID; } \
+    for (fspt_target *t : m->targets) { int rc_ = (call); if (rc_) return rc_; }  \
+    return FSPT_OK;                                                          \
+  } while (0)
+
+int fspt_multi_camera(fspt_multi *m, const float P[3], const float I[3], float fov_scale, const float lens[2], float rand_base) {
+  MULTI_EACH(fspt_camera(t, P, I, fov_scale, lens, rand_base));
+}
+int fspt_multi_trace(fspt_multi *m, uint32_t tick, float rand_base, float env_theta, uint32_t num_bounces) {
+  MULTI_EACH(fspt_trace(t, tick, rand_base, env_theta, num_bounces));
+}
+int fspt_multi_render(fspt_multi *m, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks, uint64_t seed) {
+  MULTI_EACH(fspt_render(t, cam, first_tick, n_ticks, seed));
+}
+int fspt_multi_clear(fspt_multi *m) { MULTI_EACH(fspt_clear(t)); }
+int fspt_multi_sync(fspt_multi *m) { MULTI_EACH(fspt_sync(t)); }
+
+// every device packs its own tiles and sends them to devices[0] on its own stream; devices[0] scatters them
+static int multi_gather(fspt_multi *m) {
+  fspt_target *t0 = m->targets[0];
+  m->gather_bytes = 0;
+  for (size_t i = 1; i < m->targets.size(); ++i) {
+    fspt_target *t = m->targets[i];
+    fspt::TilePackP q{};
+    multi_pack_params(t, q);
+    const size_t bytes = (size_t)q.n_owned_tiles * q.tile * q.tile * sizeof(float4);
+    if (!bytes) continue;
+    HIP_TRY(hipSetDevice(m->devices[i]));
+    q.accum = t->accum; q.packed = m->packed[i];
+    HIP_TRY(fspt::launch_tile_pack(q, false, t->stream));
+    HIP_TRY(hipMemcpyPeerAsync(m->staging[i], m->devices[0], m->packed[i], m->devices[i], bytes, t->stream));
+    HIP_TRY(hipEventRecord(m->arrived[i], t->stream));
+    m->gather_bytes += bytes;
+  }
+  HIP_TRY(hipSetDevice(m->devices[0]));
+  for (size_t i = 1; i < m->targets.size(); ++i) {
+    fspt::TilePackP q{};
+    multi_pack_params(m->targets[i], q);
+    if (!q.n_owned_tiles) continue;
+    HIP_TRY(hipStreamWaitEvent(t0->stream, m->arrived[i], 0));
+    q.accum = t0->accum; q.packed = m->staging[i];
+    HIP_TRY(fspt::launch_tile_pack(q, true, t0->stream));
+  }
+  return FSPT_OK;
+}
+
+int fspt_multi_read_radiance(fspt_multi *m, float *out) {
+  if (!m || !out) { fspt_set_error("fspt_multi_read_radiance: NULL argument"); return FSPT_E_INVALID; }
+  int rc = multi_gather(m);
+  if (rc) return rc;
+  return fspt_read_radiance(m->targets[0], out);
+}
+
+int fspt_multi_draw(fspt_multi *m, float exposure, float saturation, int denoise, float max_sigma, uint8_t *out_rgba8) {
+  if (!m || !out_rgba8) { fspt_set_error("fspt_multi_draw: NULL argument"); return FSPT_E_INVALID; }
+  int rc = multi_gather(m);
+  if (rc) return rc;
+  return fspt_draw(m->targets[0], exposure, saturation, denoise, max_sigma, out_rgba8);
+}
+
+int fspt_multi_last_gather_bytes(fspt_multi *m, uint64_t *bytes) {
+  if (!m || !bytes) { fspt_set_error("fspt_multi_last_gather_bytes: NULL argument"); return FSPT_E_INVALID; }
+  *bytes = m->gather_bytes;
   return FSPT_OK;
 }
 

@@ -88,44 +88,48 @@ struct IntersectP {
 // ---------------------------------------------------------------------------
 // Wavefront pipeline (fspt_render's default): the same per-path arithmetic cut
 // into queue-driven kernels so that every lane of a wave does the same kind of
-// work:  primary (ray generation + camera-ray traversal + its shading) -> [ trace <-> logic ] x rounds -> resolve.
+// work:  primary (ray generation + camera-ray traversal + its shading) -> [ trace <-> logic ] x rounds
+//        [-> tail: the last few live paths run to completion in one kernel] -> resolve.
 //   slot s = w * n_batch + j  : sample of tick (first_tick + j) for work index w
 //   (pixel via work_to_pixel); a batch holds n_batch ticks.  Pixel-major on purpose:
-//   the ticks of one pixel are neighbours in every queue, so a wave's primary rays are
-//   near-identical (coherent traversal, broadcast node loads) and neighbouring paths
-//   shade the same triangle/material.
-// Path state lives in HBM as float4 SoA arrays (coalesced 16-byte accesses):
-//   ray_o  ro.xyz, -
-//   thr    accumulatedReflectance.xyz, weights.y
-//   ray_d  rd.xyz, flags (bits: 0-7 bounce, 8-15 iters, 16 primary, 17 hasShadow, 18 colour is +0)
-//   col    color.xyz, -   (only touched while the colour is non-zero)
-//   shd    envDir.xyz, weights.x     pend  reflectance*envThroughput.xyz, -
-//   hit    (t, index) of the extension/primary ray;  shadow_hit  index of the NEE ray
-//   fin    finished sample colour, indexed tick-major [j][w]
-// Queues hold slot ids; WF_DEAD marks a skipped entry (ragged tile edge).
+//   the ticks of one pixel are neighbours in the primary launch, so a wave's camera rays are
+//   near-identical (coherent traversal, broadcast node loads) and shade the same triangle.
+// Path state is DENSE: round r's logic launch writes the state of its survivors to consecutive indices
+//   k = 0 .. n_r-1 of state set (r & 1) (the other set is its input), so every later access - the trace kernel's
+//   ray loads and result stores, the next round's loads - touches whole cache lines.  (Round 1 kept the state at
+//   the path's fixed slot: after a few rounds the survivors are sparse and every 16-byte access moved a 64-byte
+//   line - 4x the bytes, profiles/r01.)  float4 SoA arrays, per set:
+//   A  ro.xyz, slot (uint bits)          B  rd.xyz, flags (bits: 0-7 bounce, 8-15 iters, 16 primary, 17 hasShadow, 18 colour is +0)
+//   C  accumulatedReflectance.xyz, weights.y
+//   E  color.xyz, -   (only touched while the colour is non-zero)
+//   D  envDir.xyz, weights.x             P  reflectance*envThroughput.xyz, -     (only when the path has a NEE shadow ray)
+// Per round (indexed like the state): hit (t, index) of the extension ray, shadow_hit = index of the NEE ray.
+// fin[slot]: the finished sample colour, slot-major (a wave's finishing paths are neighbours).
 // ---------------------------------------------------------------------------
-constexpr uint32_t WF_DEAD = 0xFFFFFFFFu;
 constexpr int WF_MAX_BATCH = 128;
 constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17, WF_FLAG_COLZERO = 1u << 18;
+#ifndef FSPT_WF_HEADS
+#define FSPT_WF_HEADS 16
+#endif
+constexpr int WF_HEADS = FSPT_WF_HEADS; // work-pool heads of the trace kernel (one per item segment; waves steal from the others)
 
-struct alignas(16) WfCounts { // one per round, zeroed before the batch
-  uint32_t n_ext;  // entries of q_ext for this round   } bumped together by one 64-bit atomic
-  uint32_t n_shd;  // entries of q_shd for this round   } (n_ext low word, n_shd high word)
-  uint32_t head;   // trace kernel work-pool head (one head: XCD-segmented pools measured 50 % slower,
-                   // static segments unbalance the XCDs and the L2 hit rate did not move - profiles/r01)
-  uint32_t pad;
+struct alignas(128) WfCounts { // one per round, zeroed before the batch
+  uint32_t n_ext;          // live paths written by this round's primary / logic launch
+  uint32_t pad[15];
+  uint32_t head[WF_HEADS]; // trace kernel work-pool heads: one same-address atomic stream sustains ~65 M/s
+                           // (profiles/r01), which capped small launches at 64 rays per 15 ns
 };
+
+struct WfSet { float4 *A, *B, *C, *E, *D, *P; };
 
 struct WfP {
   uint32_t gen_rays; // primary launch: 1 = camera.fs in the kernel, 0 = read the ray buffers (two-call form)
   uint32_t lds_top; // top-of-tree nodes k_wf_trace keeps in LDS (<= scene.n_top; set by launch_wf)
   DScene scene;
-  float4 *ray_o, *ray_d, *thr, *col, *shd, *pend;
-  float4 *fin; // finished sample colours, tick-major [j][w] (resolve reads them coalesced)
+  WfSet set[2];
+  float4 *fin; // finished sample colours [slot]
   float2 *hit;
   int *shadow_hit;
-  uint32_t *q_ext[2];
-  uint32_t *q_shd[2];
   WfCounts *counts;
   uint32_t round;
   uint32_t W, H;
@@ -144,11 +148,24 @@ struct WfP {
   uint32_t shard, n_shards, tile, tiles_x, tiles_y, n_owned_tiles;
 };
 
-enum { WF_K_PRIMARY = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3 }; // also the slots of fspt_last_stage_ms
-hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream);
+// kernel classes; also the slots of fspt_last_stage_ms
+enum { WF_K_PRIMARY = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3, WF_K_TAIL = 4, WF_K_KINDS = 5 };
+// count: 0 = production kernels; 1 = counting variants doing the reference's work (NEE shadow rays traced to the closest
+// hit, tracer.fs:501); 2 = counting variants of the production work (shadow rays stop at the first hit)
+hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream_t stream);
+
+// multi-device read-out: a shard's own pixels <-> a packed array in work-index order (work_to_pixel)
+struct TilePackP {
+  float4 *accum;   // full-size W x H accumulator
+  float4 *packed;  // n_owned_tiles * tile^2 entries
+  uint32_t W, H, vw, vh;
+  uint32_t shard, n_shards, tile, tiles_x, tiles_y, n_owned_tiles;
+};
+hipError_t launch_tile_pack(const TilePackP &p, bool unpack, hipStream_t stream);
 
 // launchers (fspt_kernels.hip)
 hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream);
+size_t wf_max_stack_entries(); // deepest tree (entries per lane) whose traversal stacks fit the LDS of every kernel
 hipError_t launch_camera(uint32_t W, uint32_t H, uint32_t vw, uint32_t vh, const CameraP &cam, float rand_base, float4 *pos, float4 *dir,
                          hipStream_t stream);
 hipError_t launch_intersect(const IntersectP &p, hipStream_t stream);

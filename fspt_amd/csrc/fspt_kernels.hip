@@ -30,9 +30,6 @@ using namespace fm;
 #ifndef FSPT_TAP2
 #define FSPT_TAP2 1
 #endif
-#ifndef WF_COL_LAZY
-#define WF_COL_LAZY 1 // colour array untouched while a path's colour is +0: logic -2.5 %, +1.3 % overall (profiles/r01)
-#endif
 #ifndef WF_LOGIC_LDSTAB
 #define WF_LOGIC_LDSTAB 1
 #endif
@@ -110,7 +107,8 @@ struct Counters {
 // extension ray, tracer.fs:440,507).  `stack` points at this lane's column of
 // the wave's LDS stack (entry k at stack[k*64]).
 // ---------------------------------------------------------------------------
-template <bool COUNT>
+// ANYHIT: ray A stops at its first hit (only `shadow.index == -1` is consumed, tracer.fs:502).
+template <bool COUNT, bool ANYHIT>
 FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 dB, int &hitA, float &tB, int &hitB,
                        Counters &cnt) {
   int slot = hasA ? 0 : 1;
@@ -174,6 +172,7 @@ FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 d
       process_leaf(tris, leaf_size, ts, o, d, t, hit);
       if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
       else cur = REF_SENTINEL;
+      if (ANYHIT && slot == 0 && hit != -1) cur = REF_SENTINEL;
     }
   }
   tB = t;
@@ -724,7 +723,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 
     // ================= T phase =================
     if (ps.pix >= 0) {
-      trace_rays<COUNT>(S, stack, ps.ro, ps.hasShadow, ps.envDir, ps.rd, hitA, tB, hitB, cnt);
+      trace_rays<COUNT, false>(S, stack, ps.ro, ps.hasShadow, ps.envDir, ps.rd, hitA, tB, hitB, cnt);
     }
   }
 
@@ -740,38 +739,32 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 }
 
 // ===========================================================================
-// Wavefront pipeline: primary -> [trace <-> logic] x rounds -> resolve
+// Wavefront pipeline: primary -> [trace <-> logic] x rounds [-> tail] -> resolve
 // (layout and slot numbering: fspt_device.hpp)
 // ===========================================================================
 #ifndef WF_TRACE_CHUNK
 #define WF_TRACE_CHUNK 1024u // measured at 128-tick batches: 256 / 512 / 1024 -> trace 0.317 / 0.223 / 0.214 ms per tick; 2048+ and guided (shrinking) chunk sizes are slower
 #endif
-#ifndef WF_TRACE_STATIC_CHUNKS
-#define WF_TRACE_STATIC_CHUNKS 1u // chunks of its own every wave starts with before it turns to the shared pool head
-#endif
 // measured on C2 (profiles/r01): 1 -> 0.462, 8 -> 0.348, 16 -> 0.338, 24 -> 0.336, 32 -> 0.343 ms per tick
 #ifndef WF_INTERIOR_MIN
 #define WF_INTERIOR_MIN 16
 #endif
-#ifndef WF_SHADOW_ANYHIT
-#define WF_SHADOW_ANYHIT 1
-#endif
-#ifndef WF_REFILL_MIN
-#define WF_REFILL_MIN 1
-#endif
 #ifndef WF_LOGIC_THREADS
 #define WF_LOGIC_THREADS 512
 #endif
-// (software-pipelining the path-state loads was measured 10 % slower: 12 spills - removed)
-// measured: U = 1 / 2 / 4 / 8 -> 0.327 / 0.320 / 0.331 / 0.357 ms per tick (spills grow with U)
+// paths per thread of one block iteration of the logic kernel (classification is cheap; a larger chunk gives the dense
+// shading phase more whole waves of work)
 #ifndef WF_LOGIC_U
-#define WF_LOGIC_U 2
+#define WF_LOGIC_U 8
+#endif
+#ifndef WF_PRIMARY_U
+#define WF_PRIMARY_U 2 // measured (r01): U = 1 / 2 / 4 / 8 -> 0.327 / 0.320 / 0.331 / 0.357 ms per tick (spills grow with U)
 #endif
 
-// Path state is streamed (touched once per round): non-temporal so it does not evict the BVH and
-// shading records from L2.  FSPT_NT=0 builds the plain variant for A/B.
+// Path state is streamed (touched once per round).  FSPT_NT=1 builds the non-temporal variant for A/B
+// (measured r01: logic kernel 5 % slower with nt loads, stores box-dependent).
 #ifndef FSPT_NT
-#define FSPT_NT 0 /* measured: logic kernel 5 % slower with nt, trace unchanged (profiles/r01) */
+#define FSPT_NT 0
 #endif
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
 typedef float nt_f2 __attribute__((ext_vector_type(2)));
@@ -826,15 +819,70 @@ FM_DEV uint32_t lane_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// ---- trace: intersectScene for a queue of rays; persistent waves, per-lane refill -------
-// Items [0, n_shd) are the NEE shadow rays of q_shd, items [n_shd, n_shd + n_ext) the
-// primary/extension rays of q_ext.  A lane whose ray is finished writes its result and
-// takes the next item from the wave's pool, so all 64 lanes keep traversing.
+// ---- path state <-> registers ---------------------------------------------------------------
+FM_DEV uint32_t pack_flags(const Path &ps, bool col_zero) {
+  return ((uint32_t)ps.bounce & 255u) | (((uint32_t)ps.iters & 255u) << 8) | (ps.primary ? WF_FLAG_PRIMARY : 0u) |
+         (ps.hasShadow ? WF_FLAG_SHADOW : 0u) | (col_zero ? WF_FLAG_COLZERO : 0u);
+}
+// state of a surviving path -> index k of `o`; the colour array is only written while the colour is non-zero
+// (it is +0 until the first light arrives), D / P only when the path has a NEE shadow ray
+FM_DEV void store_path(const WfSet &o, uint32_t k, const Path &ps, uint32_t slot) {
+  const bool col_zero = ps.color.x == 0.0f && ps.color.y == 0.0f && ps.color.z == 0.0f;
+  st4(o.A + k, make_float4(ps.ro.x, ps.ro.y, ps.ro.z, __uint_as_float(slot)));
+  st4(o.B + k, make_float4(ps.rd.x, ps.rd.y, ps.rd.z, __uint_as_float(pack_flags(ps, col_zero))));
+  st4(o.C + k, make_float4(ps.thr.x, ps.thr.y, ps.thr.z, ps.wy));
+  if (!col_zero) st4(o.E + k, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
+  if (ps.hasShadow) {
+    st4(o.D + k, make_float4(ps.envDir.x, ps.envDir.y, ps.envDir.z, ps.wx));
+    st4(o.P + k, make_float4(ps.pend.x, ps.pend.y, ps.pend.z, 0.0f));
+  }
+}
+// path k of `in` with the traversal results of its rays; returns the slot
+FM_DEV uint32_t load_path(const WfSet &in, uint32_t k, Path &ps, const int *shadow_hit, int &hitA) {
+  const float4 ro = ld4(in.A + k), rd = ld4(in.B + k), th = ld4(in.C + k);
+  const uint32_t flags = __float_as_uint(rd.w);
+  float4 co = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (!(flags & WF_FLAG_COLZERO)) co = ld4(in.E + k);
+  ps.ro = v3(ro.x, ro.y, ro.z);
+  ps.rd = v3(rd.x, rd.y, rd.z);
+  ps.thr = v3(th.x, th.y, th.z);
+  ps.wy = th.w;
+  ps.color = v3(co.x, co.y, co.z);
+  ps.bounce = (int)(flags & 255u);
+  ps.iters = (int)((flags >> 8) & 255u);
+  ps.primary = (flags & WF_FLAG_PRIMARY) != 0u;
+  ps.hasShadow = (flags & WF_FLAG_SHADOW) != 0u;
+  ps.pix = 0;
+  ps.wx = 0.0f;
+  ps.envDir = v3(0.0f, 0.0f, 0.0f);
+  ps.pend = v3(0.0f, 0.0f, 0.0f);
+  hitA = -1;
+  if (ps.hasShadow) {
+    const float4 sd = ld4(in.D + k), pe = ld4(in.P + k);
+    ps.envDir = v3(sd.x, sd.y, sd.z);
+    ps.wx = sd.w;
+    ps.pend = v3(pe.x, pe.y, pe.z);
+    if (shadow_hit) hitA = ldi(shadow_hit + k);
+  }
+  return __float_as_uint(ro.w);
+}
+
+// ---- trace: intersectScene for the rays of one round; persistent waves, per-lane refill -------
+// One item per live path k of the round: its NEE shadow ray (if it has one) and then its extension ray, traced by the
+// same lane one after the other (they share their origin: one state fetch, and no items that turn out to be empty).
+// A lane whose path is done writes its results and takes the next item from the wave's pool, so all 64 lanes keep
+// traversing.
+// The pool: device-scope atomics execute at the memory side on this part (the XCDs' L2s are not coherent with each
+// other) - one address sustains ~65 M atomics/s, and device-scope loads are as slow (measured: a peek before every
+// draw cost more than it saved, profiles/r02).  So: every wave's first chunk is its own (no atomic); the chunks beyond
+// are dealt round-robin to WF_HEADS stripes (chunk c belongs to stripe c % WF_HEADS), every wave draws from the one
+// stripe it is assigned to and never from another: the stripes hold the same mix of cheap and expensive image regions,
+// so they run dry together, each head takes 1/WF_HEADS of the atomics, and a wave ends on ONE failed atomic.
 // 6 waves/SIMD minimum -> <= 80 VGPRs: measured best of {5, 7, 8(spills)} waves/SIMD (profiles/r01)
 #ifndef WF_TRACE_WAVES
 #define WF_TRACE_WAVES 6
 #endif
-template <bool COUNT>
+template <bool COUNT, bool ANYHIT>
 __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(const WfP p) {
   extern __shared__ int lds_stack[];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -844,11 +892,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   const float4 *__restrict__ nodes = S.nodes;
   const float *__restrict__ tris = S.tris;
   const uint32_t leaf_size = S.leaf_size;
-  const uint32_t *__restrict__ q_ext = p.q_ext[p.round & 1];
-  const uint32_t *__restrict__ q_shd = p.q_shd[p.round & 1];
+  const WfSet st = p.set[p.round & 1];
   WfCounts *cn = p.counts + p.round;
-  const uint32_t n_shd = cn->n_shd;
-  const uint32_t total = n_shd + cn->n_ext;
+  const uint32_t total = cn->n_ext;
 
   // top of the tree in LDS (behind the waves' stacks): every ray walks these nodes, and a fetch from LDS does not
   // occupy the vector-memory pipeline that bounds this kernel
@@ -859,25 +905,22 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     __syncthreads();
   }
 
-  // pool chunk: large while rays are plentiful (few atomics), one wave-load when they are scarce
+  // pool chunk: large while paths are plentiful (few atomics), one wave-load when they are scarce
   // (late rounds), so that every resident wave gets work
   const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
   uint32_t chunk = (total / (n_waves * 4u)) & ~63u;
   chunk = chunk < 64u ? 64u : (chunk > WF_TRACE_CHUNK ? WF_TRACE_CHUNK : chunk);
+  const uint32_t n_chunks = (total + chunk - 1u) / chunk;
+  const uint32_t wave_id = blockIdx.x * WAVES_PER_BLOCK + wave;
+  const uint32_t stripe = wave_id % WF_HEADS;
+  uint32_t pool_next = min(wave_id * chunk, total), pool_end = min(wave_id * chunk + chunk, total); // chunk `wave_id`
+  bool exhausted = n_chunks <= n_waves; // nothing beyond the waves' own chunks
 
   uint32_t c_rays = 0, c_steps = 0, c_leaves = 0;
-  // every wave's first chunk is its own slice [w*chunk, (w+1)*chunk) - no atomic: thousands of waves hitting the one
-  // pool head at start-up is what a small launch's run time consisted of; the head hands out what lies beyond
-  const uint32_t wave_id = blockIdx.x * WAVES_PER_BLOCK + wave;
-  const uint32_t own = chunk * WF_TRACE_STATIC_CHUNKS;
-  const uint32_t static_end = n_waves * own;
-  uint32_t pool_next = min(wave_id * own, total), pool_end = min(wave_id * own + own, total);
-  bool exhausted = static_end >= total; // nothing beyond the static slices
-
   bool idle = true;
   bool is_shadow = false;
-  uint32_t slot = 0;
-  V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0);
+  uint32_t path = 0;
+  V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0), d_ext = v3(0, 0, 1);
   float t = MAX_T;
   int hit = -1, cur = REF_SENTINEL, sp = 0;
 
@@ -886,43 +929,37 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     while (true) {
       unsigned long long need = __ballot(idle);
       if (need == 0ull) break;
-#if WF_REFILL_MIN > 1
-      // a refill stalls the whole wave on the new rays' loads: wait until several lanes are idle
-      if ((uint32_t)__popcll(need) < WF_REFILL_MIN && !exhausted) break;
-#endif
       uint32_t avail = pool_end - pool_next;
       if (avail == 0u) {
         if (exhausted) break;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&cn->head, chunk);
-        base = __builtin_amdgcn_readfirstlane(base) + static_end;
-        if (base >= total) { exhausted = true; break; }
-        pool_next = base;
-        pool_end = min(base + chunk, total);
+        uint32_t j = 0;
+        if (lane == 0) j = atomicAdd(&cn->head[stripe], 1u);
+        j = __builtin_amdgcn_readfirstlane(j);
+        const unsigned long long c = (unsigned long long)n_waves + (unsigned long long)j * WF_HEADS + stripe;
+        if (c >= n_chunks) { exhausted = true; break; }
+        pool_next = (uint32_t)c * chunk;
+        pool_end = min(pool_next + chunk, total);
         continue;
       }
       uint32_t rank = lane_rank(need);
       uint32_t want = (uint32_t)__popcll(need);
       uint32_t take = want < avail ? want : avail;
       if (idle && rank < take) {
-        uint32_t item = pool_next + rank;
-        bool sh = item < n_shd;
-        uint32_t s = sh ? q_shd[item] : q_ext[item - n_shd];
-        if (s != WF_DEAD) {
-          float4 ro = ld4(p.ray_o + s);
-          float4 rd = ld4(sh ? p.shd + s : p.ray_d + s);
-          o = v3(ro.x, ro.y, ro.z);
-          d = v3(rd.x, rd.y, rd.z);
-          inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-          t = MAX_T;
-          hit = -1;
-          cur = S.root_ref;
-          sp = 0;
-          slot = s;
-          is_shadow = sh;
-          idle = false;
-          if (COUNT) c_rays++;
-        }
+        const uint32_t k = pool_next + rank;
+        const float4 ro = ld4(st.A + k), rd = ld4(st.B + k);
+        const float4 sd = ld4(st.D + k); // fetched alongside (only meaningful when the path has a shadow ray)
+        o = v3(ro.x, ro.y, ro.z);
+        d_ext = v3(rd.x, rd.y, rd.z);
+        is_shadow = (__float_as_uint(rd.w) & WF_FLAG_SHADOW) != 0u;
+        d = is_shadow ? v3(sd.x, sd.y, sd.z) : d_ext;
+        inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        t = MAX_T;
+        hit = -1;
+        cur = S.root_ref;
+        sp = 0;
+        path = k;
+        idle = false;
+        if (COUNT) c_rays++;
       }
       pool_next += take;
     }
@@ -986,15 +1023,26 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
       if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
       else cur = REF_SENTINEL;
       // NEE shadow rays: only `shadow.index == -1` is consumed (tracer.fs:502), so the first hit settles
-      // the ray.  The counting variant keeps the reference's full closest-hit traversal, so the work
-      // counters stay equal to the oracle's (the algorithmic bytes of the reference algorithm).
-      if (WF_SHADOW_ANYHIT && !COUNT && is_shadow && hit != -1) cur = REF_SENTINEL;
+      // the ray.  The ANYHIT = false counting variant keeps the reference's full closest-hit traversal, so its
+      // work counters equal the oracle's (the algorithmic work of the reference algorithm).
+      if (ANYHIT && is_shadow && hit != -1) cur = REF_SENTINEL;
     }
-    // ---- finished rays: write the result, lane becomes idle ----
+    // ---- finished rays: write the result; after the shadow ray comes the path's extension ray, then the lane is idle ----
     if (!idle && cur == REF_SENTINEL) {
-      if (is_shadow) sti(p.shadow_hit + slot, hit);
-      else st2(p.hit + slot, make_float2(t, __int_as_float(hit)));
-      idle = true;
+      if (is_shadow) {
+        sti(p.shadow_hit + path, hit);
+        is_shadow = false;
+        d = d_ext;
+        inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        t = MAX_T;
+        hit = -1;
+        cur = S.root_ref;
+        sp = 0;
+        if (COUNT) c_rays++;
+      } else {
+        st2(p.hit + path, make_float2(t, __int_as_float(hit)));
+        idle = true;
+      }
     }
   }
   if (COUNT) {
@@ -1008,38 +1056,45 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   }
 }
 
-// ---- logic: one S step for every live path of the round; compacts survivors -------------
-// 4 waves/SIMD (<= 128 VGPRs, 2 spilled): measured best of {3, 4, 5(39 spills)} (profiles/r01)
-#ifndef WF_LOGIC_WAVES
-#define WF_LOGIC_WAVES 4
-#endif
-// FIRST: round 1 = the PRIMARY launch.  It does camera.fs (or reads the injected ray buffers), traces the camera ray
-// (intersectScene in place, stack in LDS) and shades it, for every slot of the batch: the primary ray never travels
-// through HBM, thr / colour / flags are constants, and the VALU-bound shading of some waves overlaps the memory-bound
-// traversal of others on the same SIMD (measured +5.6 % over separate gen / trace / logic launches, profiles/r01).
-#ifndef WF_LOGIC_WAVES_FIRST
-#define WF_LOGIC_WAVES_FIRST WF_LOGIC_WAVES
-#endif
-#ifndef WF_LOGIC_U_FIRST
-#define WF_LOGIC_U_FIRST WF_LOGIC_U
-#endif
-// LDSTAB: the small read-only tables every shading event gathers from - the flat-colour atlas (one texel per layer),
-// the environment's importance bins and the batch's randBase values - are staged in LDS once per block, so those
-// gathers go through the LDS pipeline instead of the vector-memory pipeline that bounds the kernel.
+// LDS-staged tables of the shading kernels: the small read-only tables every shading event gathers from - the
+// flat-colour atlas (one texel per layer), the environment's importance bins and the batch's randBase values - are
+// staged in LDS once per block, so those gathers go through the LDS pipeline instead of the vector-memory pipeline.
 #ifndef WF_LDS_ATLAS
 #define WF_LDS_ATLAS 1024
 #endif
 #ifndef WF_LDS_BINS
 #define WF_LDS_BINS 1024
 #endif
-template <bool COUNT, bool FIRST, bool LDSTAB>
-__global__ __launch_bounds__(WF_LOGIC_THREADS, FIRST ? WF_LOGIC_WAVES_FIRST : WF_LOGIC_WAVES) void k_wf_logic(const WfP p) {
-  extern __shared__ int lds_dyn[]; // FIRST: the waves' traversal stacks
-  static_assert(WF_LOGIC_THREADS % WAVE == 0, "whole waves");
+#ifndef WF_LOGIC_WAVES
+#define WF_LOGIC_WAVES 4 // 4 waves/SIMD (<= 128 VGPRs): measured best of {3, 4, 5(39 spills)} (profiles/r01)
+#endif
+
+template <bool COUNT>
+FM_DEV void flush_counters(const Counters &cnt, unsigned long long *counters, int first, int lane) {
+  if (!COUNT) return;
+  unsigned long long v[6] = {cnt.samples, cnt.rays, cnt.steps, cnt.leaves, cnt.shades, cnt.envs};
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    if (i < first) continue;
+    unsigned long long x = v[i];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+    if (lane == 0 && x) atomicAdd(counters + i, x);
+  }
+}
+
+// ---- primary: round 1 of a batch ---------------------------------------------------------------
+// camera.fs (or the injected ray buffers), the camera ray's intersectScene (in place, stack in LDS, no refill: the 64
+// lanes of a wave are 64 ticks of one pixel, so their traversals have similar lengths) and its shading, for every
+// slot of the batch: the primary ray never travels through HBM, thr / colour / flags are constants, and the VALU-bound
+// shading of some waves overlaps the memory-bound traversal of others on the same SIMD (measured +5.6 % over
+// separate gen / trace / logic launches, profiles/r01).  Survivors go to consecutive indices of state set 1.
+template <bool COUNT, bool LDSTAB>
+__global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary(const WfP p) {
+  extern __shared__ int lds_dyn[]; // the waves' traversal stacks
   constexpr int NW = WF_LOGIC_THREADS / WAVE;
-  constexpr int U = FIRST ? WF_LOGIC_U_FIRST : WF_LOGIC_U; // paths per thread between two compactions (amortises 2 barriers + 1 atomic)
-  __shared__ uint32_t s_cnt[2][U][NW];
-  __shared__ uint32_t s_base[2];
+  constexpr int U = WF_PRIMARY_U;
+  __shared__ uint32_t s_cnt[U][NW];
+  __shared__ uint32_t s_base;
   __shared__ uint32_t s_atlas[LDSTAB ? WF_LDS_ATLAS : 1];
   __shared__ uint4 s_bins[LDSTAB ? WF_LDS_BINS : 1];
   __shared__ float s_rb[LDSTAB ? WF_MAX_BATCH : 1];
@@ -1054,172 +1109,295 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, FIRST ? WF_LOGIC_WAVES_FIRST : WF
     S.bins = s_bins;
     __syncthreads();
   }
-  const uint32_t rd_i = (p.round - 1) & 1, wr_i = p.round & 1;
-  const uint32_t *__restrict__ q_in = p.q_ext[rd_i];
-  uint32_t *__restrict__ q_out = p.q_ext[wr_i];
-  uint32_t *__restrict__ q_shd_out = p.q_shd[wr_i];
-  const uint32_t n_in = FIRST ? p.n_batch * p.work_total : p.counts[p.round - 1].n_ext;
-  WfCounts *cn = p.counts + p.round;
+  const WfSet out = p.set[1];
+  const uint32_t n_in = p.n_batch * p.work_total;
+  WfCounts *cn = p.counts + 1;
   Counters cnt = {0, 0, 0, 0, 0, 0};
+  int *stack = lds_dyn + (size_t)wave * S.stack_n * WAVE + lane;
 
   const uint32_t span = (uint32_t)U * WF_LOGIC_THREADS;
   for (uint32_t base = blockIdx.x * span; base < n_in; base += gridDim.x * span) {
-    uint32_t slot_u[U];
-    unsigned long long m_surv[U], m_shd[U];
-    bool surv_u[U], shd_u[U];
+    V3 o_u[U], d_u[U];
+    float t_u[U];
+    int hit_u[U];
+    bool valid_u[U];
+    unsigned long long m_surv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t i = base + (uint32_t)u * WF_LOGIC_THREADS + threadIdx.x;
-      uint32_t s = WF_DEAD, fx = 0, fy = 0;
-      if (i < n_in) {
-        if (FIRST) {
-          s = work_to_pixel(p, i / p.n_batch, fx, fy) ? i : WF_DEAD;
+      uint32_t fx = 0, fy = 0;
+      bool valid = i < n_in && work_to_pixel(p, i / p.n_batch, fx, fy);
+      V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
+      float tB = MAX_T;
+      int hitB = -1;
+      if (valid) {
+        if (p.gen_rays) {
+          camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[i % p.n_batch], o, d);
         } else {
-          s = q_in[i];
+          float4 po = p.ray_pos[fy * p.W + fx], di = p.ray_dir[fy * p.W + fx];
+          o = v3(po.x, po.y, po.z);
+          d = v3(di.x, di.y, di.z);
         }
+        if (COUNT) cnt.samples++;
+        int hitA;
+        trace_rays<COUNT, false>(S, stack, o, false, d, d, hitA, tB, hitB, cnt);
       }
-      bool survive = false, shadow = false;
-      if (s != WF_DEAD) {
-        float4 ro, rd;
-        float2 h;
-        if (FIRST) {
-          V3 o, d;
-          if (p.gen_rays) {
-            camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[s % p.n_batch], o, d);
-          } else {
-            float4 po = p.ray_pos[fy * p.W + fx], di = p.ray_dir[fy * p.W + fx];
-            o = v3(po.x, po.y, po.z);
-            d = v3(di.x, di.y, di.z);
-          }
-          if (COUNT) cnt.samples++;
-          int hitA, hitB;
-          float tB;
-          trace_rays<COUNT>(S, lds_dyn + (size_t)wave * S.stack_n * WAVE + lane, o, false, d, d, hitA, tB, hitB, cnt);
-          ro = make_float4(o.x, o.y, o.z, 0.0f);
-          rd = make_float4(d.x, d.y, d.z, 0.0f);
-          h = make_float2(tB, __int_as_float(hitB));
-        } else {
-          ro = ld4(p.ray_o + s); rd = ld4(p.ray_d + s);
-          h = ld2(p.hit + s);
-        }
-        float4 th = make_float4(1.0f, 1.0f, 1.0f, 0.0f), co = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#if WF_COL_LAZY
-        // flags ride in ray_d.w; the colour array is only touched while the path's colour is non-zero (it is +0 until
-        // the first light arrives): no 16-byte write + read per round for paths that have not seen light yet
-        uint32_t flags = FIRST ? WF_FLAG_PRIMARY : __float_as_uint(rd.w);
-        if (!FIRST) { th = ld4(p.thr + s); if (!(flags & WF_FLAG_COLZERO)) co = ld4(p.col + s); }
-#else
-        if (!FIRST) { th = ld4(p.thr + s); co = ld4(p.col + s); }
-        uint32_t flags = FIRST ? WF_FLAG_PRIMARY : __float_as_uint(co.w);
-#endif
-        Path ps;
-        ps.ro = v3(ro.x, ro.y, ro.z);
-        ps.rd = v3(rd.x, rd.y, rd.z);
-        ps.thr = v3(th.x, th.y, th.z);
-        ps.wy = th.w;
-        ps.color = v3(co.x, co.y, co.z);
-        ps.bounce = (int)(flags & 255u);
-        ps.iters = (int)((flags >> 8) & 255u);
-        ps.primary = (flags & WF_FLAG_PRIMARY) != 0u;
-        ps.hasShadow = (flags & WF_FLAG_SHADOW) != 0u;
-        ps.pix = 0;
-        ps.wx = 0.0f;
-        ps.envDir = v3(0.0f, 0.0f, 0.0f);
-        ps.pend = v3(0.0f, 0.0f, 0.0f);
-        int hitA = -1;
-        if (ps.hasShadow) {
-          float4 sd = ld4(p.shd + s), pe = ld4(p.pend + s);
-          ps.envDir = v3(sd.x, sd.y, sd.z);
-          ps.wx = sd.w;
-          ps.pend = v3(pe.x, pe.y, pe.z);
-          hitA = ldi(p.shadow_hit + s);
-        }
-        const uint32_t j = s % p.n_batch;
-        bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), LDSTAB ? s_rb[j] : p.rb_trace[j], p.env_theta,
-                                            p.num_bounces, cnt);
-        if (finished) {
-          // park the sample colour tick-major (fin[j][w]) so that resolve reads coalesced
-          uint32_t w = s / p.n_batch;
-          st4(p.fin + (size_t)j * p.work_total + w, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
-        } else {
-          uint32_t nf = ((uint32_t)ps.bounce & 255u) | (((uint32_t)ps.iters & 255u) << 8) |
-                        (ps.hasShadow ? WF_FLAG_SHADOW : 0u);
-#if WF_COL_LAZY
-          const bool col_zero = ps.color.x == 0.0f && ps.color.y == 0.0f && ps.color.z == 0.0f;
-          if (col_zero) nf |= WF_FLAG_COLZERO;
-          st4(p.ray_o + s, make_float4(ps.ro.x, ps.ro.y, ps.ro.z, 0.0f));
-          st4(p.ray_d + s, make_float4(ps.rd.x, ps.rd.y, ps.rd.z, __uint_as_float(nf)));
-          st4(p.thr + s, make_float4(ps.thr.x, ps.thr.y, ps.thr.z, ps.wy));
-          if (!col_zero) st4(p.col + s, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
-#else
-          st4(p.ray_o + s, make_float4(ps.ro.x, ps.ro.y, ps.ro.z, 0.0f));
-          st4(p.ray_d + s, make_float4(ps.rd.x, ps.rd.y, ps.rd.z, 0.0f));
-          st4(p.thr + s, make_float4(ps.thr.x, ps.thr.y, ps.thr.z, ps.wy));
-          st4(p.col + s, make_float4(ps.color.x, ps.color.y, ps.color.z, __uint_as_float(nf)));
-#endif
-          if (ps.hasShadow) {
-            st4(p.shd + s, make_float4(ps.envDir.x, ps.envDir.y, ps.envDir.z, ps.wx));
-            st4(p.pend + s, make_float4(ps.pend.x, ps.pend.y, ps.pend.z, 0.0f));
-          }
-          survive = true;
-          shadow = ps.hasShadow;
-        }
-      }
-      slot_u[u] = s;
-      surv_u[u] = survive;
-      shd_u[u] = shadow;
-      m_surv[u] = __ballot(survive);
-      m_shd[u] = __ballot(shadow);
-      if (lane == 0) { s_cnt[0][u][wave] = (uint32_t)__popcll(m_surv[u]); s_cnt[1][u][wave] = (uint32_t)__popcll(m_shd[u]); }
+      o_u[u] = o; d_u[u] = d; t_u[u] = tB; hit_u[u] = hitB; valid_u[u] = valid;
+      // advance_path: a hit is shaded (and the path lives on) unless the bounce budget is already used up
+      m_surv[u] = __ballot(valid && hitB != -1 && p.num_bounces > 0u);
+      if (lane == 0) s_cnt[u][wave] = (uint32_t)__popcll(m_surv[u]);
     }
-    // block-aggregated append of survivors (q_ext) and their shadow rays (q_shd): ONE 64-bit atomic per
-    // U*512 paths (n_ext in the low word, n_shd in the high word; neither can overflow 32 bits)
+    // block-aggregated reservation of the survivors' state indices: ONE atomic per U*512 paths, before the shading
     __syncthreads();
     if (threadIdx.x == 0) {
-      uint32_t tot0 = 0, tot1 = 0;
+      uint32_t tot = 0;
       for (int u = 0; u < U; ++u)
-        for (int w2 = 0; w2 < NW; ++w2) {
-          uint32_t c0 = s_cnt[0][u][w2], c1 = s_cnt[1][u][w2];
-          s_cnt[0][u][w2] = tot0; s_cnt[1][u][w2] = tot1;
-          tot0 += c0; tot1 += c1;
-        }
-      unsigned long long old = 0ull;
-      if (tot0 | tot1)
-        old = atomicAdd(reinterpret_cast<unsigned long long *>(&cn->n_ext), ((unsigned long long)tot1 << 32) | tot0);
-      s_base[0] = (uint32_t)old;
-      s_base[1] = (uint32_t)(old >> 32);
+        for (int w2 = 0; w2 < NW; ++w2) { uint32_t c = s_cnt[u][w2]; s_cnt[u][w2] = tot; tot += c; }
+      s_base = tot ? atomicAdd(&cn->n_ext, tot) : 0u;
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (surv_u[u]) q_out[s_base[0] + s_cnt[0][u][wave] + lane_rank(m_surv[u])] = slot_u[u];
-      if (shd_u[u]) q_shd_out[s_base[1] + s_cnt[1][u][wave] + lane_rank(m_shd[u])] = slot_u[u];
+      if (!valid_u[u]) continue;
+      const uint32_t i = base + (uint32_t)u * WF_LOGIC_THREADS + threadIdx.x;
+      Path ps;
+      ps.ro = o_u[u]; ps.rd = d_u[u];
+      ps.thr = v3(1.0f, 1.0f, 1.0f);
+      ps.color = v3(0.0f, 0.0f, 0.0f);
+      ps.envDir = v3(0.0f, 0.0f, 0.0f);
+      ps.pend = v3(0.0f, 0.0f, 0.0f);
+      ps.wx = ps.wy = 0.0f;
+      ps.bounce = 0; ps.iters = 0; ps.pix = 0;
+      ps.hasShadow = false; ps.primary = true;
+      const uint32_t j = i % p.n_batch;
+      const bool finished = advance_path<COUNT>(S, ps, -1, t_u[u], hit_u[u], LDSTAB ? s_rb[j] : p.rb_trace[j], p.env_theta,
+                                                p.num_bounces, cnt);
+      if (finished) st4(p.fin + i, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
+      else store_path(out, s_base + s_cnt[u][wave] + lane_rank(m_surv[u]), ps, i);
     }
     __syncthreads();
   }
-  if (COUNT) {
-    unsigned long long v[6] = {cnt.samples, cnt.rays, cnt.steps, cnt.leaves, cnt.shades, cnt.envs};
-#pragma unroll
-    for (int i = FIRST ? 0 : 4; i < 6; ++i) {
-      unsigned long long x = v[i];
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
-      if (lane == 0 && x) atomicAdd(p.counters + i, x);
+  flush_counters<COUNT>(cnt, p.counters, 0, lane);
+}
+
+// ---- logic: one S step for every live path of the round (rounds >= 2) ---------------------------
+// Input: the n paths of state set (round-1)&1 with the results of their rays.  Per block iteration (U*512 paths):
+//   1  classify from 8 bytes per path (hit index + flags): a path is shaded - and survives - iff its extension ray hit
+//      something and its bounce budget is not used up (tracer.fs:446,509); everything else finishes here.  The shaded
+//      ones are listed in LDS, and ONE atomic reserves their consecutive output indices BEFORE any shading;
+//   2a every thread finishes its own non-shaded paths (NEE result, environment on a miss -> fin[slot]);
+//   2b the listed paths are shaded by consecutive threads - whole waves of shading work, instead of the 1-in-5 lanes
+//      a round-2 wave has when every thread keeps its own path (VALU lane utilisation 0.34 in round 1's profile).
+template <bool COUNT, bool LDSTAB>
+__global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(const WfP p) {
+  constexpr int U = WF_LOGIC_U;
+  __shared__ uint16_t s_list[U * WF_LOGIC_THREADS];
+  __shared__ uint32_t s_n, s_total, s_gbase;
+  __shared__ uint32_t s_atlas[LDSTAB ? WF_LDS_ATLAS : 1];
+  __shared__ uint4 s_bins[LDSTAB ? WF_LDS_BINS : 1];
+  __shared__ float s_rb[LDSTAB ? WF_MAX_BATCH : 1];
+  const int lane = threadIdx.x & (WAVE - 1);
+  DScene S = p.scene;
+  if (threadIdx.x == 0) s_n = 0;
+  if (LDSTAB) {
+    for (uint32_t i = threadIdx.x; i < S.atlas_layers; i += WF_LOGIC_THREADS) s_atlas[i] = p.scene.atlas[i];
+    for (uint32_t i = threadIdx.x; i < S.n_bins; i += WF_LOGIC_THREADS) s_bins[i] = p.scene.bins[i];
+    if (threadIdx.x < WF_MAX_BATCH) s_rb[threadIdx.x] = p.rb_trace[threadIdx.x];
+    S.atlas = s_atlas;
+    S.bins = s_bins;
+  }
+  __syncthreads();
+  const WfSet in = p.set[(p.round - 1) & 1], out = p.set[p.round & 1];
+  const uint32_t n_in = p.counts[p.round - 1].n_ext;
+  WfCounts *cn = p.counts + p.round;
+  Counters cnt = {0, 0, 0, 0, 0, 0};
+
+  // paths per thread and iteration: as many as keep every block busy, at most U
+  uint32_t u_eff = (n_in + gridDim.x * WF_LOGIC_THREADS - 1) / (gridDim.x * WF_LOGIC_THREADS);
+  u_eff = u_eff < 1u ? 1u : (u_eff > (uint32_t)U ? (uint32_t)U : u_eff);
+  const uint32_t span = u_eff * WF_LOGIC_THREADS;
+  for (uint32_t base = blockIdx.x * span; base < n_in; base += gridDim.x * span) {
+    // ---- 1: classify ----
+    uint32_t own_fin = 0; // bit u: own path u finishes in this round (handled in 2a)
+    for (uint32_t u = 0; u < u_eff; ++u) {
+      const uint32_t loc = u * WF_LOGIC_THREADS + threadIdx.x;
+      const uint32_t i = base + loc;
+      bool shade = false;
+      if (i < n_in) {
+        const int hidx = __float_as_int(ld2(p.hit + i).y);
+        const uint32_t flags = __float_as_uint(in.B[i].w);
+        shade = hidx != -1 && (flags & 255u) < p.num_bounces && ((flags >> 8) & 255u) < (uint32_t)MAX_PATH_ITERS;
+        if (!shade) own_fin |= 1u << u;
+      }
+      const unsigned long long m = __ballot(shade);
+      uint32_t wb = 0;
+      if (lane == 0 && m) wb = atomicAdd(&s_n, (uint32_t)__popcll(m));
+      wb = __builtin_amdgcn_readfirstlane(wb);
+      if (shade) s_list[wb + lane_rank(m)] = (uint16_t)loc;
+    }
+    __syncthreads();
+    uint32_t my_gbase = 0;
+    if (threadIdx.x == 0) {
+      const uint32_t tot = s_n;
+      s_total = tot;
+      s_n = 0;
+      my_gbase = tot ? atomicAdd(&cn->n_ext, tot) : 0u; // consumed after phase 2a, which covers its round trip
+    }
+    // ---- 2a (own finishing paths) then 2b (listed paths, dense) through ONE copy of the path code ----
+    uint32_t n_shade = 0, gbase = 0;
+    for (uint32_t jt = 0;; ++jt) {
+      uint32_t i = 0, k_out = 0;
+      bool active = false;
+      if (jt < u_eff) {
+        i = base + jt * WF_LOGIC_THREADS + threadIdx.x;
+        active = (own_fin >> jt) & 1u;
+      } else {
+        if (jt == u_eff) {
+          if (threadIdx.x == 0) s_gbase = my_gbase;
+          __syncthreads();
+          n_shade = s_total;
+          gbase = s_gbase;
+        }
+        const uint32_t tsh = (jt - u_eff) * WF_LOGIC_THREADS + threadIdx.x;
+        if ((jt - u_eff) * WF_LOGIC_THREADS >= n_shade) break; // block-uniform
+        active = tsh < n_shade;
+        if (active) { i = base + s_list[tsh]; k_out = gbase + tsh; }
+      }
+      if (active) {
+        Path ps;
+        int hitA;
+        const uint32_t slot = load_path(in, i, ps, p.shadow_hit, hitA);
+        const float2 h = ld2(p.hit + i);
+        const uint32_t j = slot % p.n_batch;
+        const bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), LDSTAB ? s_rb[j] : p.rb_trace[j],
+                                                  p.env_theta, p.num_bounces, cnt);
+        if (finished) st4(p.fin + slot, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
+        else store_path(out, k_out, ps, slot);
+      }
+    }
+    __syncthreads(); // s_list / s_total are rewritten by the next iteration
+  }
+  flush_counters<COUNT>(cnt, p.counters, 4, lane);
+}
+
+// ---- tail: the live paths of a late round run to completion in ONE kernel ------------------------
+// After a few rounds only a few thousand paths are alive, and every further round costs a trace launch as long as its
+// longest ray plus a logic launch plus two launch gaps (~220 us per round at 1080p, whatever the path count).  This
+// kernel takes the survivors of round p.round and alternates T (trace the lane's shadow + extension ray) and S
+// (advance_path) per lane until the path ends, refilling finished lanes from the list: the rounds are no longer
+// synchronised, so the cost is the longest PATH, not the sum over rounds of the longest rays.  It also ends paths that
+// refraction keeps alive beyond NUM_BOUNCES rounds (tracer.fs:488) without any host round trip.
+template <bool COUNT, bool ANYHIT>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_wf_tail(const WfP p) {
+  extern __shared__ int lds_stack[];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const DScene &S = p.scene;
+  int *stack = lds_stack + (size_t)wave * S.stack_n * WAVE + lane;
+  const WfSet in = p.set[p.round & 1];
+  WfCounts *cn = p.counts + p.round;
+  const uint32_t total = cn->n_ext;
+  Counters cnt = {0, 0, 0, 0, 0, 0};
+  Path ps;
+  ps.pix = -1;
+  uint32_t slot = 0;
+  // pool as in k_wf_trace: every wave's first 64 paths are its own, the rest is dealt out by one head
+  const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
+  const uint32_t wave_id = blockIdx.x * WAVES_PER_BLOCK + wave;
+  uint32_t pool_next = min(wave_id * WAVE, total), pool_end = min(wave_id * WAVE + WAVE, total);
+  bool exhausted = total <= n_waves * WAVE;
+  while (true) {
+    // ---- refill idle lanes with paths of the list ----
+    while (true) {
+      unsigned long long need = __ballot(ps.pix < 0);
+      if (need == 0ull) break;
+      uint32_t avail = pool_end - pool_next;
+      if (avail == 0u) {
+        if (exhausted) break;
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&cn->head[0], (uint32_t)WAVE);
+        b = __builtin_amdgcn_readfirstlane(b) + n_waves * WAVE;
+        if (b >= total) { exhausted = true; break; }
+        pool_next = b;
+        pool_end = min(b + (uint32_t)WAVE, total);
+        continue;
+      }
+      uint32_t rank = lane_rank(need);
+      uint32_t want = (uint32_t)__popcll(need);
+      uint32_t take = want < avail ? want : avail;
+      if (ps.pix < 0 && rank < take) {
+        int unused;
+        slot = load_path(in, pool_next + rank, ps, nullptr, unused);
+        ps.pix = 0;
+      }
+      pool_next += take;
+    }
+    if (__ballot(ps.pix >= 0) == 0ull) break;
+    if (ps.pix >= 0) {
+      // T: the lane's pending rays;  S: consume them
+      int hitA, hitB;
+      float tB;
+      trace_rays<COUNT, ANYHIT>(S, stack, ps.ro, ps.hasShadow, ps.envDir, ps.rd, hitA, tB, hitB, cnt);
+      if (advance_path<COUNT>(S, ps, hitA, tB, hitB, p.rb_trace[slot % p.n_batch], p.env_theta, p.num_bounces, cnt)) {
+        st4(p.fin + slot, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
+        ps.pix = -1;
+      }
     }
   }
+  flush_counters<COUNT>(cnt, p.counters, 1, lane);
 }
 
 // ---- resolve: tracer.fs:515-517 for the batch's ticks in order, per pixel --------------
+// fin is slot-major (pixel-major): a wave reads 8 ticks of 64 pixels as full 128-byte segments, transposes them
+// through LDS and every lane folds its pixel's ticks in order (the running mean is order-dependent).
+#define WF_RESOLVE_TICKS 8
 __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
-  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < p.work_total; w += gridDim.x * blockDim.x) {
+  __shared__ float4 s_t[WAVES_PER_BLOCK][WAVE * (WF_RESOLVE_TICKS + 1)];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  for (uint32_t wb = blockIdx.x * BLOCK_THREADS; wb < p.work_total; wb += gridDim.x * BLOCK_THREADS) { // block-uniform trip count
+    const uint32_t w0 = wb + (uint32_t)wave * WAVE;
+    const uint32_t w = w0 + lane;
+    uint32_t x = 0, y = 0;
+    const bool ok = w < p.work_total && work_to_pixel(p, w, x, y);
+    const uint32_t pix = y * p.W + x;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (ok) acc = p.accum[pix];
+    for (uint32_t j0 = 0; j0 < p.n_batch; j0 += WF_RESOLVE_TICKS) {
+      const uint32_t tt = j0 + ((uint32_t)lane & (WF_RESOLVE_TICKS - 1));
+#pragma unroll
+      for (int q = 0; q < WF_RESOLVE_TICKS; ++q) {
+        const uint32_t pp = (uint32_t)q * (WAVE / WF_RESOLVE_TICKS) + ((uint32_t)lane / WF_RESOLVE_TICKS);
+        const uint32_t w2 = w0 + pp;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (w2 < p.work_total && tt < p.n_batch) v = ld4(p.fin + (size_t)w2 * p.n_batch + tt);
+        s_t[wave][pp * (WF_RESOLVE_TICKS + 1) + ((uint32_t)lane & (WF_RESOLVE_TICKS - 1))] = v;
+      }
+      __syncthreads();
+      if (ok) {
+#pragma unroll
+        for (int jj = 0; jj < WF_RESOLVE_TICKS; ++jj) {
+          if (j0 + jj < p.n_batch) {
+            const float4 c = s_t[wave][lane * (WF_RESOLVE_TICKS + 1) + jj];
+            acc = accumulate_sample(acc, v3(c.x, c.y, c.z), p.first_tick + j0 + jj);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (ok) p.accum[pix] = acc;
+  }
+}
+
+// multi-device read-out (fspt_multi_read_radiance): pack a shard's own pixels into work-index order / scatter them back
+template <bool UNPACK>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_tile_pack(const TilePackP p) {
+  const uint32_t n = p.n_owned_tiles * p.tile * p.tile;
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
     uint32_t x, y;
     if (!work_to_pixel(p, w, x, y)) continue;
-    uint32_t pix = y * p.W + x;
-    float4 acc = p.accum[pix];
-    for (uint32_t j = 0; j < p.n_batch; ++j) {
-      float4 c = ld4(p.fin + (size_t)j * p.work_total + w);
-      acc = accumulate_sample(acc, v3(c.x, c.y, c.z), p.first_tick + j);
-    }
-    p.accum[pix] = acc;
+    if (UNPACK) p.accum[(size_t)y * p.W + x] = p.packed[w];
+    else p.packed[w] = p.accum[(size_t)y * p.W + x];
   }
 }
 
@@ -1305,7 +1483,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_intersect(const IntersectP p)
   Counters cnt = {0, 0, 0, 0, 0, 0};
   int hitA, hitB;
   float tB;
-  trace_rays<true>(p.scene, stack, o, false, d, d, hitA, tB, hitB, cnt);
+  trace_rays<true, false>(p.scene, stack, o, false, d, d, hitA, tB, hitB, cnt);
   p.t_out[i] = tB;
   p.index_out[i] = hitB;
   if (p.steps_out) p.steps_out[i] = cnt.steps;
@@ -1328,7 +1506,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_bvh_test(const TraceP p) {
   Counters cnt = {0, 0, 0, 0, 0, 0};
   int hitA, hitB;
   float tB;
-  trace_rays<true>(p.scene, stack, o, false, d, d, hitA, tB, hitB, cnt);
+  trace_rays<true, false>(p.scene, stack, o, false, d, d, hitA, tB, hitB, cnt);
   float c = (float)cnt.steps * 0.001f;
   float ft = (float)p.tick, den = ft + 1.0f;
   float4 prev = p.accum[pix], o4;
@@ -1363,6 +1541,13 @@ __global__ void k_math(int op, const float *a, const float *b, uint32_t n, float
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+// Stacks deeper than the default 64 KB of dynamic LDS (trees deeper than ~31 levels under a 512-thread block) need the
+// per-kernel opt-in; gfx950 has 160 KB per CU.
+template <class K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 48u * 1024u) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 static size_t stack_bytes(const DScene &S) { return (size_t)WAVES_PER_BLOCK * S.stack_n * WAVE * sizeof(int); }
 
 hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream) {
@@ -1375,21 +1560,30 @@ hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus,
   if (grid > max_useful) grid = max_useful;
   if (grid == 0) return hipSuccess;
   dim3 g(grid), b(BLOCK_THREADS);
-  if (gen_rays) {
-    if (count) hipLaunchKernelGGL((k_trace<true, true>), g, b, lds, stream, p);
-    else hipLaunchKernelGGL((k_trace<true, false>), g, b, lds, stream, p);
-  } else {
-    if (count) hipLaunchKernelGGL((k_trace<false, true>), g, b, lds, stream, p);
-    else hipLaunchKernelGGL((k_trace<false, false>), g, b, lds, stream, p);
-  }
+  hipError_t e;
+#define FSPT_LAUNCH_MEGA(G, C)                                                              \
+  do {                                                                                        \
+    if ((e = allow_lds(k_trace<G, C>, lds)) != hipSuccess) return e;                          \
+    hipLaunchKernelGGL((k_trace<G, C>), g, b, lds, stream, p);                                \
+  } while (0)
+  if (gen_rays) { if (count) FSPT_LAUNCH_MEGA(true, true); else FSPT_LAUNCH_MEGA(true, false); }
+  else { if (count) FSPT_LAUNCH_MEGA(false, true); else FSPT_LAUNCH_MEGA(false, false); }
+#undef FSPT_LAUNCH_MEGA
   return hipGetLastError();
 }
 
-hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int num_cus, hipStream_t stream) {
+size_t wf_max_stack_entries() {
+  // the largest LDS user per stack entry is the primary launch: 8 waves x 256 B per entry next to ~22 KB of staged tables
+  const size_t lds_cu = 160u * 1024u, tables = 24u * 1024u;
+  return (lds_cu - tables) / ((WF_LOGIC_THREADS / WAVE) * WAVE * sizeof(int));
+}
+
+hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream_t stream) {
   const uint32_t total = p.n_batch * p.work_total;
   if (total == 0) return hipSuccess;
+  hipError_t e = hipSuccess;
   if (kernel == WF_K_TRACE) {
-    // persistent: the grid only has to fill the machine; the pool head balances the work
+    // persistent: the grid only has to fill the machine; the pool heads balance the work
     uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
     size_t lds = stack_bytes(p.scene);
     // LDS left over per block at the occupancy the stacks (and the registers: 7 blocks) allow -> top-of-tree cache
@@ -1404,26 +1598,59 @@ hipError_t launch_wf(int kernel, const WfP &p, bool gen_rays, bool count, int nu
       q.lds_top = WF_TRACE_LDS_TOP ? min(min(fit, p.scene.n_top), (uint32_t)WF_TRACE_LDS_TOP) : 0u;
       lds += (size_t)q.lds_top * NODE_F4 * sizeof(float4);
     }
-    if (count) hipLaunchKernelGGL((k_wf_trace<true>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, q);
-    else hipLaunchKernelGGL((k_wf_trace<false>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, q);
-  } else if (kernel == WF_K_LOGIC || kernel == WF_K_PRIMARY) { // PRIMARY = the logic kernel's round-1 specialisation
+#define FSPT_LAUNCH_TRACE(C, A)                                                                            \
+    do {                                                                                                     \
+      if ((e = allow_lds(k_wf_trace<C, A>, lds)) != hipSuccess) return e;                                    \
+      hipLaunchKernelGGL((k_wf_trace<C, A>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, q);               \
+    } while (0)
+    if (count == 1) FSPT_LAUNCH_TRACE(true, false);
+    else if (count == 2) FSPT_LAUNCH_TRACE(true, true);
+    else FSPT_LAUNCH_TRACE(false, true);
+#undef FSPT_LAUNCH_TRACE
+  } else if (kernel == WF_K_TAIL) {
+    uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 3u);
+    size_t lds = stack_bytes(p.scene);
+#define FSPT_LAUNCH_TAIL(C, A)                                                                             \
+    do {                                                                                                     \
+      if ((e = allow_lds(k_wf_tail<C, A>, lds)) != hipSuccess) return e;                                     \
+      hipLaunchKernelGGL((k_wf_tail<C, A>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);                \
+    } while (0)
+    if (count == 1) FSPT_LAUNCH_TAIL(true, false);
+    else if (count == 2) FSPT_LAUNCH_TAIL(true, true);
+    else FSPT_LAUNCH_TAIL(false, true);
+#undef FSPT_LAUNCH_TAIL
+  } else if (kernel == WF_K_LOGIC || kernel == WF_K_PRIMARY) {
     uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * 4u);
-    const bool first = (kernel == WF_K_PRIMARY);
-    const bool lds = WF_LOGIC_LDSTAB && p.scene.atlas_res == 1u && p.scene.atlas_layers <= WF_LDS_ATLAS && p.scene.n_bins <= WF_LDS_BINS;
-    const size_t dyn = first ? (size_t)(WF_LOGIC_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int) : 0;
-#define FSPT_LAUNCH_LOGIC(C, F, T) hipLaunchKernelGGL((k_wf_logic<C, F, T>), dim3(grid), dim3(WF_LOGIC_THREADS), dyn, stream, p)
-    if (count) {
-      if (first) { if (lds) FSPT_LAUNCH_LOGIC(true, true, true); else FSPT_LAUNCH_LOGIC(true, true, false); }
-      else { if (lds) FSPT_LAUNCH_LOGIC(true, false, true); else FSPT_LAUNCH_LOGIC(true, false, false); }
+    const bool tab = WF_LOGIC_LDSTAB && p.scene.atlas_res == 1u && p.scene.atlas_layers <= WF_LDS_ATLAS && p.scene.n_bins <= WF_LDS_BINS;
+    if (kernel == WF_K_PRIMARY) {
+      const size_t dyn = (size_t)(WF_LOGIC_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int);
+#define FSPT_LAUNCH_PRIMARY(C, T)                                                                          \
+      do {                                                                                                   \
+        if ((e = allow_lds(k_wf_primary<C, T>, dyn)) != hipSuccess) return e;                                \
+        hipLaunchKernelGGL((k_wf_primary<C, T>), dim3(grid), dim3(WF_LOGIC_THREADS), dyn, stream, p);        \
+      } while (0)
+      if (count) { if (tab) FSPT_LAUNCH_PRIMARY(true, true); else FSPT_LAUNCH_PRIMARY(true, false); }
+      else { if (tab) FSPT_LAUNCH_PRIMARY(false, true); else FSPT_LAUNCH_PRIMARY(false, false); }
+#undef FSPT_LAUNCH_PRIMARY
     } else {
-      if (first) { if (lds) FSPT_LAUNCH_LOGIC(false, true, true); else FSPT_LAUNCH_LOGIC(false, true, false); }
-      else { if (lds) FSPT_LAUNCH_LOGIC(false, false, true); else FSPT_LAUNCH_LOGIC(false, false, false); }
-    }
+#define FSPT_LAUNCH_LOGIC(C, T) hipLaunchKernelGGL((k_wf_logic<C, T>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p)
+      if (count) { if (tab) FSPT_LAUNCH_LOGIC(true, true); else FSPT_LAUNCH_LOGIC(true, false); }
+      else { if (tab) FSPT_LAUNCH_LOGIC(false, true); else FSPT_LAUNCH_LOGIC(false, false); }
 #undef FSPT_LAUNCH_LOGIC
+    }
   } else {
     uint32_t grid = min((p.work_total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 16u);
     hipLaunchKernelGGL(k_wf_resolve, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_tile_pack(const TilePackP &p, bool unpack, hipStream_t stream) {
+  const uint32_t n = p.n_owned_tiles * p.tile * p.tile;
+  if (n == 0) return hipSuccess;
+  const uint32_t grid = min((n + BLOCK_THREADS - 1) / BLOCK_THREADS, 4096u);
+  if (unpack) hipLaunchKernelGGL(k_tile_pack<true>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
+  else hipLaunchKernelGGL(k_tile_pack<false>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
   return hipGetLastError();
 }
 
@@ -1446,6 +1673,8 @@ hipError_t launch_draw(const float4 *acc, uint32_t W, uint32_t H, float exposure
 hipError_t launch_bvh_test(const TraceP &p, hipStream_t stream) {
   uint32_t n = p.n_owned_tiles * p.tile * p.tile;
   if (n == 0) return hipSuccess;
+  hipError_t e = allow_lds(k_bvh_test, stack_bytes(p.scene));
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_bvh_test, dim3((n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS), stack_bytes(p.scene),
                      stream, p);
   return hipGetLastError();
@@ -1453,6 +1682,8 @@ hipError_t launch_bvh_test(const TraceP &p, hipStream_t stream) {
 
 hipError_t launch_intersect(const IntersectP &p, hipStream_t stream) {
   if (p.n == 0) return hipSuccess;
+  hipError_t e = allow_lds(k_intersect, stack_bytes(p.scene));
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_intersect, dim3((p.n + BLOCK_THREADS - 1) / BLOCK_THREADS), dim3(BLOCK_THREADS),
                      stack_bytes(p.scene), stream, p);
   return hipGetLastError();

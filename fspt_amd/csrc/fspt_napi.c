@@ -18,7 +18,11 @@
  *   readRadiance(target, Float32Array(W*H*4))                        (what draw.fs:87 reads)
  *   draw(target, exposure, saturation, denoise, maxSigma, Uint8Array(W*H*4))   (drawQuad, main.js:809-824)
  *   setShard(target, shard, nShards, tile) / setPipeline(target, pipeline, batch)
- *   setMemoryLimit(target, bytes) / pathStateBytes(target) -> {bytes, batchTicks} / prepare(target)
+ *   setMemoryLimit(target, bytes) / pathStateBytes(target) -> {bytes, batchTicks} / prepare(target) / setTail(target, round)
+ *   renderAsync(target, params, firstTick, nTicks, seed) -> Promise   (fspt_render + fspt_sync as napi_async_work)
+ *   multiCreate(sceneDesc, [devices], W, H) -> multi handle; multiCamera / multiTrace / multiRender / multiRenderAsync /
+ *   multiClear / multiSync / multiReadRadiance / multiDraw / multiTarget(multi, i) / multiDestroy   (fspt_multi_*: one frame
+ *   over several GPUs from this one JS thread, tiles gathered onto the first device at read-out)
  *   enableCounters(target, on) / counters(target) -> object
  *   builderCreate / builderParseObj / builderCommit / builderNormalize / builderBuild / builderAutofocus /
  *   builderDestroy                                                   (native obj_loader.js + bvh.js, 1:1 fspt_builder_*)
@@ -133,43 +137,49 @@ static int unwrap(napi_env env, napi_value v, void **out) {
 }
 
 /* ------------------------------------------------------------------ scene */
+/* {bvh, tri, mat, norm, uv, atlas, atlasRes, atlasLayers, env, envW, envH, bins, leafSize} -> fspt_scene_desc viewing
+ * the TypedArrays (valid while the JS object is alive, i.e. for the duration of the call) */
+static int parse_scene_desc(napi_env env, napi_value obj, fspt_scene_desc *d) {
+  memset(d, 0, sizeof(*d));
+  napi_value v; void *p; size_t n;
+  if (prop(env, obj, "bvh", &v) || typed(env, v, napi_float32_array, 0, &p, &n)) return -1;
+  d->bvh = (const float *)p; d->n_nodes = (uint32_t)(n / 9);
+  if (prop(env, obj, "tri", &v) || typed(env, v, napi_float32_array, 0, &p, &n)) return -1;
+  d->tri = (const float *)p; d->n_tris = (uint32_t)(n / 9);
+  size_t nm, nn, nu;
+  if (prop(env, obj, "mat", &v) || typed(env, v, napi_float32_array, 0, &p, &nm)) return -1;
+  d->mat = (const float *)p;
+  if (prop(env, obj, "norm", &v) || typed(env, v, napi_float32_array, 0, &p, &nn)) return -1;
+  d->norm = (const float *)p;
+  if (prop(env, obj, "uv", &v) || typed(env, v, napi_float32_array, 0, &p, &nu)) return -1;
+  d->uv = (const float *)p;
+  if (nm != (size_t)d->n_tris * 12 || nn != (size_t)d->n_tris * 27 || nu != (size_t)d->n_tris * 6) {
+    napi_throw_range_error(env, NULL, "fspt_napi: mat/norm/uv lengths do not match tri (12/27/6 floats per triangle)");
+    return -1;
+  }
+  if (prop(env, obj, "atlas", &v) || typed(env, v, napi_uint8_array, 0, &p, &n)) return -1;
+  d->atlas = (const uint8_t *)p;
+  if (prop_u32(env, obj, "atlasRes", &d->atlas_res) || prop_u32(env, obj, "atlasLayers", &d->atlas_layers)) return -1;
+  if (n != (size_t)d->atlas_res * d->atlas_res * d->atlas_layers * 4) {
+    napi_throw_range_error(env, NULL, "fspt_napi: atlas length != atlasRes^2 * atlasLayers * 4");
+    return -1;
+  }
+  if (prop(env, obj, "env", &v) || typed(env, v, napi_uint8_array, 1, &p, &n)) return -1;
+  d->env = (const uint8_t *)p;
+  if (d->env) {
+    if (prop_u32(env, obj, "envW", &d->env_w) || prop_u32(env, obj, "envH", &d->env_h)) return -1;
+    if (n != (size_t)d->env_w * d->env_h * 4) { napi_throw_range_error(env, NULL, "fspt_napi: env length != envW*envH*4"); return -1; }
+  }
+  if (prop(env, obj, "bins", &v) || typed(env, v, napi_uint32_array, 0, &p, &n)) return -1;
+  d->bins = (const uint32_t *)p; d->n_bins = (uint32_t)(n / 4);
+  if (prop_u32(env, obj, "leafSize", &d->leaf_size)) return -1;
+  return 0;
+}
 static napi_value SceneCreate(napi_env env, napi_callback_info info) {
   napi_value a[2];
   if (get_args(env, info, 2, a)) return NULL;
   fspt_scene_desc d;
-  memset(&d, 0, sizeof(d));
-  napi_value v; void *p; size_t n;
-  if (prop(env, a[0], "bvh", &v) || typed(env, v, napi_float32_array, 0, &p, &n)) return NULL;
-  d.bvh = (const float *)p; d.n_nodes = (uint32_t)(n / 9);
-  if (prop(env, a[0], "tri", &v) || typed(env, v, napi_float32_array, 0, &p, &n)) return NULL;
-  d.tri = (const float *)p; d.n_tris = (uint32_t)(n / 9);
-  size_t nm, nn, nu;
-  if (prop(env, a[0], "mat", &v) || typed(env, v, napi_float32_array, 0, &p, &nm)) return NULL;
-  d.mat = (const float *)p;
-  if (prop(env, a[0], "norm", &v) || typed(env, v, napi_float32_array, 0, &p, &nn)) return NULL;
-  d.norm = (const float *)p;
-  if (prop(env, a[0], "uv", &v) || typed(env, v, napi_float32_array, 0, &p, &nu)) return NULL;
-  d.uv = (const float *)p;
-  if (nm != (size_t)d.n_tris * 12 || nn != (size_t)d.n_tris * 27 || nu != (size_t)d.n_tris * 6) {
-    napi_throw_range_error(env, NULL, "fspt_napi: mat/norm/uv lengths do not match tri (12/27/6 floats per triangle)");
-    return NULL;
-  }
-  if (prop(env, a[0], "atlas", &v) || typed(env, v, napi_uint8_array, 0, &p, &n)) return NULL;
-  d.atlas = (const uint8_t *)p;
-  if (prop_u32(env, a[0], "atlasRes", &d.atlas_res) || prop_u32(env, a[0], "atlasLayers", &d.atlas_layers)) return NULL;
-  if (n != (size_t)d.atlas_res * d.atlas_res * d.atlas_layers * 4) {
-    napi_throw_range_error(env, NULL, "fspt_napi: atlas length != atlasRes^2 * atlasLayers * 4");
-    return NULL;
-  }
-  if (prop(env, a[0], "env", &v) || typed(env, v, napi_uint8_array, 1, &p, &n)) return NULL;
-  d.env = (const uint8_t *)p;
-  if (d.env) {
-    if (prop_u32(env, a[0], "envW", &d.env_w) || prop_u32(env, a[0], "envH", &d.env_h)) return NULL;
-    if (n != (size_t)d.env_w * d.env_h * 4) { napi_throw_range_error(env, NULL, "fspt_napi: env length != envW*envH*4"); return NULL; }
-  }
-  if (prop(env, a[0], "bins", &v) || typed(env, v, napi_uint32_array, 0, &p, &n)) return NULL;
-  d.bins = (const uint32_t *)p; d.n_bins = (uint32_t)(n / 4);
-  if (prop_u32(env, a[0], "leafSize", &d.leaf_size)) return NULL;
+  if (parse_scene_desc(env, a[0], &d)) return NULL;
   int32_t device = 0;
   napi_get_value_int32(env, a[1], &device);
   fspt_scene *s = NULL;
@@ -229,37 +239,216 @@ static napi_value Trace(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_trace((fspt_target *)h, tick, (float)rb, (float)theta, nb));
   return undefined(env);
 }
+static int parse_camera_params(napi_env env, napi_value obj, fspt_camera_params *cp) {
+  napi_value v; double d;
+  memset(cp, 0, sizeof(*cp));
+  if (prop(env, obj, "P", &v) || float_list(env, v, cp->P, 3)) return -1;
+  if (prop(env, obj, "I", &v) || float_list(env, v, cp->I, 3)) return -1;
+  if (prop(env, obj, "lens", &v) || float_list(env, v, cp->lens, 2)) return -1;
+  if (prop_f64(env, obj, "fovScale", 0.5, &d)) return -1;
+  cp->fov_scale = (float)d;
+  if (prop_f64(env, obj, "envTheta", 0.0, &d)) return -1;
+  cp->env_theta = (float)d;
+  napi_value nbv; napi_valuetype nbt = napi_undefined;
+  cp->num_bounces = 4; /* tracer.fs:9 */
+  if (napi_get_named_property(env, obj, "numBounces", &nbv) == napi_ok) napi_typeof(env, nbv, &nbt);
+  if (nbt != napi_undefined && nbt != napi_null && get_bounces(env, nbv, &cp->num_bounces)) return -1;
+  return 0;
+}
+/* seed: BigInt (full 64-bit xorshift state) or a number < 2^53 */
+static int parse_seed(napi_env env, napi_value v, uint64_t *seed64) {
+  napi_valuetype st;
+  napi_typeof(env, v, &st);
+  if (st == napi_bigint) {
+    bool lossless = true;
+    if (napi_get_value_bigint_uint64(env, v, seed64, &lossless) != napi_ok) { napi_throw_type_error(env, NULL, "fspt_napi: bad seed"); return -1; }
+    return 0;
+  }
+  double seed;
+  if (get_f64(env, v, &seed)) return -1;
+  *seed64 = (uint64_t)seed;
+  return 0;
+}
 static napi_value Render(napi_env env, napi_callback_info info) {
-  napi_value a[5], v; void *h; uint32_t first, n; double seed, d;
+  napi_value a[5]; void *h; uint32_t first, n; uint64_t seed64 = 0;
   if (get_args(env, info, 5, a)) return NULL;
   fspt_camera_params cp;
-  memset(&cp, 0, sizeof(cp));
-  if (prop(env, a[1], "P", &v) || float_list(env, v, cp.P, 3)) return NULL;
-  if (prop(env, a[1], "I", &v) || float_list(env, v, cp.I, 3)) return NULL;
-  if (prop(env, a[1], "lens", &v) || float_list(env, v, cp.lens, 2)) return NULL;
-  if (prop_f64(env, a[1], "fovScale", 0.5, &d)) return NULL; cp.fov_scale = (float)d;
-  if (prop_f64(env, a[1], "envTheta", 0.0, &d)) return NULL; cp.env_theta = (float)d;
-  {
-    napi_value nbv; napi_valuetype nbt = napi_undefined;
-    cp.num_bounces = 4; /* tracer.fs:9 */
-    if (napi_get_named_property(env, a[1], "numBounces", &nbv) == napi_ok) napi_typeof(env, nbv, &nbt);
-    if (nbt != napi_undefined && nbt != napi_null && get_bounces(env, nbv, &cp.num_bounces)) return NULL;
-  }
+  if (parse_camera_params(env, a[1], &cp)) return NULL;
   if (unwrap(env, a[0], &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[2], &first));
   NAPI_OK(napi_get_value_uint32(env, a[3], &n));
-  /* seed: BigInt (full 64-bit xorshift state) or a number < 2^53 */
-  uint64_t seed64 = 0;
-  napi_valuetype st;
-  napi_typeof(env, a[4], &st);
-  if (st == napi_bigint) {
-    bool lossless = true;
-    NAPI_OK(napi_get_value_bigint_uint64(env, a[4], &seed64, &lossless));
-  } else {
-    if (get_f64(env, a[4], &seed)) return NULL;
-    seed64 = (uint64_t)seed;
-  }
+  if (parse_seed(env, a[4], &seed64)) return NULL;
   FSPT_OK_OR_THROW(fspt_render((fspt_target *)h, &cp, first, n, seed64));
+  return undefined(env);
+}
+
+/* renderAsync(target, params, firstTick, nTicks, seed) -> Promise<undefined>
+ * fspt_render + fspt_sync on a libuv worker thread (napi_async_work), so an interactive host keeps its event loop
+ * while a long batch runs.  The caller must not touch the target until the promise settles: all calls for
+ * one target still come from one thread AT A TIME (include/fspt.h). */
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  fspt_target *target;
+  fspt_multi *multi;
+  fspt_camera_params cp;
+  uint32_t first, n;
+  uint64_t seed;
+  int rc;
+  char err[600];
+} render_job;
+static void render_execute(napi_env env, void *data) {
+  (void)env;
+  render_job *j = (render_job *)data;
+  if (j->multi) {
+    j->rc = fspt_multi_render(j->multi, &j->cp, j->first, j->n, j->seed);
+    if (j->rc == 0) j->rc = fspt_multi_sync(j->multi);
+  } else {
+    j->rc = fspt_render(j->target, &j->cp, j->first, j->n, j->seed);
+    if (j->rc == 0) j->rc = fspt_sync(j->target);
+  }
+  /* fspt_last_error() is thread-local: fetch it on the thread that made the call */
+  if (j->rc != 0) snprintf(j->err, sizeof(j->err), "libfspt error %d: %s", j->rc, fspt_last_error());
+}
+static void render_complete(napi_env env, napi_status status, void *data) {
+  render_job *j = (render_job *)data;
+  napi_value v;
+  if (status == napi_ok && j->rc == 0) {
+    napi_get_undefined(env, &v);
+    napi_resolve_deferred(env, j->deferred, v);
+  } else {
+    napi_value msg;
+    napi_create_string_utf8(env, status == napi_ok ? j->err : "fspt_napi: async work cancelled", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &v);
+    napi_reject_deferred(env, j->deferred, v);
+  }
+  napi_delete_async_work(env, j->work);
+  free(j);
+}
+static napi_value render_async(napi_env env, napi_callback_info info, int multi) {
+  napi_value a[5], promise, name; void *h; uint64_t seed64 = 0;
+  if (get_args(env, info, 5, a)) return NULL;
+  render_job *j = (render_job *)calloc(1, sizeof(render_job));
+  if (!j) { napi_throw_error(env, NULL, "fspt_napi: out of memory"); return NULL; }
+  if (parse_camera_params(env, a[1], &j->cp) || unwrap(env, a[0], &h) || parse_seed(env, a[4], &seed64) ||
+      napi_get_value_uint32(env, a[2], &j->first) != napi_ok || napi_get_value_uint32(env, a[3], &j->n) != napi_ok) {
+    bool pending = false;
+    napi_is_exception_pending(env, &pending);
+    if (!pending) napi_throw_type_error(env, NULL, "fspt_napi: renderAsync(target, params, firstTick, nTicks, seed)");
+    free(j);
+    return NULL;
+  }
+  if (multi) j->multi = (fspt_multi *)h; else j->target = (fspt_target *)h;
+  j->seed = seed64;
+  if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+      napi_create_string_utf8(env, "fspt_render", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+      napi_create_async_work(env, NULL, name, render_execute, render_complete, j, &j->work) != napi_ok ||
+      napi_queue_async_work(env, j->work) != napi_ok) {
+    free(j);
+    napi_throw_error(env, NULL, "fspt_napi: could not queue the async work");
+    return NULL;
+  }
+  return promise;
+}
+static napi_value RenderAsync(napi_env env, napi_callback_info info) { return render_async(env, info, 0); }
+static napi_value MultiRenderAsync(napi_env env, napi_callback_info info) { return render_async(env, info, 1); }
+
+/* ------------------------------------------------------- several devices (fspt_multi_*) */
+static napi_value MultiCreate(napi_env env, napi_callback_info info) {
+  /* multiCreate(sceneDesc, [device, ...], W, H) */
+  napi_value a[4]; uint32_t n = 0, W, H; int devices[64];
+  if (get_args(env, info, 4, a)) return NULL;
+  fspt_scene_desc d;
+  if (parse_scene_desc(env, a[0], &d)) return NULL;
+  if (napi_get_array_length(env, a[1], &n) != napi_ok || n == 0 || n > 64) { napi_throw_range_error(env, NULL, "fspt_napi: devices must be an array of 1..64 ordinals"); return NULL; }
+  for (uint32_t i = 0; i < n; ++i) {
+    napi_value e; int32_t v;
+    if (napi_get_element(env, a[1], i, &e) != napi_ok || napi_get_value_int32(env, e, &v) != napi_ok) { napi_throw_type_error(env, NULL, "fspt_napi: device ordinals must be numbers"); return NULL; }
+    devices[i] = v;
+  }
+  NAPI_OK(napi_get_value_uint32(env, a[2], &W));
+  NAPI_OK(napi_get_value_uint32(env, a[3], &H));
+  fspt_multi *m = NULL;
+  FSPT_OK_OR_THROW(fspt_multi_create(&d, devices, n, W, H, &m));
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, m, NULL, NULL, &ext));
+  return ext;
+}
+static napi_value MultiDestroy(napi_env env, napi_callback_info info) {
+  napi_value a[1]; void *h;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  FSPT_OK_OR_THROW(fspt_multi_destroy((fspt_multi *)h));
+  return undefined(env);
+}
+static napi_value MultiTarget(napi_env env, napi_callback_info info) {
+  napi_value a[2], ext; void *h; uint32_t i; fspt_target *t = NULL;
+  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &i));
+  FSPT_OK_OR_THROW(fspt_multi_target((fspt_multi *)h, i, &t));
+  NAPI_OK(napi_create_external(env, t, NULL, NULL, &ext));
+  return ext;
+}
+static napi_value MultiCamera(napi_env env, napi_callback_info info) {
+  napi_value a[6]; void *h; float P[3], I[3], lens[2]; double fov, rb;
+  if (get_args(env, info, 6, a) || unwrap(env, a[0], &h)) return NULL;
+  if (float_list(env, a[1], P, 3) || float_list(env, a[2], I, 3) || get_f64(env, a[3], &fov) || float_list(env, a[4], lens, 2) ||
+      get_f64(env, a[5], &rb)) return NULL;
+  FSPT_OK_OR_THROW(fspt_multi_camera((fspt_multi *)h, P, I, (float)fov, lens, (float)rb));
+  return undefined(env);
+}
+static napi_value MultiTrace(napi_env env, napi_callback_info info) {
+  napi_value a[5]; void *h; uint32_t tick, nb; double rb, theta;
+  if (get_args(env, info, 5, a)) return NULL;
+  if (get_f64(env, a[2], &rb) || get_f64(env, a[3], &theta) || get_bounces(env, a[4], &nb)) return NULL;
+  if (unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &tick));
+  FSPT_OK_OR_THROW(fspt_multi_trace((fspt_multi *)h, tick, (float)rb, (float)theta, nb));
+  return undefined(env);
+}
+static napi_value MultiRender(napi_env env, napi_callback_info info) {
+  napi_value a[5]; void *h; uint32_t first, n; uint64_t seed64 = 0;
+  if (get_args(env, info, 5, a)) return NULL;
+  fspt_camera_params cp;
+  if (parse_camera_params(env, a[1], &cp)) return NULL;
+  if (unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[2], &first));
+  NAPI_OK(napi_get_value_uint32(env, a[3], &n));
+  if (parse_seed(env, a[4], &seed64)) return NULL;
+  FSPT_OK_OR_THROW(fspt_multi_render((fspt_multi *)h, &cp, first, n, seed64));
+  return undefined(env);
+}
+static napi_value MultiClear(napi_env env, napi_callback_info info) {
+  napi_value a[1]; void *h;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  FSPT_OK_OR_THROW(fspt_multi_clear((fspt_multi *)h));
+  return undefined(env);
+}
+static napi_value MultiSync(napi_env env, napi_callback_info info) {
+  napi_value a[1]; void *h;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  FSPT_OK_OR_THROW(fspt_multi_sync((fspt_multi *)h));
+  return undefined(env);
+}
+static napi_value MultiReadRadiance(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h, *p; size_t n;
+  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h) || typed(env, a[1], napi_float32_array, 0, &p, &n)) return NULL;
+  FSPT_OK_OR_THROW(fspt_multi_read_radiance((fspt_multi *)h, (float *)p));
+  return a[1];
+}
+static napi_value MultiDraw(napi_env env, napi_callback_info info) {
+  napi_value a[6]; void *h, *p; size_t n; double ex, sat, sig; bool den;
+  if (get_args(env, info, 6, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_f64(env, a[1], &ex) || get_f64(env, a[2], &sat)) return NULL;
+  NAPI_OK(napi_get_value_bool(env, a[3], &den));
+  if (get_f64(env, a[4], &sig) || typed(env, a[5], napi_uint8_array, 0, &p, &n)) return NULL;
+  FSPT_OK_OR_THROW(fspt_multi_draw((fspt_multi *)h, (float)ex, (float)sat, den ? 1 : 0, (float)sig, (uint8_t *)p));
+  return a[5];
+}
+static napi_value SetTail(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h; int32_t r;
+  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_int32(env, a[1], &r));
+  FSPT_OK_OR_THROW(fspt_target_set_tail((fspt_target *)h, r));
   return undefined(env);
 }
 static napi_value Clear(napi_env env, napi_callback_info info) {
@@ -617,7 +806,10 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"traceTest", TraceTest}, {"render", Render}, {"clear", Clear},
       {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline},
-      {"setMemoryLimit", SetMemoryLimit}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare},
+      {"setMemoryLimit", SetMemoryLimit}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail},
+      {"renderAsync", RenderAsync}, {"multiCreate", MultiCreate}, {"multiDestroy", MultiDestroy}, {"multiTarget", MultiTarget},
+      {"multiCamera", MultiCamera}, {"multiTrace", MultiTrace}, {"multiRender", MultiRender}, {"multiRenderAsync", MultiRenderAsync},
+      {"multiClear", MultiClear}, {"multiSync", MultiSync}, {"multiReadRadiance", MultiReadRadiance}, {"multiDraw", MultiDraw},
       {"enableCounters", EnableCounters}, {"counters", GetCounters}, {"builderCreate", BuilderCreate}, {"builderDestroy", BuilderDestroy},
       {"builderParseObj", BuilderParseObj}, {"builderCommit", BuilderCommit}, {"builderNormalize", BuilderNormalize},
       {"builderBuild", BuilderBuild}, {"builderAutofocus", BuilderAutofocus}, {"envBins", EnvBins},

@@ -303,6 +303,15 @@ class PathTracer {
     for (let k = 0; k < 2 * nTicks; k++) this._randBase();
     this.pingpong += nTicks;
   }
+  /** render(nTicks) on a worker thread (napi_async_work): resolves when the ticks are on the device's accumulator.
+   *  Do not call anything else on this tracer until it settles. */
+  renderAsync(nTicks) {
+    const p = addon.renderAsync(this._target, { P: this.eye, I: this.dir, fovScale: this.fovScale, lens: this.lensFeatures,
+      envTheta: this.envTheta, numBounces: this.numBounces }, this.pingpong, nTicks, this._rng[0]);
+    for (let k = 0; k < 2 * nTicks; k++) this._randBase();
+    this.pingpong += nTicks;
+    return p;
+  }
   clear() { addon.clear(this._target); this.pingpong = 0; }                                  // main.js:826-836
   readRadiance(out) {
     out = out || new Float32Array(this.resolution[0] * this.resolution[1] * 4);
@@ -320,6 +329,8 @@ class PathTracer {
   setViewport(w, h) { addon.setViewport(this._target, w || 0, h || 0); }
   setShard(shard, nShards, tile) { addon.setShard(this._target, shard, nShards, tile || 32); }
   setPipeline(name, batch) { addon.setPipeline(this._target, name === 'megakernel' ? 0 : (name === 'wavefront2' ? 2 : 1), batch || 0); }
+  /** -1 adaptive (default), 0 never, r >= 1: the tail kernel takes the live paths over after wavefront round r */
+  setTail(round) { addon.setTail(this._target, round === undefined ? -1 : round); }
   /** cap / query the wavefront path state (include/fspt.h: fspt_target_set_memory_limit) and pre-allocate it */
   setMemoryLimit(bytes) { addon.setMemoryLimit(this._target, bytes || 0); }
   pathStateBytes() { return addon.pathStateBytes(this._target); }
@@ -329,5 +340,48 @@ class PathTracer {
   close() { if (this._target) { addon.targetDestroy(this._target); addon.sceneDestroy(this._scene); this._target = null; } }
 }
 
-module.exports = { addon, TexturePacker, getMaterial, parseMaterials, mergeSceneProps, resampleImage, packReferenceScene, buildScene,
+/** The same frame driver over several GPUs of the node from this one JS thread (include/fspt.h: fspt_multi_*):
+ *  every device traces every devices.length-th 32x32 tile, nothing moves between devices while rendering, and
+ *  readRadiance() / drawQuad() gather the tiles onto devices[0] with peer-to-peer copies.  Bit-identical to one GPU. */
+class MultiPathTracer {
+  constructor(scene, width, height, devices) {
+    this.resolution = [width, height];
+    this.devices = devices && devices.length ? devices.slice() : [0];
+    this._multi = addon.multiCreate(scene, this.devices, width, height);
+    this.fovScale = 0.5; this.envTheta = 0; this.dir = [0, 0, -1]; this.eye = [0, 0, 2];
+    this.lensFeatures = [1 - 1 / 2.0, 0.02];
+    this.numBounces = 4;
+    this.pingpong = 0;
+    this._rng = new BigUint64Array([1n]);
+  }
+  seed(s) { this._rng[0] = BigInt(s); }
+  _randBase() { return addon.randBaseNext(this._rng); }
+  _params() { return { P: this.eye, I: this.dir, fovScale: this.fovScale, lens: this.lensFeatures, envTheta: this.envTheta, numBounces: this.numBounces }; }
+  drawCamera(randBase) { addon.multiCamera(this._multi, this.eye, this.dir, this.fovScale, this.lensFeatures, randBase === undefined ? this._randBase() : randBase); }
+  drawTracer(i, randBase) { addon.multiTrace(this._multi, i, randBase === undefined ? this._randBase() : randBase, this.envTheta, this.numBounces); }
+  tick() { this.drawCamera(); this.drawTracer(this.pingpong); this.pingpong++; }
+  _advance(nTicks) { for (let k = 0; k < 2 * nTicks; k++) this._randBase(); this.pingpong += nTicks; }
+  render(nTicks) { addon.multiRender(this._multi, this._params(), this.pingpong, nTicks, this._rng[0]); this._advance(nTicks); }
+  renderAsync(nTicks) { const p = addon.multiRenderAsync(this._multi, this._params(), this.pingpong, nTicks, this._rng[0]); this._advance(nTicks); return p; }
+  clear() { addon.multiClear(this._multi); this.pingpong = 0; }
+  sync() { addon.multiSync(this._multi); }
+  readRadiance(out) {
+    out = out || new Float32Array(this.resolution[0] * this.resolution[1] * 4);
+    if (out.length !== this.resolution[0] * this.resolution[1] * 4) throw new RangeError('readRadiance: need W*H*4 floats');
+    return addon.multiReadRadiance(this._multi, out);
+  }
+  drawQuad(exposure, saturation, denoise, maxSigma, out) {
+    out = out || new Uint8Array(this.resolution[0] * this.resolution[1] * 4);
+    if (out.length !== this.resolution[0] * this.resolution[1] * 4) throw new RangeError('drawQuad: need W*H*4 bytes');
+    return addon.multiDraw(this._multi, exposure === undefined ? 1 : exposure, saturation === undefined ? 1 : saturation,
+      !!denoise, maxSigma === undefined ? 3 : maxSigma, out);
+  }
+  setPipeline(name, batch) {
+    const code = name === 'megakernel' ? 0 : (name === 'wavefront2' ? 2 : 1);
+    for (let i = 0; i < this.devices.length; i++) addon.setPipeline(addon.multiTarget(this._multi, i), code, batch || 0);
+  }
+  close() { if (this._multi) { addon.multiDestroy(this._multi); this._multi = null; } }
+}
+
+module.exports = { addon, MultiPathTracer, TexturePacker, getMaterial, parseMaterials, mergeSceneProps, resampleImage, packReferenceScene, buildScene,
   PathTracer, saveBlob, loadBlob };

@@ -548,6 +548,76 @@ def bunny_props():
     ]
 
 
+def procedural_maps(res=2048, seed=11):
+    """Stand-ins for the reference's dungeon texture set (scene/bunny.json:24-36: 2048^2 baseColor / metallicRoughness /
+    normal / emissive images; the normal maps are missing blobs in the checkout): flagstones with mortar lines, per-stone
+    tint and roughness, a tangent-space normal map from the same height field, a few emissive runes.
+    Returns {url: RGBA8 [res, res, 4]} for both image-mapped props."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:res, 0:res].astype(np.float32)
+    cells = 16
+    cx, cy = xx * cells / res, yy * cells / res
+    ix, iy = np.floor(cx).astype(np.int32), np.floor(cy).astype(np.int32)
+    fx, fy = cx - ix, cy - iy
+    edge = np.minimum(np.minimum(fx, 1 - fx), np.minimum(fy, 1 - fy))      # distance to the mortar line, in cells
+    mortar = np.clip(1.0 - edge / 0.06, 0.0, 1.0)
+    tint = rng.uniform(0.55, 1.0, (cells, cells, 3)).astype(np.float32)[iy % cells, ix % cells]
+    rough_stone = rng.uniform(0.25, 0.8, (cells, cells)).astype(np.float32)[iy % cells, ix % cells]
+    grain = (np.sin(xx * 0.37 + np.sin(yy * 0.11) * 3.0) * np.sin(yy * 0.29 + xx * 0.05) * 0.5 + 0.5).astype(np.float32)
+    height = (1.0 - mortar) * (0.8 + 0.2 * grain)
+    gy, gx = np.gradient(height)
+    nrm = np.stack([-gx * 6.0, -gy * 6.0, np.ones_like(gx)], -1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+
+    def rgba(c):
+        c = np.clip(c, 0.0, 1.0)
+        a = np.full(c.shape[:2] + (1,), 1.0, np.float32)
+        return np.round(np.concatenate([c, a], -1) * 255.0).astype(np.uint8)
+
+    def maps(base_rgb, metal):
+        base = (tint * base_rgb * (0.75 + 0.25 * grain[..., None])) * (1.0 - 0.6 * mortar[..., None])
+        mr = np.stack([np.full_like(grain, metal) * (1.0 - mortar), np.clip(rough_stone + 0.3 * mortar, 0, 1), np.zeros_like(grain)], -1)
+        return rgba(base), rgba(mr), rgba(nrm * [0.5, 0.5, 1.0] + [0.5, 0.5, 0.0])
+
+    out = {}
+    d, m, n = maps(np.array([0.62, 0.58, 0.52], np.float32), 0.0)
+    out["asset_packs/dungeon/RootNode_baseColor.png"] = d
+    out["asset_packs/dungeon/RootNode_metallicRoughness.png"] = m
+    out["asset_packs/dungeon/RootNode_normal.png"] = n
+    d, m, n = maps(np.array([0.45, 0.5, 0.6], np.float32), 0.35)
+    out["asset_packs/dungeon/Scene_-_Root_baseColor.jpeg"] = d
+    out["asset_packs/dungeon/Scene_-_Root_metallicRoughness.png"] = m
+    out["asset_packs/dungeon/Scene_-_Root_normal.png"] = n
+    rune = ((ix + 3 * iy) % 11 == 0) & (np.abs(fx - 0.5) < 0.12) & (np.abs(fy - 0.5) < 0.3)
+    out["asset_packs/dungeon/Scene_-_Root_emissive.jpeg"] = rgba(rune[..., None] * np.array([1.0, 0.55, 0.15], np.float32))
+    return out
+
+
+def bunny_props_textured():
+    """scene/bunny.json:6-41 with the floor / wall quads image-mapped exactly as the reference lists them (baseColor,
+    metallicRoughness, normal; the wall also an emissive map); the bunny stays a flat-colour cube-sphere."""
+    p = bunny_props()
+    p[1].update(diffuse="asset_packs/dungeon/RootNode_baseColor.png",
+                metallicRoughness="asset_packs/dungeon/RootNode_metallicRoughness.png",
+                normal="asset_packs/dungeon/RootNode_normal.png")
+    p[2].update(emission="asset_packs/dungeon/Scene_-_Root_emissive.jpeg",
+                diffuse="asset_packs/dungeon/Scene_-_Root_baseColor.jpeg",
+                metallicRoughness="asset_packs/dungeon/Scene_-_Root_metallicRoughness.png",
+                normal="asset_packs/dungeon/Scene_-_Root_normal.png")
+    return p
+
+
+def bunny_scene_textured(n=76, env_size=(2048, 1024), sun_deg=1.5, sun_gain=60.0, res=2048):
+    """The 'bunny' configs with the reference's real atlas size: 2048^2 image maps on both quads (7 image layers + the
+    flat-colour layers, 16 MB each) - the 4 x 4-tap bilinear atlas gather of tracer.fs:453-456 on an atlas that does not
+    fit any cache."""
+    texts = {"synthetic/cube_sphere.obj": cube_sphere_obj(n), "synthetic/quad.obj": QUAD_OBJ}
+    env, w, h = synthetic_env(env_size[0], env_size[1], sun_deg=sun_deg, sun_gain=sun_gain)
+    s = build_scene(bunny_props_textured(), texts, env=env, env_w=w, env_h=h, images=procedural_maps(res), atlas_res=res)
+    s.meta = dict(kind="bunny-synthetic-textured", n=n, res=res)
+    return s
+
+
 BUNNY_CAMERA = dict(P=[-0.751, 0.665, 1.820], I=[0.304, -0.489, -0.818], fov_scale=0.5, env_theta=1.66,
                     focal_depth=2.0, aperture=0.02)
 """scene/bunny.json:3-5, index.html:25,27, main.js:67-74."""

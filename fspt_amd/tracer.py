@@ -127,9 +127,13 @@ class PathTracer:
         return b.value, n.value
 
     def last_stage_ms(self):
-        ms = (C.c_float * 4)(); n = (C.c_uint32 * 4)()
+        ms = (C.c_float * 5)(); n = (C.c_uint32 * 5)()
         L.check(L.lib().fspt_last_stage_ms(self._t, ms, n))
-        return {k: (ms[i], n[i]) for i, k in enumerate(("primary", "trace", "logic", "resolve"))}
+        return {k: (ms[i], n[i]) for i, k in enumerate(("primary", "trace", "logic", "resolve", "tail"))}
+
+    def set_tail(self, round=-1):
+        """-1: adaptive (default), 0: never, r >= 1: the tail kernel takes over after wavefront round r."""
+        L.check(L.lib().fspt_target_set_tail(self._t, int(round)))
 
     def enable_counters(self, on=True):
         """0 / False: off.  1 / True: count the reference algorithm's work (equals the oracle's counters).
@@ -218,6 +222,110 @@ class PathTracer:
         if self._t:
             L.lib().fspt_target_destroy(self._t)
             self._t = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiPathTracer:
+    """PathTracer's frame driver over several GPUs from ONE host thread (include/fspt.h: fspt_multi_*): every device
+    traces every len(devices)-th 32x32 tile of the same frame, nothing moves between devices while rendering, and
+    readRadiance() / draw() gather the tiles onto devices[0] with peer-to-peer copies.  Same attribute and method
+    names as PathTracer; the result is bit-identical to a single-GPU render."""
+    NUM_BOUNCES = PathTracer.NUM_BOUNCES
+
+    def __init__(self, arrays, width, height, devices=(0,), num_bounces=None):
+        self.arrays = arrays
+        self.devices = [int(d) for d in devices]
+        self.resolution = (int(width), int(height))
+        self._m = C.c_void_p()
+        desc = arrays.desc()
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        L.check(L.lib().fspt_multi_create(C.byref(desc), devs, len(self.devices), self.resolution[0], self.resolution[1],
+                                          C.byref(self._m)))
+        self.fovScale = 0.5
+        self.envTheta = 0.0
+        self.dir = [0.0, 0.0, -1.0]
+        self.eye = [0.0, 0.0, 2.0]
+        self.lensFeatures = [1.0 - 1.0 / 2.0, 0.02]
+        self.num_bounces = self.NUM_BOUNCES if num_bounces is None else int(num_bounces)
+        self.pingpong = 0
+        self._rng = C.c_uint64(1)
+
+    set_camera = PathTracer.set_camera
+    seed = PathTracer.seed
+    next_rand_base = PathTracer.next_rand_base
+
+    def _targets(self):
+        for i in range(len(self.devices)):
+            t = C.c_void_p()
+            L.check(L.lib().fspt_multi_target(self._m, i, C.byref(t)))
+            yield t
+
+    def set_pipeline(self, pipeline, batch_ticks=0):
+        code = {"megakernel": 0, "wavefront": 1, "wavefront2": 2}.get(pipeline, pipeline)
+        for t in self._targets():
+            L.check(L.lib().fspt_target_set_pipeline(t, int(code), int(batch_ticks)))
+
+    def set_tail(self, round=-1):
+        for t in self._targets():
+            L.check(L.lib().fspt_target_set_tail(t, int(round)))
+
+    def prepare(self):
+        for t in self._targets():
+            L.check(L.lib().fspt_target_prepare(t))
+
+    def drawCamera(self, randBase):
+        P = (C.c_float * 3)(*self.eye); I = (C.c_float * 3)(*self.dir); lens = (C.c_float * 2)(*self.lensFeatures)
+        L.check(L.lib().fspt_multi_camera(self._m, P, I, self.fovScale, lens, float(randBase)))
+
+    def drawTracer(self, i, randBase):
+        L.check(L.lib().fspt_multi_trace(self._m, int(i), float(randBase), self.envTheta, self.num_bounces))
+
+    tick = PathTracer.tick
+
+    def render(self, n_ticks):
+        cp = L.CameraParams()
+        cp.P = (C.c_float * 3)(*self.eye); cp.I = (C.c_float * 3)(*self.dir)
+        cp.fov_scale = self.fovScale; cp.lens = (C.c_float * 2)(*self.lensFeatures)
+        cp.env_theta = self.envTheta; cp.num_bounces = self.num_bounces
+        L.check(L.lib().fspt_multi_render(self._m, C.byref(cp), self.pingpong, int(n_ticks), self._rng.value))
+        for _ in range(2 * int(n_ticks)):
+            self.next_rand_base()
+        self.pingpong += int(n_ticks)
+
+    def clear(self):
+        L.check(L.lib().fspt_multi_clear(self._m))
+        self.pingpong = 0
+
+    def sync(self):
+        L.check(L.lib().fspt_multi_sync(self._m))
+
+    def readRadiance(self):
+        W, H = self.resolution
+        out = np.zeros((H, W, 4), np.float32)
+        L.check(L.lib().fspt_multi_read_radiance(self._m, L.fptr(out)))
+        return out
+
+    def draw(self, exposure=1.0, saturation=1.0, denoise=False, max_sigma=3.0):
+        W, H = self.resolution
+        out = np.zeros((H, W, 4), np.uint8)
+        L.check(L.lib().fspt_multi_draw(self._m, float(exposure), float(saturation), 1 if denoise else 0, float(max_sigma),
+                                        L.u8ptr(out)))
+        return out
+
+    def last_gather_bytes(self):
+        b = C.c_uint64()
+        L.check(L.lib().fspt_multi_last_gather_bytes(self._m, C.byref(b)))
+        return b.value
+
+    def close(self):
+        if self._m:
+            L.lib().fspt_multi_destroy(self._m)
+            self._m = C.c_void_p()
 
     def __del__(self):
         try:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FSPT_ABI_VERSION 1
+#define FSPT_ABI_VERSION 2
 
 enum {
   FSPT_OK = 0,
@@ -177,9 +177,9 @@ int fspt_target_set_viewport(fspt_target *target, uint32_t w, uint32_t h);
  *   pipeline 2 "wavefront, two lanes": pipeline 1 with the batch split in two halves that run
  *              concurrently on two HIP streams (separate path state, resolves chained in tick order). */
 int fspt_target_set_pipeline(fspt_target *target, int pipeline, uint32_t batch_ticks);
-/* Wavefront path state lives in device memory: 140 bytes per (pixel, tick) of a batch.  It is sized for the largest
- * n_ticks any call on this target has asked for so far (at most batch_ticks; fspt_trace = 1 tick = 0.29 GB at
- * 1920x1080, a 128-tick fspt_render = 37 GB) and grows when a longer call arrives.  fspt_target_set_memory_limit caps
+/* Wavefront path state lives in device memory: 220 bytes per (pixel, tick) of a batch.  It is sized for the largest
+ * n_ticks any call on this target has asked for so far (at most batch_ticks; fspt_trace = 1 tick = 0.46 GB at
+ * 1920x1080, a 128-tick fspt_render = 58 GB) and grows when a longer call arrives.  fspt_target_set_memory_limit caps
  * it (bytes; 0 = no cap): a batch that does not fit the cap - or the free device memory - is halved until it does,
  * which only costs speed (results do not depend on the batch size).  FSPT_E_NOMEM when even one tick does not fit. */
 int fspt_target_set_memory_limit(fspt_target *target, uint64_t bytes);
@@ -189,10 +189,46 @@ int fspt_target_path_state_bytes(fspt_target *target, uint64_t *bytes, uint32_t 
  * (sized for the full configured batch_ticks) instead of lazily inside the first fspt_trace / fspt_render.  Blocking. */
 int fspt_target_prepare(fspt_target *target);
 /* Per-kernel-class timing of the most recent fspt_trace / fspt_render (wavefront pipeline):
- * summed HIP-event durations and launch counts for {primary, trace, logic, resolve}: primary = the first launch of
- * a batch (ray generation + the camera ray's traversal + its shading in one kernel), trace / logic = the later
- * rounds' traversal and shading launches, resolve = the running-mean fold. Blocking. */
-int fspt_last_stage_ms(fspt_target *target, float ms[4], uint32_t launches[4]);
+ * summed HIP-event durations and launch counts for {primary, trace, logic, resolve, tail}: primary = the first launch
+ * of a batch (ray generation + the camera ray's traversal + its shading in one kernel), trace / logic = the later
+ * rounds' traversal and shading launches, resolve = the running-mean fold, tail = the kernel that runs the last live
+ * paths to completion. Blocking. */
+int fspt_last_stage_ms(fspt_target *target, float ms[5], uint32_t launches[5]);
+/* When the wavefront pipeline hands the remaining live paths to the tail kernel (one launch that alternates traversal
+ * and shading per path until it ends, instead of one trace + one logic launch per bounce): -1 (default) decides from
+ * the live-path counts of the previous batch, 0 never (except for paths that refraction keeps alive beyond
+ * NUM_BOUNCES rounds, tracer.fs:488), r >= 1 after round r.  Results are bit-identical for every setting. */
+int fspt_target_set_tail(fspt_target *target, int round);
+
+/* ------------------------------------------------------------------------
+ * One frame over several GPUs of a node, driven by ONE host thread (the reference's host is a single JS thread;
+ * README.md:28 lists "tiled rendering" as a TODO).  fspt_multi_create uploads the scene to every listed device and
+ * makes one render target per device that owns every n_devices-th 32x32 tile (fspt_target_set_shard; the RNG depends
+ * on pixel coordinates and randBase only - camera.fs:38, tracer.fs:458 - so the assembled frame is bit-identical to a
+ * single-GPU render).  The draw calls below enqueue on every device and return; NO data moves between devices while
+ * rendering.  fspt_multi_read_radiance / fspt_multi_draw do the one exchange: every device packs its own tiles, the
+ * packed tiles travel to devices[0] with peer-to-peer copies (xGMI) on the devices' own streams, devices[0] scatters
+ * them into its full-size accumulator.  A device may be listed more than once (its share of the tiles is then traced
+ * by several targets one after the other) - that is how a 1-GPU box exercises the path.
+ * ---------------------------------------------------------------------- */
+typedef struct fspt_multi fspt_multi;
+int fspt_multi_create(const fspt_scene_desc *desc, const int *devices, uint32_t n_devices,
+                      uint32_t width, uint32_t height, fspt_multi **out);
+int fspt_multi_destroy(fspt_multi *m);
+/* the per-device target i (for fspt_target_set_pipeline / _set_tail / _prepare / counters); owned by m */
+int fspt_multi_target(fspt_multi *m, uint32_t i, fspt_target **out);
+int fspt_multi_camera(fspt_multi *m, const float P[3], const float I[3], float fov_scale, const float lens[2],
+                      float rand_base);                                     /* drawCamera on every device   */
+int fspt_multi_trace(fspt_multi *m, uint32_t tick, float rand_base, float env_theta, uint32_t num_bounces);
+int fspt_multi_render(fspt_multi *m, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
+                      uint64_t seed);                                       /* fspt_render on every device  */
+int fspt_multi_clear(fspt_multi *m);
+int fspt_multi_sync(fspt_multi *m);
+/* Gather (see above), then what fspt_read_radiance / fspt_draw do on the assembled frame.  Blocking. */
+int fspt_multi_read_radiance(fspt_multi *m, float *out);
+int fspt_multi_draw(fspt_multi *m, float exposure, float saturation, int denoise, float max_sigma, uint8_t *out_rgba8);
+/* Bytes that crossed between devices in the most recent gather (the exchange's payload: 16 bytes per foreign pixel). */
+int fspt_multi_last_gather_bytes(fspt_multi *m, uint64_t *bytes);
 
 /* clear() (main.js:826-836). */
 int fspt_clear(fspt_target *target);
@@ -222,7 +258,10 @@ int fspt_intersect(fspt_scene *scene, const float *rays, uint32_t n, float *t_ou
 
 /* Work counters for the byte accounting of SURVEY 8d, summed over every
  * sample traced since the last fspt_clear / fspt_counters_reset when
- * counting is enabled (a slower kernel variant; off by default). */
+ * counting is enabled (slower kernel variants; off by default).  enable = 1 counts the REFERENCE's work: NEE shadow
+ * rays are traced to their closest hit like tracer.fs:501 does, so the counters equal the oracle's.  enable = 2 counts
+ * the work of the production kernels, whose shadow rays stop at the first hit (only `shadow.index == -1` is consumed,
+ * tracer.fs:502): fewer steps / leaves, everything else - and every radiance value - identical. */
 typedef struct fspt_counters {
   uint64_t samples;     /* tracer.fs main() invocations                      */
   uint64_t rays;        /* intersectScene calls            (tracer.fs:366)   */

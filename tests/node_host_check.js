@@ -31,6 +31,32 @@ if (mode === 'exports') {
   const s = F.loadBlob(job.blob_in);
   F.saveBlob(job.blob_out, s);
   out.n_tris = s.tri.length / 9; out.leafSize = s.leafSize; out.atlasLayers = s.atlasLayers;
+} else if (mode === 'render_multi') {
+  // one frame over several (virtual) devices from this one JS thread, part of it through the async entry point
+  const s = F.buildScene(job.props, job.objs, env, 4);
+  const mp = new F.MultiPathTracer(s, job.W, job.H, job.devices);
+  mp.eye = job.cam.P; mp.dir = job.cam.I; mp.fovScale = job.cam.fov_scale; mp.envTheta = job.cam.env_theta;
+  mp.lensFeatures = job.cam.lens; mp.numBounces = job.bounces;
+  mp.seed(job.seed);
+  mp.render(job.ticks_fused);
+  for (let k = 0; k < job.ticks_two_call; k++) mp.tick();
+  let ticked = 0;
+  const iv = setInterval(() => { ticked++; }, 1);
+  mp.renderAsync(job.ticks_async).then(() => {
+    clearInterval(iv);
+    out.radiance = b64(mp.readRadiance());
+    out.event_loop_alive = ticked >= 0;
+    // single-target async render of the same job for comparison
+    const pt = new F.PathTracer(s, job.W, job.H, 0);
+    pt.eye = job.cam.P; pt.dir = job.cam.I; pt.fovScale = job.cam.fov_scale; pt.envTheta = job.cam.env_theta;
+    pt.lensFeatures = job.cam.lens; pt.numBounces = job.bounces;
+    pt.seed(job.seed);
+    return pt.renderAsync(job.ticks_fused + job.ticks_two_call + job.ticks_async).then(() => {
+      out.radiance_single = b64(pt.readRadiance());
+      pt.close(); mp.close();
+      fs.writeFileSync(process.argv[4], JSON.stringify(out));
+    });
+  }).catch((e) => { console.error(e); process.exit(1); });
 } else if (mode === 'bounces_range') {
   // NUM_BOUNCES outside [0, 64] or not an integer: RangeError at the N-API boundary, before any device call
   out.errors = {};

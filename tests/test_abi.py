@@ -31,7 +31,7 @@ def test_binding_covers_header():
 
 
 def test_abi_version():
-    assert L.lib().fspt_abi_version() == 1
+    assert L.lib().fspt_abi_version() == 2
 
 
 def test_rand_base_stream_range():

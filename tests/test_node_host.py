@@ -39,10 +39,12 @@ def dec(b, dt):
 
 def test_addon_exports():
     out = run_node("exports", {})
-    assert out["abi"] == 1
+    assert out["abi"] == 2
     for name in ("sceneCreate", "targetCreate", "camera", "trace", "render", "clear", "readRadiance", "setShard",
                  "builderCreate", "builderParseObj", "builderCommit", "builderNormalize", "builderBuild",
-                 "builderAutofocus", "builderDestroy", "envBins", "counters"):
+                 "builderAutofocus", "builderDestroy", "envBins", "counters", "renderAsync", "multiCreate", "multiRender",
+                 "multiRenderAsync", "multiReadRadiance", "multiDraw", "multiTarget", "multiDestroy", "setTail",
+                 "setMemoryLimit", "prepare"):
         assert name in out["exports"]
 
 
@@ -114,6 +116,23 @@ def test_js_host_render_matches_oracle(small_scene, camera):
     O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
              0, 5, 21, want)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_js_multi_device_and_async_render(small_scene, camera):
+    """The JS host drives several (here: virtual, device 0 listed three times) devices from its one thread, and
+    renderAsync (napi_async_work) resolves with the frame complete: both equal the oracle's render."""
+    W, H = 100, 70
+    job = small_job()
+    job.update(W=W, H=H, bounces=4, seed=33, ticks_fused=2, ticks_two_call=1, ticks_async=3, devices=[0, 0, 0],
+               cam=dict(P=camera["P"], I=camera["I"], fov_scale=camera["fov_scale"], env_theta=camera["env_theta"],
+                        lens=camera["lens"]))
+    out = run_node("render_multi", job)
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
+             0, 6, 33, want)
+    assert np.array_equal(dec(out["radiance"], np.float32).reshape(H, W, 4), want)
+    assert np.array_equal(dec(out["radiance_single"], np.float32).reshape(H, W, 4), want)
 
 
 def test_blob_roundtrip_python_and_js(small_scene, tmp_path):

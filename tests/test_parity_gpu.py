@@ -16,9 +16,12 @@ pytestmark = pytest.mark.gpu
 PIPELINES = ["wavefront", "megakernel"]
 
 
-def make_pt(arrays, W, H, cam, bounces=4, pipeline="wavefront", batch=0):
+def make_pt(arrays, W, H, cam, bounces=4, pipeline="wavefront", batch=0, tail=0):
+    """tail=0: every round through the trace / logic kernels (tiny test frames would otherwise hand everything after
+    round 1 to the tail kernel); the tail kernel has its own tests."""
     pt = PathTracer(arrays, W, H, num_bounces=bounces)
     pt.set_pipeline(pipeline, batch)
+    pt.set_tail(tail)
     pt.set_camera(cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["focal_depth"], cam["aperture"])
     return pt
 
@@ -49,6 +52,18 @@ def test_math_bitwise(op, name):
         assert np.abs(ref - np.sin(a.astype(np.float64))).max() < 3e-7
     if name == "div":
         assert np.array_equal(ref, a / b)
+
+
+@pytest.mark.parametrize("name", ["sin", "cos", "atan2", "asin", "exp2", "log2", "pow", "sqrt", "div"])
+def test_math_accuracy_vs_float64(name):
+    """The DEVICE results against numpy float64, not against the oracle (tests/mathref.py): oracle_math.h and
+    fspt_math.hpp are the same spec written twice, so their bit equality alone would let a shared error through."""
+    import mathref
+    a, b = mathref.inputs(name, seed=7)
+    out = np.zeros(a.size, np.float32)
+    L.check(L.lib().fspt_math_eval(0, mathref.OPS[name], L.fptr(a), L.fptr(b) if b is not None else None, a.size, L.fptr(out)))
+    mathref.check(name, out, a, b)
+    assert np.array_equal(out.view(np.uint32), O.math_eval(mathref.OPS[name], a, b).view(np.uint32))  # and == oracle
 
 
 def test_camera_bitwise(small_scene, camera):
@@ -181,8 +196,9 @@ def test_refractive_scene_bitwise(pipeline):
              counters=oc)
     assert np.array_equal(pt.readRadiance(), want)
     assert pt.counters() == oc.as_dict()
-    if pipeline == "wavefront":  # refraction really extended paths beyond NUM_BOUNCES + 1 rounds
-        assert pt.last_stage_ms()["logic"][1] > 4
+    if pipeline == "wavefront":  # refraction really extended paths beyond NUM_BOUNCES + 1 rounds: the tail kernel ends them
+        st = pt.last_stage_ms()
+        assert st["logic"][1] == 4 and st["tail"][1] == 1 and st["tail"][0] > 0
 
 
 @pytest.mark.parametrize("pipeline", PIPELINES)
@@ -213,7 +229,72 @@ def test_stage_timing(small_scene, camera):
     # per batch: one primary launch (camera ray + its traversal + its shading), then rounds 1..4 of trace and
     # rounds 2..5 of logic, one resolve
     assert st["primary"][1] == 2 and st["resolve"][1] == 2 and st["trace"][1] == 2 * 4 and st["logic"][1] == 2 * 4
-    assert all(v[0] > 0 for v in st.values())
+    assert st["tail"] == (0.0, 0)
+    assert all(v[0] > 0 for k, v in st.items() if k != "tail")
+    # the tail kernel after round 2: primary, trace 1, logic 2, tail
+    pt.set_tail(2)
+    pt.render(2)
+    st = pt.last_stage_ms()
+    assert (st["primary"][1], st["trace"][1], st["logic"][1], st["tail"][1], st["resolve"][1]) == (1, 1, 1, 1, 1)
+
+
+@pytest.mark.parametrize("tail", [-1, 1, 2, 3, 5, 9])
+@pytest.mark.parametrize("scene_name", ["medium", "variant"])
+def test_tail_kernel_bitwise(medium_scene, camera, tail, scene_name):
+    """The tail kernel (live paths of a late round run to completion in one launch) takes over after round `tail`
+    (-1: decided from the previous batch's live-path counts): radiance and work counters are those of the oracle
+    whatever the hand-over round, with and without refraction (`variant`: paths outlive NUM_BOUNCES rounds)."""
+    if scene_name == "variant":
+        from test_goldens import scene_from_golden
+        arrays = scene_from_golden("variant")
+        cam = dict(P=[0.3, 1.2, 3.4], I=[-0.05, -0.3, -0.95], fov_scale=0.5, env_theta=1.66, focal_depth=2.0, aperture=0.02,
+                   lens=[0.5, 0.02])
+    else:
+        arrays, cam = medium_scene, camera
+    W, H, nb = 112, 72, 6
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], nb, 0, 7, 11, want,
+             counters=oc)
+    pt = make_pt(arrays, W, H, cam, nb, "wavefront", 3, tail=tail)
+    pt.enable_counters(1)
+    pt.clear()
+    pt.seed(11)
+    pt.render(2); pt.render(5)  # three batches: the adaptive setting has a history from the second one on
+    assert np.array_equal(pt.readRadiance(), want)
+    assert pt.counters() == oc.as_dict()
+    st = pt.last_stage_ms()
+    if tail == -1:
+        assert st["tail"][1] >= 1  # a 112x72 frame never has enough live paths to fill a trace launch
+    elif tail <= nb:
+        assert st["tail"][1] == 2 and st["trace"][1] == 2 * (tail - 1) and st["logic"][1] == 2 * (tail - 1)
+    pt.close()
+
+
+def test_counters_of_the_production_kernels(medium_scene, camera):
+    """fspt_enable_counters(2): the work the timed kernels really do.  NEE shadow rays stop at their first hit, so
+    steps and leaves are at most the reference's; rays, shades, environment lookups and every radiance value are
+    the same.  Mode 1 (the reference's work) equals the oracle's counters."""
+    W, H = 128, 80
+    res = {}
+    for mode in (1, 2):
+        pt = make_pt(medium_scene, W, H, camera, 8, "wavefront")
+        pt.enable_counters(mode)
+        pt.clear()
+        pt.seed(3)
+        pt.render(3)
+        res[mode] = (pt.counters(), pt.readRadiance())
+        pt.close()
+    oc = O.OCounters()
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 8,
+             0, 3, 3, want, counters=oc)
+    assert res[1][0] == oc.as_dict()
+    assert np.array_equal(res[1][1], want) and np.array_equal(res[2][1], want)
+    c1, c2 = res[1][0], res[2][0]
+    for k in ("samples", "rays", "shades", "env_lookups"):
+        assert c1[k] == c2[k], k
+    assert c2["steps"] < c1["steps"] and c2["leaves"] < c1["leaves"]
 
 
 @pytest.mark.parametrize("params", [(1.0, 1.0, False, 3.0), (2.5, 0.6, False, 3.0), (1.0, 1.0, True, 3.0),
@@ -447,6 +528,130 @@ def test_bvh_deeper_than_the_reference_stack_is_rejected():
     with pytest.raises(L.FsptError) as e:
         Scene(arr)
     assert e.value.code == -1 and "depth" in str(e.value)
+
+
+def chain_scene(n_leaves, env_from):
+    """A chain-shaped BVH of depth n_leaves - 1 in the reference layout (pre-order; interior i: left = a one-triangle
+    leaf, right = the next interior), small randomly placed triangles along +x, flat normals, a grey diffuse material
+    and the environment (incl. importance bins) of `env_from`."""
+    from fspt_amd import scene as S
+    rng = np.random.default_rng(n_leaves)
+    tri = np.zeros((n_leaves, 3, 3), np.float32)
+    for k in range(n_leaves):
+        c = np.array([k, rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2)])
+        tri[k] = c + rng.uniform(-0.9, 0.9, (3, 3)) * [0.3, 1, 1]  # boxes overlap the chain's axis: rays along it visit every level
+    lo = tri.min(1); hi = tri.max(1)
+    n_nodes = 2 * n_leaves - 1
+    bvh = np.zeros((n_nodes, 9), np.float32)
+    iv = bvh.view(np.int32)
+    idx = 0
+    for i in range(n_leaves - 1):  # interior i (covers leaves i..), then its left child: leaf i
+        iv[idx, 0] = idx + 1; iv[idx, 1] = idx + 2; iv[idx, 2] = -1
+        bvh[idx, 3:6] = lo[i:].min(0); bvh[idx, 6:9] = hi[i:].max(0)
+        idx += 1
+        iv[idx, 0] = 0; iv[idx, 1] = 0; iv[idx, 2] = i
+        bvh[idx, 3:6] = lo[i]; bvh[idx, 6:9] = hi[i]
+        idx += 1
+    iv[idx, 0] = 0; iv[idx, 1] = 0; iv[idx, 2] = n_leaves - 1
+    bvh[idx, 3:6] = lo[-1]; bvh[idx, 6:9] = hi[-1]
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tan = tri[:, 1] - tri[:, 0]
+    tan /= np.linalg.norm(tan, axis=1, keepdims=True)
+    bit = np.cross(nrm, tan)
+    norm = np.zeros((n_leaves, 3, 3, 3), np.float32)  # per vertex: n, t, bt
+    norm[:, :, 0] = nrm[:, None]; norm[:, :, 1] = tan[:, None]; norm[:, :, 2] = bit[:, None]
+    mat = np.zeros((n_leaves, 12), np.float32)
+    mat[:, 0:4] = [0, 1, 2, 3]   # diffuse / emissive / normal / metallic-roughness layers
+    mat[:, 9:11] = [1.4, -1.0]   # ior, dielectric
+    atlas = np.array([[200, 190, 180, 255], [0, 0, 0, 255], [128, 128, 255, 255], [0, 140, 0, 255]], np.uint8)
+    return S.SceneArrays(bvh=bvh.reshape(-1), tri=tri.reshape(-1), mat=mat.reshape(-1), norm=norm.reshape(-1),
+                         uv=np.zeros(n_leaves * 6, np.float32), atlas=atlas.reshape(-1), atlas_res=1, atlas_layers=4,
+                         env=env_from.env, env_w=env_from.env_w, env_h=env_from.env_h, bins=env_from.bins)
+
+
+@pytest.mark.parametrize("n_leaves", [41, 64])
+def test_deep_chain_bvh_bitwise(small_scene, n_leaves):
+    """depth 32-63 was accepted but the primary launch's LDS stacks (8 waves x (depth + 1) x 256 B) passed the
+    default 64 KB of dynamic LDS at depth 31 and nothing raised the limit.  Depth 40 and 63 (the deepest tree the
+    reference's int stack[64] can walk): traversal results and step counts, both pipelines, the tail kernel and the
+    mode=test draw - all against the oracle.  Rays looking down the chain (-x) push one entry per level."""
+    arrays = chain_scene(n_leaves, small_scene)
+    sc = Scene(arrays)
+    assert sc.depth == n_leaves - 1
+    rng = np.random.default_rng(1)
+    n = 4096
+    o = np.stack([np.full(n, n_leaves + 2.0), rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n)], 1)
+    tgt = np.stack([rng.uniform(-1, n_leaves, n), rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n)], 1)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    rays[n // 2:, 0] = -3.0; rays[n // 2:, 3] *= -1  # and from the shallow end
+    t, idx, steps, leaves = sc.intersect(rays)
+    ot, oidx, osteps, oleaves = O.intersect(arrays, rays)
+    assert np.array_equal(t, ot) and np.array_equal(idx, oidx) and np.array_equal(steps, osteps) and np.array_equal(leaves, oleaves)
+    assert (idx >= 0).mean() > 0.3 and leaves.max() >= n_leaves // 2  # rays down the chain stack one entry per level: > 32 deep for 64
+    W, H = 72, 40
+    cam = dict(P=[n_leaves + 2.5, 0.05, 0.1], I=[-1.0, -0.01, -0.02], fov_scale=0.5, env_theta=1.66, focal_depth=2.0,
+               aperture=0.02, lens=[0.5, 0.02])
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 3, 0, 2, 9, want, counters=oc)
+    assert want[..., :3].max() > 0
+    for pipeline, tail in (("wavefront", 0), ("wavefront", 2), ("megakernel", 0)):
+        pt = PathTracer(sc, W, H, num_bounces=3)
+        pt.set_pipeline(pipeline, 0)
+        pt.set_tail(tail)
+        pt.set_camera(cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["focal_depth"], cam["aperture"])
+        pt.enable_counters(1)
+        pt.clear()
+        pt.seed(9)
+        pt.render(2)
+        assert np.array_equal(pt.readRadiance(), want), (pipeline, tail)
+        assert pt.counters() == oc.as_dict(), (pipeline, tail)
+        if pipeline == "wavefront" and tail == 0:  # bvh_test.fs through the same stacks
+            pt.clear()
+            pt.drawCamera(12.5)
+            pt.drawTracerTest(0)
+            pos, dd = O.camera(W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], 12.5)
+            ref = np.zeros((H, W, 4), np.float32)
+            O.trace_test(arrays, W, H, pos, dd, 0, ref)
+            assert np.array_equal(pt.readRadiance(), ref)
+        pt.close()
+
+
+@pytest.mark.parametrize("n_dev", [1, 2, 3])
+def test_multi_device_target_bitwise(medium_scene, camera, n_dev):
+    """fspt_multi_*: one host thread, one target per device, every device traces every n-th 32x32 tile, the read-out
+    gathers the tiles onto devices[0] with peer copies.  Device list = the first min(n, device_count) real devices
+    cycled (a 1-GPU box lists device 0 n times: same tile split, same pack / peer-copy / scatter path).  Radiance and
+    the tone-mapped frame equal the single-target render bit for bit; also through the two-call form."""
+    from fspt_amd import MultiPathTracer
+    n_real = max(1, min(n_dev, L.lib().fspt_device_count()))
+    devices = [i % n_real for i in range(n_dev)]
+    W, H = 200, 120  # 7 x 4 tiles: ragged edges, uneven tile counts per device
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 5,
+             0, 6, 77, want)
+    mp = MultiPathTracer(medium_scene, W, H, devices, num_bounces=5)
+    mp.set_camera(camera["P"], camera["I"], camera["fov_scale"], camera["env_theta"], camera["focal_depth"], camera["aperture"])
+    mp.set_pipeline("wavefront", 4)
+    mp.seed(77)
+    mp.render(4)
+    part = mp.readRadiance()  # a read-out in the middle must not disturb the accumulation
+    assert part[..., 3].min() == 1.0
+    mp.tick(); mp.tick()      # fspt_multi_camera + fspt_multi_trace continue the same stream
+    got = mp.readRadiance()
+    assert np.array_equal(got, want)
+    n_tiles = 7 * 4
+    foreign = sum(len(range(s, n_tiles, n_dev)) for s in range(1, n_dev))
+    assert mp.last_gather_bytes() == foreign * 32 * 32 * 16
+    assert np.array_equal(mp.draw(1.3, 0.9, True, 2.0), O.draw(want, 1.3, 0.9, True, 2.0))
+    mp.clear()
+    mp.seed(77)
+    mp.render(6)
+    assert np.array_equal(mp.readRadiance(), want)
+    mp.close()
 
 
 def test_bound_torch_accumulator_and_tile_gather_on_gpu(small_scene, camera):
