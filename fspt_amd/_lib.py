@@ -109,6 +109,8 @@ SIGNATURES = {
     "fspt_last_stage_ms": (C.c_int, [_VP, _F, _U32]),
     "fspt_target_prepare": (C.c_int, [_VP]),
     "fspt_target_set_tail": (C.c_int, [_VP, C.c_int]),
+    "fspt_target_set_deferred": (C.c_int, [_VP, C.c_int]),
+    "fspt_target_live_paths": (C.c_int, [_VP, C.POINTER(C.c_double), C.c_uint32]),
     "fspt_target_set_memory_limit": (C.c_int, [_VP, C.c_uint64]),
     "fspt_target_path_state_bytes": (C.c_int, [_VP, C.POINTER(C.c_uint64), _U32]),
     "fspt_multi_create": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),

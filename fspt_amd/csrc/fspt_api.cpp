@@ -17,6 +17,10 @@
 #include <string>
 #include <vector>
 
+#ifndef FSPT_NODE_TREELET
+#define FSPT_NODE_TREELET 0 // nodes per treelet below the breadth-first top of the tree; 0 = pre-order (profiles/r02: A/B on the 1 M-triangle scene)
+#endif
+
 static thread_local char g_err[512] = "";
 
 void fspt_set_error(const char *fmt, ...) {
@@ -80,6 +84,14 @@ struct fspt_target {
     hipEvent_t resolved = nullptr; // this lane's most recent resolve has finished
   } lanes[2];
   uint32_t n_lanes = 1; // 2 = pipeline code 2: measured +3 % at 64+ ticks, -17 % at 8 ticks (profiles/r01)
+  // Deferred two-call ticks (fspt_camera + fspt_trace): recorded, executed in batches at the next flush point
+  struct Deferred { fspt_camera_params cam; float rb_cam; uint32_t tick; float rb_trace; };
+  std::vector<Deferred> pending;
+  fspt_camera_params last_cam{}; // the most recent fspt_camera call (num_bounces / env_theta filled in by fspt_trace)
+  float last_rb_cam = 0.0f;
+  bool cam_recorded = false;     // last_cam is valid and newer than the ray buffers' contents
+  bool rays_injected = false;    // the ray buffers hold caller-supplied rays (fspt_set_rays): trace them as they are
+  bool defer = true;             // fspt_target_set_deferred
   int tail_round = -1;       // fspt_target_set_tail: -1 adaptive, 0 never, r >= 1 after round r
   float live_frac[80] = {};  // live paths after round r / slots of the batch, from the most recent finished batch
   bool live_known = false;
@@ -92,6 +104,27 @@ struct fspt_target {
   uint32_t ev_used = 0;       // pairs used by the last render
   bool ev_overflow = false;
 };
+
+// RGBA8 image (row-major, w x h) -> 8 x 4-texel tiles (fspt_device.hpp: TEX_TILE_*), padded to whole tiles.
+// Returns the number of texels of the tiled image; with src == nullptr only that.
+static size_t tile_image(const uint8_t *src, uint32_t w, uint32_t h, std::vector<uint32_t> &out) {
+  const uint32_t tx = (w + fspt::TEX_TILE_W - 1) / fspt::TEX_TILE_W, ty = (h + fspt::TEX_TILE_H - 1) / fspt::TEX_TILE_H;
+  const size_t n = (size_t)tx * ty * fspt::TEX_TILE_W * fspt::TEX_TILE_H;
+  if (!src) return n;
+  out.assign(n, 0u);
+  for (uint32_t j = 0; j < h; ++j)
+    for (uint32_t i = 0; i < w; ++i) {
+      uint32_t v;
+      std::memcpy(&v, src + ((size_t)j * w + i) * 4, 4);
+      out[((size_t)(j / fspt::TEX_TILE_H) * tx + i / fspt::TEX_TILE_W) * (fspt::TEX_TILE_W * fspt::TEX_TILE_H) +
+          (j % fspt::TEX_TILE_H) * fspt::TEX_TILE_W + (i % fspt::TEX_TILE_W)] = v;
+    }
+  return n;
+}
+
+static int flush_pending(fspt_target *t);
+static int materialise_rays(fspt_target *t);
+#define FLUSH_OR_RETURN(t) do { int rc_f = flush_pending(t); if (rc_f) return rc_f; } while (0)
 
 static int check_device(int device) {
   int n = 0;
@@ -198,8 +231,41 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
       if (word(l, 2) <= -1) queue.push_back(l);
       if (word(r, 2) <= -1) queue.push_back(r);
     }
+#if FSPT_NODE_TREELET > 1
+    // Below the breadth-first top: TREELETS.  A treelet = a subtree root and its descendants in breadth-first order, up to
+    // FSPT_NODE_TREELET nodes, stored contiguously; the treelets hanging off it follow, depth-first.  A ray that enters
+    // a treelet finds the next few levels of its descent - and the sibling it will pop later - in the same or the next
+    // 128-byte lines, instead of one line per level (pre-order keeps only the LEFT child next to its parent).  Only the
+    // numbering changes: same nodes, same boxes, same traversal order, bit-identical results.
+    {
+      std::vector<uint32_t> roots; // subtree roots waiting to be laid out (a stack: depth-first over treelets)
+      for (size_t q = queue.size(); q-- > 0;)
+        if (ref[queue[q]] == INT32_MAX) roots.push_back(queue[q]); // discovered by the top's BFS but beyond its budget
+      std::vector<uint32_t> local;
+      while (!roots.empty()) {
+        const uint32_t root = roots.back();
+        roots.pop_back();
+        local.assign(1, root);
+        for (size_t q = 0; q < local.size(); ++q) {
+          const uint32_t i = local[q];
+          ref[i] = (int32_t)next++;
+          const uint32_t ch[2] = {(uint32_t)word(i, 0), (uint32_t)word(i, 1)};
+          for (uint32_t c : ch)
+            if (word(c, 2) <= -1 && local.size() < (size_t)FSPT_NODE_TREELET) local.push_back(c);
+        }
+        // children of the treelet's nodes that did not fit: roots of the next treelets (right before left on the
+        // stack, so the left subtree is laid out first, like pre-order)
+        for (size_t q = local.size(); q-- > 0;) {
+          const uint32_t i = local[q];
+          const uint32_t ch[2] = {(uint32_t)word(i, 1), (uint32_t)word(i, 0)};
+          for (uint32_t c : ch)
+            if (word(c, 2) <= -1 && ref[c] == INT32_MAX) roots.push_back(c);
+        }
+      }
+    }
+#endif
     for (uint32_t i = 0; i < N; ++i)
-      if (ref[i] == INT32_MAX) ref[i] = (int32_t)next++;
+      if (ref[i] == INT32_MAX) ref[i] = (int32_t)next++; // (pre-order for whatever is left: nothing, with treelets)
   }
   std::vector<float> nodes((size_t)(n_interior ? n_interior : 1) * 16, 0.0f);
   // depth of every node (root 0); a child's depth = parent's + 1
@@ -267,9 +333,27 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   if (e == hipSuccess) e = upload(&s->nodes, nodes.data(), nodes.size() * 4);
   if (e == hipSuccess) e = upload(&s->tris, tris.data(), tris.size() * 4);
   if (e == hipSuccess) e = upload(&s->shade, shade.data(), shade.size() * 4);
-  if (e == hipSuccess)
-    e = upload(&s->atlas, desc->atlas, (size_t)desc->atlas_res * desc->atlas_res * desc->atlas_layers * 4);
-  if (e == hipSuccess && desc->env) e = upload(&s->env, desc->env, (size_t)desc->env_w * desc->env_h * 4);
+  // textures: 8 x 4-texel tiles (one 128-byte line per tile); the 1 x 1 flat-colour atlas stays a plain table
+  uint32_t layer_stride = desc->atlas_res * desc->atlas_res;
+  if (e == hipSuccess) {
+    if (desc->atlas_res > 1) {
+      std::vector<uint32_t> tiled;
+      layer_stride = (uint32_t)tile_image(nullptr, desc->atlas_res, desc->atlas_res, tiled);
+      std::vector<uint32_t> all((size_t)layer_stride * desc->atlas_layers);
+      for (uint32_t l = 0; l < desc->atlas_layers; ++l) {
+        tile_image(desc->atlas + (size_t)l * desc->atlas_res * desc->atlas_res * 4, desc->atlas_res, desc->atlas_res, tiled);
+        std::memcpy(&all[(size_t)l * layer_stride], tiled.data(), (size_t)layer_stride * 4);
+      }
+      e = upload(&s->atlas, all.data(), all.size() * 4);
+    } else {
+      e = upload(&s->atlas, desc->atlas, (size_t)desc->atlas_layers * 4);
+    }
+  }
+  if (e == hipSuccess && desc->env) {
+    std::vector<uint32_t> tiled;
+    tile_image(desc->env, desc->env_w, desc->env_h, tiled);
+    e = upload(&s->env, tiled.data(), tiled.size() * 4);
+  }
   if (e == hipSuccess) e = upload(&s->bins, desc->bins, (size_t)desc->n_bins * 16);
   if (e != hipSuccess) {
     fspt_set_error("scene upload failed: %s", hipGetErrorString(e));
@@ -283,6 +367,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   s->d.env = (const uint32_t *)s->env;
   s->d.bins = (const uint4 *)s->bins;
   s->d.atlas_res = desc->atlas_res;
+  s->d.atlas_layer_stride = layer_stride;
   s->d.atlas_layers = desc->atlas_layers;
   s->d.env_w = desc->env ? desc->env_w : 0;
   s->d.env_h = desc->env ? desc->env_h : 0;
@@ -359,6 +444,7 @@ int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **
 
 int fspt_target_destroy(fspt_target *t) {
   if (!t) return FSPT_OK;
+  t->pending.clear(); // recorded ticks nobody can observe any more
   hipSetDevice(t->scene->device);
   if (t->stream) hipStreamSynchronize(t->stream);
   hipFree(t->accum_own); hipFree(t->ray_pos); hipFree(t->ray_dir); hipFree(t->work_counters); hipFree(t->counters);
@@ -381,6 +467,7 @@ int fspt_target_destroy(fspt_target *t) {
 
 int fspt_target_set_shard(fspt_target *t, uint32_t shard, uint32_t n_shards, uint32_t tile) {
   if (!t) { fspt_set_error("fspt_target_set_shard: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   if (n_shards == 0 || shard >= n_shards) { fspt_set_error("shard %u of %u invalid", shard, n_shards); return FSPT_E_INVALID; }
   if (tile == 0 || tile % 8 != 0 || tile > 256) { fspt_set_error("tile %u must be a multiple of 8 in [8,256]", tile); return FSPT_E_INVALID; }
   t->shard = shard; t->n_shards = n_shards; t->tile = tile;
@@ -389,6 +476,7 @@ int fspt_target_set_shard(fspt_target *t, uint32_t shard, uint32_t n_shards, uin
 
 int fspt_target_bind_accumulator(fspt_target *t, void *device_ptr) {
   if (!t) { fspt_set_error("fspt_target_bind_accumulator: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   t->accum = device_ptr ? (float4 *)device_ptr : t->accum_own;
   return FSPT_OK;
 }
@@ -402,11 +490,14 @@ int fspt_target_accumulator(fspt_target *t, void **device_ptr) {
 int fspt_camera(fspt_target *t, const float P[3], const float I[3], float fov_scale, const float lens[2],
                 float rand_base) {
   if (!t || !P || !I || !lens) { fspt_set_error("fspt_camera: NULL argument"); return FSPT_E_INVALID; }
-  HIP_TRY(hipSetDevice(t->scene->device));
-  fspt::CameraP c;
-  std::memcpy(c.P, P, 12); std::memcpy(c.I, I, 12);
-  c.fov_scale = fov_scale; c.lens[0] = lens[0]; c.lens[1] = lens[1];
-  HIP_TRY(fspt::launch_camera(t->W, t->H, t->vw, t->vh, c, rand_base, t->ray_pos, t->ray_dir, t->stream));
+  // drawCamera is recorded, not launched: the ticks that use these rays generate them inside the path kernel (the ray
+  // textures are only written when somebody looks at them: fspt_read_rays, fspt_trace_test)
+  std::memset(&t->last_cam, 0, sizeof(t->last_cam));
+  std::memcpy(t->last_cam.P, P, 12); std::memcpy(t->last_cam.I, I, 12);
+  t->last_cam.fov_scale = fov_scale; t->last_cam.lens[0] = lens[0]; t->last_cam.lens[1] = lens[1];
+  t->last_rb_cam = rand_base;
+  t->cam_recorded = true;
+  t->rays_injected = false;
   t->rays_valid = true;
   return FSPT_OK;
 }
@@ -414,6 +505,9 @@ int fspt_camera(fspt_target *t, const float P[3], const float I[3], float fov_sc
 int fspt_set_rays(fspt_target *t, const float *pos, const float *dir) {
   if (!t || !pos || !dir) { fspt_set_error("fspt_set_rays: NULL argument"); return FSPT_E_INVALID; }
   HIP_TRY(hipSetDevice(t->scene->device));
+  FLUSH_OR_RETURN(t);
+  t->cam_recorded = false;
+  t->rays_injected = true;
   size_t bytes = (size_t)t->W * t->H * 16;
   HIP_TRY(hipMemcpyAsync(t->ray_pos, pos, bytes, hipMemcpyHostToDevice, t->stream));
   HIP_TRY(hipMemcpyAsync(t->ray_dir, dir, bytes, hipMemcpyHostToDevice, t->stream));
@@ -426,6 +520,8 @@ int fspt_read_rays(fspt_target *t, float *pos, float *dir) {
   if (!t || !pos || !dir) { fspt_set_error("fspt_read_rays: NULL argument"); return FSPT_E_INVALID; }
   if (!t->rays_valid) { fspt_set_error("fspt_read_rays: no rays generated yet"); return FSPT_E_STATE; }
   HIP_TRY(hipSetDevice(t->scene->device));
+  FLUSH_OR_RETURN(t);
+  { int rcm = materialise_rays(t); if (rcm) return rcm; }
   size_t bytes = (size_t)t->W * t->H * 16;
   HIP_TRY(hipMemcpyAsync(pos, t->ray_pos, bytes, hipMemcpyDeviceToHost, t->stream));
   HIP_TRY(hipMemcpyAsync(dir, t->ray_dir, bytes, hipMemcpyDeviceToHost, t->stream));
@@ -666,11 +762,93 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
 // (WfCounts[WF_ROUNDS_MAX + 2], the 8-bit bounce field of the path flags) in range for any caller value.
 static uint32_t clamp_bounces(uint32_t nb) { return nb > (uint32_t)FSPT_MAX_BOUNCES ? (uint32_t)FSPT_MAX_BOUNCES : nb; }
 
+// n_ticks ticks with ray generation in the path kernels and explicit per-tick randBase values, on either pipeline
+static int render_ticks(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
+                        const float *rbc, const float *rbt) {
+  t->ev_used = 0; t->ev_overflow = false;
+  if (t->pipeline == 1) {
+    HIP_TRY(hipEventRecord(t->ev0, t->stream));
+    int rc = render_wavefront(t, cam, first_tick, n_ticks, rbc, rbt, false);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(t->ev1, t->stream));
+    t->timed = true; t->last_launches = n_ticks;
+    return FSPT_OK;
+  }
+  fspt::TraceP p{};
+  fill_trace_params(t, p);
+  std::memcpy(p.cam.P, cam->P, 12); std::memcpy(p.cam.I, cam->I, 12);
+  p.cam.fov_scale = cam->fov_scale; p.cam.lens[0] = cam->lens[0]; p.cam.lens[1] = cam->lens[1];
+  p.env_theta = cam->env_theta; p.num_bounces = cam->num_bounces;
+  bool first = true;
+  uint32_t done = 0;
+  while (done < n_ticks) {
+    uint32_t batch = n_ticks - done < WORK_RING ? n_ticks - done : WORK_RING;
+    HIP_TRY(hipMemsetAsync(t->work_counters, 0, (size_t)batch * 4, t->stream));
+    if (first) { HIP_TRY(hipEventRecord(t->ev0, t->stream)); first = false; }
+    for (uint32_t k = 0; k < batch; ++k) {
+      p.rand_base_cam = rbc[done + k];
+      p.rand_base = rbt[done + k];
+      p.tick = first_tick + done + k;
+      p.work_counter = t->work_counters + k;
+      HIP_TRY(fspt::launch_trace(p, true, t->count != 0, t->scene->num_cus, t->stream));
+    }
+    done += batch;
+  }
+  HIP_TRY(hipEventRecord(t->ev1, t->stream));
+  t->timed = true; t->last_launches = n_ticks;
+  return FSPT_OK;
+}
+
+// Execute the recorded two-call ticks: runs of consecutive ticks with the same camera / envTheta / NUM_BOUNCES go
+// through the batched path (ray generation in the kernel from the recorded randBase values - the same arithmetic as
+// k_camera followed by a trace of the ray buffers, tests/test_parity_gpu.py).  Called by everything that observes or
+// changes state the ticks depend on.
+static bool same_view(const fspt_camera_params &a, const fspt_camera_params &b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
+static int flush_pending(fspt_target *t) {
+  if (t->pending.empty()) return FSPT_OK;
+  std::vector<fspt_target::Deferred> q;
+  q.swap(t->pending); // (a failing batch drops the rest: the error is reported once)
+  HIP_TRY(hipSetDevice(t->scene->device));
+  std::vector<float> rbc, rbt;
+  size_t i = 0;
+  while (i < q.size()) {
+    size_t j = i + 1;
+    while (j < q.size() && same_view(q[j].cam, q[i].cam) && q[j].tick == q[j - 1].tick + 1) ++j;
+    rbc.clear(); rbt.clear();
+    for (size_t k = i; k < j; ++k) { rbc.push_back(q[k].rb_cam); rbt.push_back(q[k].rb_trace); }
+    int rc = render_ticks(t, &q[i].cam, q[i].tick, (uint32_t)(j - i), rbc.data(), rbt.data());
+    if (rc) return rc;
+    i = j;
+  }
+  return FSPT_OK;
+}
+
+// the ray buffers as the most recent fspt_camera call left them (drawCamera's two render targets)
+static int materialise_rays(fspt_target *t) {
+  if (!t->cam_recorded) return FSPT_OK;
+  fspt::CameraP c;
+  std::memcpy(c.P, t->last_cam.P, 12); std::memcpy(c.I, t->last_cam.I, 12);
+  c.fov_scale = t->last_cam.fov_scale; c.lens[0] = t->last_cam.lens[0]; c.lens[1] = t->last_cam.lens[1];
+  HIP_TRY(fspt::launch_camera(t->W, t->H, t->vw, t->vh, c, t->last_rb_cam, t->ray_pos, t->ray_dir, t->stream));
+  t->cam_recorded = false;
+  return FSPT_OK;
+}
+
 int fspt_trace(fspt_target *t, uint32_t tick, float rand_base, float env_theta, uint32_t num_bounces) {
   if (!t) { fspt_set_error("fspt_trace: NULL target"); return FSPT_E_INVALID; }
   if (!t->rays_valid) { fspt_set_error("fspt_trace: call fspt_camera or fspt_set_rays first"); return FSPT_E_STATE; }
   HIP_TRY(hipSetDevice(t->scene->device));
   num_bounces = clamp_bounces(num_bounces);
+  if (!t->rays_injected) {
+    // rays come from fspt_camera: record the tick; it runs with its neighbours in one batch at the next flush point
+    fspt_target::Deferred d;
+    d.cam = t->last_cam; d.cam.env_theta = env_theta; d.cam.num_bounces = num_bounces;
+    d.rb_cam = t->last_rb_cam; d.tick = tick; d.rb_trace = rand_base;
+    t->pending.push_back(d);
+    if (!t->defer || t->pending.size() >= (size_t)t->batch_ticks) return flush_pending(t);
+    return FSPT_OK;
+  }
+  FLUSH_OR_RETURN(t);
   if (t->pipeline == 1) {
     fspt_camera_params cp{};
     cp.env_theta = env_theta; cp.num_bounces = num_bounces;
@@ -699,6 +877,9 @@ int fspt_trace_test(fspt_target *t, uint32_t tick) {
   if (!t) { fspt_set_error("fspt_trace_test: NULL target"); return FSPT_E_INVALID; }
   if (!t->rays_valid) { fspt_set_error("fspt_trace_test: call fspt_camera or fspt_set_rays first"); return FSPT_E_STATE; }
   HIP_TRY(hipSetDevice(t->scene->device));
+  FLUSH_OR_RETURN(t);
+  int rcm = materialise_rays(t);
+  if (rcm) return rcm;
   fspt::TraceP p{};
   fill_trace_params(t, p);
   p.tick = tick;
@@ -714,50 +895,26 @@ int fspt_render(fspt_target *t, const fspt_camera_params *cam_in, uint32_t first
   if (!t || !cam_in) { fspt_set_error("fspt_render: NULL argument"); return FSPT_E_INVALID; }
   if (n_ticks == 0) return FSPT_OK;
   HIP_TRY(hipSetDevice(t->scene->device));
+  FLUSH_OR_RETURN(t);
   fspt_camera_params cam_c = *cam_in;
   cam_c.num_bounces = clamp_bounces(cam_c.num_bounces);
-  const fspt_camera_params *cam = &cam_c;
-  t->ev_used = 0; t->ev_overflow = false;
-  if (t->pipeline == 1) {
-    std::vector<float> rbc(n_ticks), rbt(n_ticks);
-    uint64_t st0 = seed;
-    for (uint32_t k = 0; k < n_ticks; ++k) { rbc[k] = fspt_rand_base_next(&st0); rbt[k] = fspt_rand_base_next(&st0); }
-    HIP_TRY(hipEventRecord(t->ev0, t->stream));
-    int rc = render_wavefront(t, cam, first_tick, n_ticks, rbc.data(), rbt.data(), false);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(t->ev1, t->stream));
-    t->timed = true; t->last_launches = n_ticks;
-    return FSPT_OK;
-  }
-  fspt::TraceP p{};
-  fill_trace_params(t, p);
-  std::memcpy(p.cam.P, cam->P, 12); std::memcpy(p.cam.I, cam->I, 12);
-  p.cam.fov_scale = cam->fov_scale; p.cam.lens[0] = cam->lens[0]; p.cam.lens[1] = cam->lens[1];
-  p.env_theta = cam->env_theta; p.num_bounces = cam->num_bounces;
-  uint64_t st = seed;
-  bool first = true;
-  uint32_t done = 0;
-  while (done < n_ticks) {
-    uint32_t batch = n_ticks - done < WORK_RING ? n_ticks - done : WORK_RING;
-    HIP_TRY(hipMemsetAsync(t->work_counters, 0, (size_t)batch * 4, t->stream));
-    if (first) { HIP_TRY(hipEventRecord(t->ev0, t->stream)); first = false; }
-    for (uint32_t k = 0; k < batch; ++k) {
-      p.rand_base_cam = fspt_rand_base_next(&st);
-      p.rand_base = fspt_rand_base_next(&st);
-      p.tick = first_tick + done + k;
-      p.work_counter = t->work_counters + k;
-      HIP_TRY(fspt::launch_trace(p, true, t->count != 0, t->scene->num_cus, t->stream));
-    }
-    done += batch;
-  }
-  HIP_TRY(hipEventRecord(t->ev1, t->stream));
-  t->timed = true; t->last_launches = n_ticks;
+  std::vector<float> rbc(n_ticks), rbt(n_ticks);
+  uint64_t st0 = seed;
+  for (uint32_t k = 0; k < n_ticks; ++k) { rbc[k] = fspt_rand_base_next(&st0); rbt[k] = fspt_rand_base_next(&st0); }
+  return render_ticks(t, &cam_c, first_tick, n_ticks, rbc.data(), rbt.data());
+}
+
+int fspt_target_set_deferred(fspt_target *t, int enable) {
+  if (!t) { fspt_set_error("fspt_target_set_deferred: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
+  t->defer = enable != 0;
   return FSPT_OK;
 }
 
 int fspt_clear(fspt_target *t) {
   if (!t) { fspt_set_error("fspt_clear: NULL target"); return FSPT_E_INVALID; }
   HIP_TRY(hipSetDevice(t->scene->device));
+  FLUSH_OR_RETURN(t);
   HIP_TRY(hipMemsetAsync(t->accum, 0, (size_t)t->W * t->H * 16, t->stream));
   return FSPT_OK;
 }
@@ -765,6 +922,7 @@ int fspt_clear(fspt_target *t) {
 int fspt_sync(fspt_target *t) {
   if (!t) { fspt_set_error("fspt_sync: NULL target"); return FSPT_E_INVALID; }
   HIP_TRY(hipSetDevice(t->scene->device));
+  FLUSH_OR_RETURN(t);
   HIP_TRY(hipStreamSynchronize(t->stream));
   return FSPT_OK;
 }
@@ -772,6 +930,7 @@ int fspt_sync(fspt_target *t) {
 int fspt_read_radiance(fspt_target *t, float *out) {
   if (!t || !out) { fspt_set_error("fspt_read_radiance: NULL argument"); return FSPT_E_INVALID; }
   HIP_TRY(hipSetDevice(t->scene->device));
+  FLUSH_OR_RETURN(t);
   HIP_TRY(hipMemcpyAsync(out, t->accum, (size_t)t->W * t->H * 16, hipMemcpyDeviceToHost, t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
   return FSPT_OK;
@@ -786,6 +945,7 @@ int fspt_draw_scaled(fspt_target *t, float exposure, float saturation, int denoi
   if (!t || !out_rgba8) { fspt_set_error("fspt_draw: NULL argument"); return FSPT_E_INVALID; }
   if (!(scale > 0.0f && scale <= 1.0f)) { fspt_set_error("fspt_draw: scale must be in (0, 1]"); return FSPT_E_INVALID; }
   HIP_TRY(hipSetDevice(t->scene->device));
+  FLUSH_OR_RETURN(t);
   size_t n = (size_t)t->W * t->H;
   uint32_t *d = nullptr;
   HIP_TRY(hipMalloc((void **)&d, n * 4));
@@ -799,6 +959,7 @@ int fspt_draw_scaled(fspt_target *t, float exposure, float saturation, int denoi
 
 int fspt_last_kernel_ms(fspt_target *t, float *ms, uint32_t *launches) {
   if (!t || !ms) { fspt_set_error("fspt_last_kernel_ms: NULL argument"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   if (!t->timed) { fspt_set_error("fspt_last_kernel_ms: nothing traced yet"); return FSPT_E_STATE; }
   HIP_TRY(hipSetDevice(t->scene->device));
   HIP_TRY(hipEventSynchronize(t->ev1));
@@ -809,6 +970,7 @@ int fspt_last_kernel_ms(fspt_target *t, float *ms, uint32_t *launches) {
 
 int fspt_target_set_viewport(fspt_target *t, uint32_t w, uint32_t h) {
   if (!t) { fspt_set_error("fspt_target_set_viewport: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   if (w > t->W || h > t->H) { fspt_set_error("fspt_target_set_viewport: %ux%u exceeds the target %ux%u", w, h, t->W, t->H); return FSPT_E_INVALID; }
   t->vw = w ? w : t->W;
   t->vh = h ? h : t->H;
@@ -817,6 +979,7 @@ int fspt_target_set_viewport(fspt_target *t, uint32_t w, uint32_t h) {
 
 int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks) {
   if (!t) { fspt_set_error("fspt_target_set_pipeline: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   if (pipeline < 0 || pipeline > 2) { fspt_set_error("pipeline must be 0 (megakernel), 1 (wavefront) or 2 (wavefront, two lanes)"); return FSPT_E_INVALID; }
   if (batch_ticks > (uint32_t)fspt::WF_MAX_BATCH * (pipeline == 2 ? 2u : 1u)) {
     fspt_set_error("batch_ticks must be <= %d per lane", fspt::WF_MAX_BATCH);
@@ -830,13 +993,28 @@ int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks)
 
 int fspt_target_set_tail(fspt_target *t, int round) {
   if (!t) { fspt_set_error("fspt_target_set_tail: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   if (round < -1 || round > FSPT_MAX_BOUNCES + 1) { fspt_set_error("fspt_target_set_tail: round must be -1 (adaptive), 0 (never) or 1..%d", FSPT_MAX_BOUNCES + 1); return FSPT_E_INVALID; }
   t->tail_round = round;
   return FSPT_OK;
 }
 
+int fspt_target_live_paths(fspt_target *t, double *frac, uint32_t n_rounds) {
+  if (!t || !frac) { fspt_set_error("fspt_target_live_paths: NULL argument"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
+  HIP_TRY(hipSetDevice(t->scene->device));
+  for (auto &ln : t->lanes) {
+    if (!ln.counts_pending) continue;
+    HIP_TRY(hipEventSynchronize(ln.counts_ready));
+    wf_collect_counts(t, ln);
+  }
+  for (uint32_t r = 0; r < n_rounds; ++r) frac[r] = (t->live_known && r < 80) ? (double)t->live_frac[r] : 0.0;
+  return t->live_known ? FSPT_OK : FSPT_E_STATE;
+}
+
 int fspt_target_set_memory_limit(fspt_target *t, uint64_t bytes) {
   if (!t) { fspt_set_error("fspt_target_set_memory_limit: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   t->mem_limit = bytes;
   return FSPT_OK;
 }
@@ -852,6 +1030,7 @@ int fspt_target_path_state_bytes(fspt_target *t, uint64_t *bytes, uint32_t *batc
 
 int fspt_target_prepare(fspt_target *t) {
   if (!t) { fspt_set_error("fspt_target_prepare: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   HIP_TRY(hipSetDevice(t->scene->device));
   if (t->pipeline != 1) return FSPT_OK;
   fspt::TraceP tp{};
@@ -864,6 +1043,7 @@ int fspt_target_prepare(fspt_target *t) {
 
 int fspt_last_stage_ms(fspt_target *t, float ms[5], uint32_t launches[5]) {
   if (!t || !ms || !launches) { fspt_set_error("fspt_last_stage_ms: NULL argument"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   HIP_TRY(hipSetDevice(t->scene->device));
   HIP_TRY(hipStreamSynchronize(t->stream));
   for (int k = 0; k < fspt::WF_K_KINDS; ++k) { ms[k] = 0.0f; launches[k] = 0; }
@@ -879,12 +1059,14 @@ int fspt_last_stage_ms(fspt_target *t, float ms[5], uint32_t launches[5]) {
 
 int fspt_enable_counters(fspt_target *t, int enable) {
   if (!t) { fspt_set_error("fspt_enable_counters: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   t->count = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
   return FSPT_OK;
 }
 
 int fspt_counters_reset(fspt_target *t) {
   if (!t) { fspt_set_error("fspt_counters_reset: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   HIP_TRY(hipSetDevice(t->scene->device));
   HIP_TRY(hipMemsetAsync(t->counters, 0, 48, t->stream));
   return FSPT_OK;
@@ -892,6 +1074,7 @@ int fspt_counters_reset(fspt_target *t) {
 
 int fspt_get_counters(fspt_target *t, fspt_counters *out) {
   if (!t || !out) { fspt_set_error("fspt_get_counters: NULL argument"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
   HIP_TRY(hipSetDevice(t->scene->device));
   unsigned long long v[6];
   HIP_TRY(hipMemcpyAsync(v, t->counters, 48, hipMemcpyDeviceToHost, t->stream));
@@ -1009,6 +1192,7 @@ int fspt_multi_sync(fspt_multi *m) { MULTI_EACH(fspt_sync(t)); }
 static int multi_gather(fspt_multi *m) {
   fspt_target *t0 = m->targets[0];
   m->gather_bytes = 0;
+  for (fspt_target *t : m->targets) FLUSH_OR_RETURN(t); // recorded two-call ticks of every device run before its tiles are packed
   for (size_t i = 1; i < m->targets.size(); ++i) {
     fspt_target *t = m->targets[i];
     fspt::TilePackP q{};

@@ -17,6 +17,15 @@ constexpr float M_TAU_F = M_PI_F * 2.0f; // tracer.fs:13
 constexpr float INV_PI_F = 1.0f / M_PI_F;
 constexpr int MAX_PATH_ITERS = 64;       // cap on tracer.fs:488's unbounded i--
 
+// Textures (environment, atlas layers with res > 1) are stored in tiles of 8 x 4 texels = 128 bytes = one cache line
+// (rows of tiles, a tile's texels row-major), images padded to whole tiles.
+#ifndef FSPT_TEX_TILE_W_LOG2
+#define FSPT_TEX_TILE_W_LOG2 3
+#define FSPT_TEX_TILE_H_LOG2 2
+#endif
+constexpr int TEX_TILE_W_LOG2 = FSPT_TEX_TILE_W_LOG2, TEX_TILE_H_LOG2 = FSPT_TEX_TILE_H_LOG2; // 0, 0 = plain row-major (A/B)
+constexpr int TEX_TILE_W = 1 << TEX_TILE_W_LOG2, TEX_TILE_H = 1 << TEX_TILE_H_LOG2;
+
 constexpr int NODE_F4 = 4;   // 64-byte two-child node = 4 x float4
 constexpr int TRI_FLOATS = 9;  // 36-byte packed pre-edged triangle (traversal)
 constexpr int HITREC_F4 = 12; // 192-byte hit record (shading) = 12 x float4 = exactly 3 cache lines
@@ -36,10 +45,11 @@ struct DScene {
   const float4 *nodes;
   const float *tris;    // packed 9-float triangles (+ LEAF_SIZE padding records)
   const float4 *hitrec; // 12 x float4 per triangle
-  const uint32_t *atlas; // RGBA8 texels, layer-major
-  const uint32_t *env;   // RGBE texels (NULL = black default environment)
+  const uint32_t *atlas; // RGBA8 texels, layer-major; res > 1: every layer tiled (TEX_TILE_*), atlas_layer_stride texels apart
+  const uint32_t *env;   // RGBE texels, tiled (NULL = black default environment)
   const uint4 *bins;
   uint32_t atlas_res, atlas_layers;
+  uint32_t atlas_layer_stride;
   uint32_t env_w, env_h;
   uint32_t n_bins;
   uint32_t leaf_size;

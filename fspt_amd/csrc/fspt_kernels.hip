@@ -199,8 +199,17 @@ FM_DEV float safe_floor_coord(float u) {
   return f;
 }
 struct Tap4 { uint32_t t00, t10, t01, t11; float a, b; };
-FM_DEV Tap4 bilinear_taps(const uint32_t *texels, int w, int h, float s, float t, bool repeat_t) {
-  Tap4 r;
+// Texel (i, j) of a w-wide image stored in 8 x 4-texel tiles (fspt_device.hpp: TEX_TILE_*): one tile = one 128-byte
+// cache line, so the 2 x 2 footprint of a bilinear fetch lies in 1.4 lines on average instead of 2 rows = 2 lines.
+FM_DEV uint32_t tex_offset(int i, int j, int tiles_x) {
+  return (uint32_t)(((j >> TEX_TILE_H_LOG2) * tiles_x + (i >> TEX_TILE_W_LOG2)) << (TEX_TILE_W_LOG2 + TEX_TILE_H_LOG2)) +
+         (uint32_t)(((j & (TEX_TILE_H - 1)) << TEX_TILE_W_LOG2) + (i & (TEX_TILE_W - 1)));
+}
+// Footprint of a bilinear fetch at (s, t): the four texel offsets and the two weights.  Shared by the four atlas layers
+// a shading event reads at the same uv (tracer.fs:453-456): the wrap / floor / tile arithmetic is done once.
+struct TapGeom { uint32_t o00, o10, o01, o11; float a, b; bool pair; };
+FM_DEV TapGeom bilinear_geom(int w, int h, float s, float t, bool repeat_t) {
+  TapGeom g;
   float u = fma_(s, (float)w, -0.5f), v = fma_(t, (float)h, -0.5f);
   float fu = safe_floor_coord(u), fv = safe_floor_coord(v);
   float a = u - fu, b = v - fv;
@@ -212,38 +221,42 @@ FM_DEV Tap4 bilinear_taps(const uint32_t *texels, int w, int h, float s, float t
   int j1, j0w;
   if (repeat_t) { j1 = wrap_repeat(j0 + 1, h); j0w = wrap_repeat(j0, h); }
   else { j1 = wrap_clamp(j0 + 1, h); j0w = wrap_clamp(j0, h); }
-#if FSPT_TAP2
-  // the two taps of a row are neighbours unless the column wraps: one 8-byte load (dword-aligned) instead of two
-  // 4-byte loads - half the lane-requests on the vector-memory pipeline, same texel values
+  const int tiles_x = (w + TEX_TILE_W - 1) >> TEX_TILE_W_LOG2;
+  g.o00 = tex_offset(i0, j0w, tiles_x); g.o01 = tex_offset(i0, j1, tiles_x);
+  g.o10 = tex_offset(i1, j0w, tiles_x); g.o11 = tex_offset(i1, j1, tiles_x);
+  // the two taps of a row are neighbours unless the column wraps or leaves the tile: one 8-byte load (dword-aligned)
+  // instead of two 4-byte loads - half the lane-requests on the vector-memory pipeline, same texel values
+  g.pair = FSPT_TAP2 && i1 == i0 + 1 && (TEX_TILE_W == 1 || (i0 & (TEX_TILE_W - 1)) != TEX_TILE_W - 1);
+  g.a = a; g.b = b;
+  return g;
+}
+FM_DEV Tap4 fetch_taps(const uint32_t *texels, const TapGeom &g) {
+  Tap4 r;
   typedef uint32_t u2a __attribute__((ext_vector_type(2), aligned(4)));
-  const uint32_t *r0 = texels + (size_t)j0w * w, *r1 = texels + (size_t)j1 * w;
-  if (i1 == i0 + 1) {
-    u2a q0 = *reinterpret_cast<const u2a *>(r0 + i0), q1 = *reinterpret_cast<const u2a *>(r1 + i0);
+  if (g.pair) {
+    u2a q0 = *reinterpret_cast<const u2a *>(texels + g.o00), q1 = *reinterpret_cast<const u2a *>(texels + g.o01);
     r.t00 = q0.x; r.t10 = q0.y; r.t01 = q1.x; r.t11 = q1.y;
   } else {
-    r.t00 = r0[i0]; r.t10 = r0[i1]; r.t01 = r1[i0]; r.t11 = r1[i1];
+    r.t00 = texels[g.o00]; r.t10 = texels[g.o10];
+    r.t01 = texels[g.o01]; r.t11 = texels[g.o11];
   }
-#else
-  r.t00 = texels[(size_t)j0w * w + i0];
-  r.t10 = texels[(size_t)j0w * w + i1];
-  r.t01 = texels[(size_t)j1 * w + i0];
-  r.t11 = texels[(size_t)j1 * w + i1];
-#endif
-  r.a = a; r.b = b;
+  r.a = g.a; r.b = g.b;
   return r;
+}
+FM_DEV Tap4 bilinear_taps(const uint32_t *texels, int w, int h, float s, float t, bool repeat_t) {
+  return fetch_taps(texels, bilinear_geom(w, h, s, t, repeat_t));
 }
 FM_DEV float tap_channel(const Tap4 &tp, int ch) {
   float t00 = unorm8((tp.t00 >> (8 * ch)) & 255u), t10 = unorm8((tp.t10 >> (8 * ch)) & 255u);
   float t01 = unorm8((tp.t01 >> (8 * ch)) & 255u), t11 = unorm8((tp.t11 >> (8 * ch)) & 255u);
   return lerp_(lerp_(t00, t10, tp.a), lerp_(t01, t11, tp.a), tp.b);
 }
-// texture(texArray, vec3(uv, layer)) (tracer.fs:453-456)
-FM_DEV Tap4 atlas_taps(const DScene &S, float u, float v, float layer) {
+// texture(texArray, vec3(uv, layer)) (tracer.fs:453-456): the layer's texels for a footprint computed once per uv
+FM_DEV Tap4 atlas_taps(const DScene &S, const TapGeom &g, float layer) {
   int l = (int)floor_(layer + 0.5f);
   if (l < 0) l = 0;
   if (l > (int)S.atlas_layers - 1) l = (int)S.atlas_layers - 1;
-  const uint32_t *base = S.atlas + (size_t)l * S.atlas_res * S.atlas_res;
-  return bilinear_taps(base, (int)S.atlas_res, (int)S.atlas_res, u, v, true);
+  return fetch_taps(S.atlas + (size_t)l * S.atlas_layer_stride, g);
 }
 // envSample + envColor (tracer.fs:410-419)
 template <bool COUNT>
@@ -473,14 +486,18 @@ FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randB
     texNormal = v3((unorm8(q & 255u) - 0.5f) * 2.0f, (unorm8((q >> 8) & 255u) - 0.5f) * 2.0f,
                    (unorm8((q >> 16) & 255u) - 0.0f) * 1.0f);
   } else {
-    Tap4 q = atlas_taps(S, tcx, tcy, layDiffuse);
+    const TapGeom tg = bilinear_geom((int)S.atlas_res, (int)S.atlas_res, tcx, tcy, true);
+    // all eight loads of the four layers are issued before the first texel is decoded
+    const Tap4 qd = atlas_taps(S, tg, layDiffuse), qe = atlas_taps(S, tg, laySpec), qr = atlas_taps(S, tg, layRough),
+               qn = atlas_taps(S, tg, layNormal);
+    Tap4 q = qd;
     texDiffuse = v3(tap_channel(q, 0), tap_channel(q, 1), tap_channel(q, 2));
-    q = atlas_taps(S, tcx, tcy, laySpec);
+    q = qe;
     texEmissive = v3(tap_channel(q, 0), tap_channel(q, 1), tap_channel(q, 2));
-    q = atlas_taps(S, tcx, tcy, layRough);
+    q = qr;
     metallic = tap_channel(q, 0);
     rough = tap_channel(q, 1);
-    q = atlas_taps(S, tcx, tcy, layNormal);
+    q = qn;
     texNormal = v3((tap_channel(q, 0) - 0.5f) * 2.0f, (tap_channel(q, 1) - 0.5f) * 2.0f,
                    (tap_channel(q, 2) - 0.0f) * 1.0f);
   }
@@ -743,7 +760,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 // (layout and slot numbering: fspt_device.hpp)
 // ===========================================================================
 #ifndef WF_TRACE_CHUNK
-#define WF_TRACE_CHUNK 1024u // measured at 128-tick batches: 256 / 512 / 1024 -> trace 0.317 / 0.223 / 0.214 ms per tick; 2048+ and guided (shrinking) chunk sizes are slower
+#define WF_TRACE_CHUNK 512u // cap of the pool chunk (paths).  Measured (profiles/r02, per-path items): 128 / 256 / 512 / 1024 -> 3 970 / 4 807 / 4 893 / 4 882 Msamples/s at 128-tick batches, 3 240 / 3 700 / 3 660 / 3 510 at 20 ticks (a draw stalls the wave for a memory-side atomic round trip)
 #endif
 // measured on C2 (profiles/r01): 1 -> 0.462, 8 -> 0.348, 16 -> 0.338, 24 -> 0.336, 32 -> 0.343 ms per tick
 #ifndef WF_INTERIOR_MIN

@@ -18,7 +18,7 @@
  *   readRadiance(target, Float32Array(W*H*4))                        (what draw.fs:87 reads)
  *   draw(target, exposure, saturation, denoise, maxSigma, Uint8Array(W*H*4))   (drawQuad, main.js:809-824)
  *   setShard(target, shard, nShards, tile) / setPipeline(target, pipeline, batch)
- *   setMemoryLimit(target, bytes) / pathStateBytes(target) -> {bytes, batchTicks} / prepare(target) / setTail(target, round)
+ *   setMemoryLimit(target, bytes) / pathStateBytes(target) -> {bytes, batchTicks} / prepare(target) / setTail(target, round) / setDeferred(target, on)
  *   renderAsync(target, params, firstTick, nTicks, seed) -> Promise   (fspt_render + fspt_sync as napi_async_work)
  *   multiCreate(sceneDesc, [devices], W, H) -> multi handle; multiCamera / multiTrace / multiRender / multiRenderAsync /
  *   multiClear / multiSync / multiReadRadiance / multiDraw / multiTarget(multi, i) / multiDestroy   (fspt_multi_*: one frame
@@ -444,6 +444,13 @@ static napi_value MultiDraw(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_multi_draw((fspt_multi *)h, (float)ex, (float)sat, den ? 1 : 0, (float)sig, (uint8_t *)p));
   return a[5];
 }
+static napi_value SetDeferred(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h; bool on;
+  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_bool(env, a[1], &on));
+  FSPT_OK_OR_THROW(fspt_target_set_deferred((fspt_target *)h, on ? 1 : 0));
+  return undefined(env);
+}
 static napi_value SetTail(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; int32_t r;
   if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
@@ -806,7 +813,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"traceTest", TraceTest}, {"render", Render}, {"clear", Clear},
       {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline},
-      {"setMemoryLimit", SetMemoryLimit}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail},
+      {"setMemoryLimit", SetMemoryLimit}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail}, {"setDeferred", SetDeferred},
       {"renderAsync", RenderAsync}, {"multiCreate", MultiCreate}, {"multiDestroy", MultiDestroy}, {"multiTarget", MultiTarget},
       {"multiCamera", MultiCamera}, {"multiTrace", MultiTrace}, {"multiRender", MultiRender}, {"multiRenderAsync", MultiRenderAsync},
       {"multiClear", MultiClear}, {"multiSync", MultiSync}, {"multiReadRadiance", MultiReadRadiance}, {"multiDraw", MultiDraw},

@@ -331,6 +331,9 @@ class PathTracer {
   setPipeline(name, batch) { addon.setPipeline(this._target, name === 'megakernel' ? 0 : (name === 'wavefront2' ? 2 : 1), batch || 0); }
   /** -1 adaptive (default), 0 never, r >= 1: the tail kernel takes the live paths over after wavefront round r */
   setTail(round) { addon.setTail(this._target, round === undefined ? -1 : round); }
+  /** drawCamera + drawTracer ticks are recorded and run as batches at the next read-out (default, include/fspt.h);
+   *  false: every drawTracer executes at once */
+  setDeferred(on) { addon.setDeferred(this._target, on !== false); }
   /** cap / query the wavefront path state (include/fspt.h: fspt_target_set_memory_limit) and pre-allocate it */
   setMemoryLimit(bytes) { addon.setMemoryLimit(this._target, bytes || 0); }
   pathStateBytes() { return addon.pathStateBytes(this._target); }

@@ -131,6 +131,17 @@ class PathTracer:
         L.check(L.lib().fspt_last_stage_ms(self._t, ms, n))
         return {k: (ms[i], n[i]) for i, k in enumerate(("primary", "trace", "logic", "resolve", "tail"))}
 
+    def set_deferred(self, on=True):
+        """Two-call ticks (drawCamera + drawTracer) are recorded and run in batches at the next read-out (default);
+        False: every drawTracer executes at once."""
+        L.check(L.lib().fspt_target_set_deferred(self._t, 1 if on else 0))
+
+    def live_paths(self, n_rounds=12):
+        """Fraction of the batch's samples still alive after round r (index r; r = 1 is the primary launch)."""
+        f = (C.c_double * n_rounds)()
+        L.check(L.lib().fspt_target_live_paths(self._t, f, n_rounds))
+        return list(f)
+
     def set_tail(self, round=-1):
         """-1: adaptive (default), 0: never, r >= 1: the tail kernel takes over after wavefront round r."""
         L.check(L.lib().fspt_target_set_tail(self._t, int(round)))

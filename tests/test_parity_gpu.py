@@ -169,6 +169,68 @@ def test_clear_and_inject_rays(small_scene, camera):
     assert np.array_equal(a, acc)
 
 
+@pytest.mark.parametrize("pipeline", PIPELINES)
+@pytest.mark.parametrize("deferred", [True, False])
+def test_two_call_ticks_are_batched_bitwise(medium_scene, camera, pipeline, deferred):
+    """The reference's own call pattern (main.js:842-843: drawCamera + drawTracer per tick, nothing read in between) is
+    recorded and executed as wavefront batches at the next read-out: one batch per run of ticks with an unchanged view.
+    7 ticks, the camera moves after the 4th, envTheta changes after the 6th -> 3 batches; an injected-ray tick in between
+    is traced from the buffers at once.  Frame and counters equal the oracle's tick-by-tick run."""
+    W, H, nb = 96, 56, 5
+    pt = make_pt(medium_scene, W, H, camera, nb, pipeline, 0)
+    pt.set_deferred(deferred)
+    pt.enable_counters(1)
+    pt.clear()
+    rbs = O.rand_base_stream(4, 14)
+    acc = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    eye2 = [camera["P"][0] + 0.2, camera["P"][1], camera["P"][2] - 0.1]
+    for k in range(7):
+        if k == 4:
+            pt.eye = eye2
+        if k == 6:
+            pt.envTheta = camera["env_theta"] + 0.25
+        pt.drawCamera(rbs[2 * k]); pt.drawTracer(k, rbs[2 * k + 1])
+        pos, d = O.camera(W, H, pt.eye, camera["I"], camera["fov_scale"], camera["lens"], rbs[2 * k])
+        O.trace(medium_scene, W, H, pos, d, k, rbs[2 * k + 1], pt.envTheta, nb, acc, counters=oc)
+    got = pt.readRadiance()  # the flush point
+    assert np.array_equal(got, acc)
+    assert pt.counters() == oc.as_dict()
+    if pipeline == "wavefront":
+        # the last executed group is the single tick with the new envTheta
+        assert pt.last_stage_ms()["primary"][1] == 1
+    # the ray buffers still show the LAST drawCamera (materialised on demand), and injected rays are traced from them
+    p7, d7 = pt.readRays()
+    pos, d = O.camera(W, H, eye2, camera["I"], camera["fov_scale"], camera["lens"], rbs[12])
+    assert np.array_equal(p7, pos) and np.array_equal(d7, d)
+    pt.setRays(pos[:, ::-1].copy(), d[:, ::-1].copy())
+    pt.drawTracer(7, 55.5)
+    O.trace(medium_scene, W, H, pos[:, ::-1].copy(), d[:, ::-1].copy(), 7, 55.5, pt.envTheta, nb, acc)
+    assert np.array_equal(pt.readRadiance(), acc)
+    # a camera tick after the injected one is generated in the kernel again
+    pt.drawCamera(rbs[13]); pt.drawTracer(8, 77.25)
+    pos, d = O.camera(W, H, eye2, camera["I"], camera["fov_scale"], camera["lens"], rbs[13])
+    O.trace(medium_scene, W, H, pos, d, 8, 77.25, pt.envTheta, nb, acc)
+    assert np.array_equal(pt.readRadiance(), acc)
+    pt.close()
+
+
+def test_deferred_ticks_fill_a_batch(small_scene, camera):
+    """batch_ticks recorded ticks run without waiting for a read-out (bounded memory for a host that never reads)."""
+    W, H = 64, 40
+    pt = make_pt(small_scene, W, H, camera, 3, "wavefront", 4)
+    pt.seed(2)
+    for _ in range(9):
+        pt.tick()
+    # no read-out so far: two batches of 4 have run, one tick is still recorded
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 3,
+             0, 9, 2, want)
+    assert np.array_equal(pt.readRadiance(), want)
+    assert pt.last_stage_ms()["primary"][1] == 1  # the flush at read-out ran the one leftover tick
+    pt.close()
+
+
 def test_trace_before_rays_is_state_error(small_scene):
     pt = PathTracer(small_scene, 16, 16)
     with pytest.raises(L.FsptError) as e:
@@ -375,12 +437,40 @@ def test_textured_scene_bitwise(camera, pipeline):
     assert pt.counters() == oc.as_dict()
 
 
-@pytest.mark.parametrize("aperture", [0.02, 0.1])
-def test_baseline_c1_config_bitwise(aperture):
-    """BASELINE configs[0] - the reference's own CPU-runnable case: 256x256, depth 4, 16 spp on the 69 316-triangle
-    scene - and the same with configs[4]'s aperture 0.1: the whole frame equals the oracle bit for bit."""
+@pytest.mark.parametrize("pipeline,tail", [("wavefront", 0), ("wavefront", 2), ("megakernel", 0)])
+def test_textured_bunny_scene_bitwise(camera, pipeline, tail):
+    """bench.py --textured's scene (scene/bunny.json:18-41: baseColor / metallicRoughness / normal image maps on both
+    quads, an emissive map on the wall) at atlas res 512: 11 layers, the 4 x 4-tap bilinear gather with REPEAT wrap,
+    normal mapping and emission - frame and work counters equal the oracle's."""
     from fspt_amd import scene as S
-    arrays = S.bunny_scene(n=76)
+    arrays = S.bunny_scene_textured(n=16, env_size=(256, 128), res=512)
+    assert arrays.atlas_res == 512 and arrays.atlas_layers == 11
+    W, H = 160, 96
+    pt = make_pt(arrays, W, H, camera, 4, pipeline, tail=tail)
+    pt.enable_counters(True)
+    pt.clear()
+    pt.seed(8)
+    pt.render(3)
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(arrays, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4, 0, 3, 8,
+             want, counters=oc)
+    got = pt.readRadiance()
+    assert np.array_equal(got, want)
+    assert pt.counters() == oc.as_dict()
+    assert len(np.unique(got[..., :3].reshape(-1, 3), axis=0)) > W * H // 2  # really textured: (nearly) every pixel differs
+    pt.close()
+
+
+@pytest.mark.parametrize("aperture,sun", [(0.02, None), (0.1, None), (0.1, (0.5, 2000.0))])
+def test_baseline_c1_config_bitwise(aperture, sun):
+    """BASELINE configs[0] - the reference's own CPU-runnable case: 256x256, depth 4, 16 spp on the 69 316-triangle
+    scene - then with configs[4]'s aperture 0.1, then configs[4] as SURVEY 8d defines it (bench.py --config c5:
+    aperture 0.1 AND a smaller, brighter sun -> 94 importance bins instead of 86): the whole frame equals the oracle
+    bit for bit."""
+    from fspt_amd import scene as S
+    arrays = S.bunny_scene(n=76) if sun is None else S.bunny_scene(n=76, sun_deg=sun[0], sun_gain=sun[1])
+    assert arrays.bins.size // 4 == (86 if sun is None else 94)
     cam = dict(S.BUNNY_CAMERA, aperture=aperture)
     cam["lens"] = S.lens_features(cam["focal_depth"], cam["aperture"])
     W = H = 256

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Derive the committed profile files from a tools/prof_r02.sh session.
+    python tools/collect_r02.py <tag> <workload-key> [<tag> <workload-key> ...]
+ -> profiles/r02/<tag>_kernel_stats.csv, <tag>_bench.json.log, <tag>_pmc_summary.txt and profiles/hbm_traffic.json
+    (bytes per sample per kernel, stamped with the hash of the kernel sources the numbers were measured on)."""
+import collections, csv, glob, json, os, re, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+G, P = "gpurun_out", os.path.join("profiles", "r02")
+os.makedirs(P, exist_ok=True)
+pairs = list(zip(sys.argv[1::2], sys.argv[2::2]))
+out = {"source_sha": bench.source_sha(),
+       "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate runs) over `bench.py --warmup 0 --reps 1 --no-cpu-baseline`"
+              " (one 128-tick batch + the counting ticks, which run other kernel variants); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024"
+              " (MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B)", "workloads": {}}
+
+
+def kname(n):
+    m = re.search(r"(k_wf_\w+|k_trace)(<[^>]*>)?", n)
+    return m.group(0) if m else None
+
+
+for tag, wl in pairs:
+    ks = glob.glob(f"{G}/{tag}_kt/**/*kernel_stats.csv", recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(P, f"{tag}_kernel_stats.csv"))
+    log = f"{G}/{tag}_kt.log"
+    samples = None
+    if os.path.exists(log):
+        for l in open(log):
+            if l.startswith("{"):
+                open(os.path.join(P, f"{tag}_bench.json.log"), "w").write(l)
+                j = json.loads(l)
+                w, h = re.search(r"(\d+)x(\d+)", j["metric"]).groups()
+                samples = int(w) * int(h) * j["steps"]  # samples of the one timed batch
+    res = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        agg = collections.defaultdict(list)
+        for f in glob.glob(f"{G}/{tag}_{c}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = kname(r["Kernel_Name"])
+                if k and r["Counter_Name"] == c:
+                    agg[k].append(float(r["Counter_Value"]))
+        res[c] = agg
+    kern = {}
+    for k, f in res["FETCH_SIZE"].items():
+        w = res["WRITE_SIZE"].get(k, [])
+        if not w or not samples or "<true" in k:
+            continue  # counting variants are not the timed kernels
+        total = (2 * sum(f) + sum(w)) * 1024
+        kern[k] = {"launches": len(f), "FETCH_SIZE_KB_sum": sum(f), "WRITE_SIZE_KB_sum": sum(w),
+                   "hbm_bytes_per_launch": total / len(f), "hbm_bytes_per_sample": total / samples}
+    out["workloads"][wl] = {"samples_per_batch": samples, "kernels": kern}
+    # SQ / TA / TD summaries
+    agg = collections.OrderedDict()
+    for f in sorted(glob.glob(f"{G}/{tag}_sq*/**/*counter_collection.csv", recursive=True)):
+        for r in csv.DictReader(open(f)):
+            k = kname(r["Kernel_Name"])
+            if k and "<true" not in k:
+                agg.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    if agg:
+        with open(os.path.join(P, f"{tag}_pmc_summary.txt"), "w") as o:
+            for (k, c), v in agg.items():
+                o.write(f"{k:32s} {c:40s} launches={len(v):4d} sum={sum(v):.6g} mean={sum(v) / len(v):.6g}\n")
+    for k, v in kern.items():
+        print(wl, k, "launches", v["launches"], "GB/launch", round(v["hbm_bytes_per_launch"] / 1e9, 3), "B/sample", round(v["hbm_bytes_per_sample"], 1))
+json.dump(out, open(os.path.join("profiles", "hbm_traffic.json"), "w"), indent=1)

@@ -9,10 +9,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("W", type=int); ap.add_argument("H", type=int)
 ap.add_argument("--tail", type=int, default=-1)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--mesh-n", type=int, default=76)
 ap.add_argument("--two-call", action="store_true", help="fspt_camera + fspt_trace per tick instead of fspt_render")
 ap.add_argument("K", type=int, nargs="+")
 a = ap.parse_args()
-arrays = S.bunny_scene(n=76)
+arrays = S.bunny_scene(n=a.mesh_n)
 for K in a.K:
     pt = fspt_amd.PathTracer(arrays, a.W, a.H, num_bounces=8)
     pt.set_camera(**S.BUNNY_CAMERA)
@@ -33,5 +34,5 @@ for K in a.K:
         best = dt if best is None or _ == 1 else min(best, dt)
     st = pt.last_stage_ms()
     print(a.W, a.H, "K", K, "tail", a.tail, "two_call" if a.two_call else "fused", "wall ms", round(best * 1e3, 3), "Ms/s", round(a.W * a.H * K / best / 1e6, 1),
-          {k: (round(v[0], 3), v[1]) for k, v in st.items()}, flush=True)
+          {k: (round(v[0], 3), v[1]) for k, v in st.items()}, "live", [round(x, 4) for x in pt.live_paths(10)[1:]], flush=True)
     pt.close()
