@@ -43,7 +43,7 @@ struct fspt_scene {
   int device = 0;
   int num_cus = 256;
   fspt::DScene d{};
-  void *nodes = nullptr, *tris = nullptr, *shade = nullptr, *atlas = nullptr, *env = nullptr, *bins = nullptr;
+  void *nodes = nullptr, *tris = nullptr, *shade = nullptr, *atlas = nullptr, *layer_tab = nullptr, *env = nullptr, *bins = nullptr;
   uint32_t depth = 0, n_nodes = 0, n_tris = 0, n_interior = 0;
   bool has_dielectric = false; // some triangle can refract (tracer.fs:481-488: unbounded path length)
 };
@@ -333,21 +333,28 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   if (e == hipSuccess) e = upload(&s->nodes, nodes.data(), nodes.size() * 4);
   if (e == hipSuccess) e = upload(&s->tris, tris.data(), tris.size() * 4);
   if (e == hipSuccess) e = upload(&s->shade, shade.data(), shade.size() * 4);
-  // textures: 8 x 4-texel tiles (one 128-byte line per tile); the 1 x 1 flat-colour atlas stays a plain table
-  uint32_t layer_stride = desc->atlas_res * desc->atlas_res;
+  // Atlas: a layer table + the non-constant layers in 8 x 4-texel tiles (one 128-byte line per tile).  A layer whose
+  // texels are all equal - every flat colour: TexturePacker fills whole layers with them (texture_packer.js:36-42),
+  // and a colours-only atlas is 1 x 1 - is not stored at all: its texel sits in the table.
+  uint32_t layer_stride = 0, n_stored = 0;
   if (e == hipSuccess) {
-    if (desc->atlas_res > 1) {
-      std::vector<uint32_t> tiled;
-      layer_stride = (uint32_t)tile_image(nullptr, desc->atlas_res, desc->atlas_res, tiled);
-      std::vector<uint32_t> all((size_t)layer_stride * desc->atlas_layers);
-      for (uint32_t l = 0; l < desc->atlas_layers; ++l) {
-        tile_image(desc->atlas + (size_t)l * desc->atlas_res * desc->atlas_res * 4, desc->atlas_res, desc->atlas_res, tiled);
-        std::memcpy(&all[(size_t)l * layer_stride], tiled.data(), (size_t)layer_stride * 4);
-      }
-      e = upload(&s->atlas, all.data(), all.size() * 4);
-    } else {
-      e = upload(&s->atlas, desc->atlas, (size_t)desc->atlas_layers * 4);
+    const size_t per_layer = (size_t)desc->atlas_res * desc->atlas_res;
+    std::vector<uint32_t> tab((size_t)desc->atlas_layers * 2), all, tiled;
+    layer_stride = (uint32_t)tile_image(nullptr, desc->atlas_res, desc->atlas_res, tiled);
+    for (uint32_t l = 0; l < desc->atlas_layers; ++l) {
+      const uint8_t *src = desc->atlas + (size_t)l * per_layer * 4;
+      uint32_t first;
+      std::memcpy(&first, src, 4);
+      bool constant = true;
+      for (size_t k = 1; k < per_layer && constant; ++k) constant = std::memcmp(src + k * 4, &first, 4) == 0;
+      tab[2 * l + 1] = first;
+      if (constant) { tab[2 * l] = fspt::LAYER_CONST; continue; }
+      tab[2 * l] = n_stored++;
+      tile_image(src, desc->atlas_res, desc->atlas_res, tiled);
+      all.insert(all.end(), tiled.begin(), tiled.end());
     }
+    e = upload(&s->layer_tab, tab.data(), tab.size() * 4);
+    if (e == hipSuccess) e = upload(&s->atlas, all.data(), all.size() * 4);
   }
   if (e == hipSuccess && desc->env) {
     std::vector<uint32_t> tiled;
@@ -364,6 +371,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   s->d.tris = (const float *)s->tris;
   s->d.hitrec = (const float4 *)s->shade;
   s->d.atlas = (const uint32_t *)s->atlas;
+  s->d.layer_tab = (const uint2 *)s->layer_tab;
   s->d.env = (const uint32_t *)s->env;
   s->d.bins = (const uint4 *)s->bins;
   s->d.atlas_res = desc->atlas_res;
@@ -388,7 +396,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
 int fspt_scene_destroy(fspt_scene *s) {
   if (!s) return FSPT_OK;
   hipSetDevice(s->device);
-  hipFree(s->nodes); hipFree(s->tris); hipFree(s->shade); hipFree(s->atlas); hipFree(s->env); hipFree(s->bins);
+  hipFree(s->nodes); hipFree(s->tris); hipFree(s->shade); hipFree(s->atlas); hipFree(s->layer_tab); hipFree(s->env); hipFree(s->bins);
   delete s;
   return FSPT_OK;
 }

@@ -26,6 +26,8 @@ constexpr int MAX_PATH_ITERS = 64;       // cap on tracer.fs:488's unbounded i--
 constexpr int TEX_TILE_W_LOG2 = FSPT_TEX_TILE_W_LOG2, TEX_TILE_H_LOG2 = FSPT_TEX_TILE_H_LOG2; // 0, 0 = plain row-major (A/B)
 constexpr int TEX_TILE_W = 1 << TEX_TILE_W_LOG2, TEX_TILE_H = 1 << TEX_TILE_H_LOG2;
 
+constexpr uint32_t LAYER_CONST = 0xFFFFFFFFu;
+
 constexpr int NODE_F4 = 4;   // 64-byte two-child node = 4 x float4
 constexpr int TRI_FLOATS = 9;  // 36-byte packed pre-edged triangle (traversal)
 constexpr int HITREC_F4 = 12; // 192-byte hit record (shading) = 12 x float4 = exactly 3 cache lines
@@ -45,7 +47,8 @@ struct DScene {
   const float4 *nodes;
   const float *tris;    // packed 9-float triangles (+ LEAF_SIZE padding records)
   const float4 *hitrec; // 12 x float4 per triangle
-  const uint32_t *atlas; // RGBA8 texels, layer-major; res > 1: every layer tiled (TEX_TILE_*), atlas_layer_stride texels apart
+  const uint32_t *atlas; // RGBA8 texels of the STORED (non-constant) layers, each tiled (TEX_TILE_*), atlas_layer_stride texels apart
+  const uint2 *layer_tab; // per atlas layer: x = index of the stored layer, or LAYER_CONST: every texel equals y
   const uint32_t *env;   // RGBE texels, tiled (NULL = black default environment)
   const uint4 *bins;
   uint32_t atlas_res, atlas_layers;

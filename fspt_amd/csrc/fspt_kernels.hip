@@ -251,12 +251,22 @@ FM_DEV float tap_channel(const Tap4 &tp, int ch) {
   float t01 = unorm8((tp.t01 >> (8 * ch)) & 255u), t11 = unorm8((tp.t11 >> (8 * ch)) & 255u);
   return lerp_(lerp_(t00, t10, tp.a), lerp_(t01, t11, tp.a), tp.b);
 }
-// texture(texArray, vec3(uv, layer)) (tracer.fs:453-456): the layer's texels for a footprint computed once per uv
+// texture(texArray, vec3(uv, layer)) (tracer.fs:453-456): the layer's texels for a footprint computed once per uv.
+// A layer whose texels are all equal (TexturePacker fills a whole res x res layer for every flat colour once one image
+// is in the atlas, texture_packer.js:36-42) is not stored: its one texel comes from the layer table, and
+// lerp(x, x, a) = fma(a, 0, x) = x exactly, so the four equal taps give the same bits as the fetch would.
 FM_DEV Tap4 atlas_taps(const DScene &S, const TapGeom &g, float layer) {
   int l = (int)floor_(layer + 0.5f);
   if (l < 0) l = 0;
   if (l > (int)S.atlas_layers - 1) l = (int)S.atlas_layers - 1;
-  return fetch_taps(S.atlas + (size_t)l * S.atlas_layer_stride, g);
+  const uint2 info = S.layer_tab[l];
+  if (info.x == LAYER_CONST) {
+    Tap4 r;
+    r.t00 = r.t10 = r.t01 = r.t11 = info.y;
+    r.a = g.a; r.b = g.b;
+    return r;
+  }
+  return fetch_taps(S.atlas + (size_t)info.x * S.atlas_layer_stride, g);
 }
 // envSample + envColor (tracer.fs:410-419)
 template <bool COUNT>
@@ -475,14 +485,14 @@ FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randB
       int l = (int)floor_(layer + 0.5f);
       return l < 0 ? 0u : ((uint32_t)l > nl ? nl : (uint32_t)l);
     };
-    uint32_t q = S.atlas[layer_of(layDiffuse)];
+    uint32_t q = S.layer_tab[layer_of(layDiffuse)].y;
     texDiffuse = v3(unorm8(q & 255u), unorm8((q >> 8) & 255u), unorm8((q >> 16) & 255u));
-    q = S.atlas[layer_of(laySpec)];
+    q = S.layer_tab[layer_of(laySpec)].y;
     texEmissive = v3(unorm8(q & 255u), unorm8((q >> 8) & 255u), unorm8((q >> 16) & 255u));
-    q = S.atlas[layer_of(layRough)];
+    q = S.layer_tab[layer_of(layRough)].y;
     metallic = unorm8(q & 255u);
     rough = unorm8((q >> 8) & 255u);
-    q = S.atlas[layer_of(layNormal)];
+    q = S.layer_tab[layer_of(layNormal)].y;
     texNormal = v3((unorm8(q & 255u) - 0.5f) * 2.0f, (unorm8((q >> 8) & 255u) - 0.5f) * 2.0f,
                    (unorm8((q >> 16) & 255u) - 0.0f) * 1.0f);
   } else {
@@ -1074,7 +1084,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 }
 
 // LDS-staged tables of the shading kernels: the small read-only tables every shading event gathers from - the
-// flat-colour atlas (one texel per layer), the environment's importance bins and the batch's randBase values - are
+// atlas layer table (the texel of every flat-colour layer), the environment's importance bins and the batch's randBase values - are
 // staged in LDS once per block, so those gathers go through the LDS pipeline instead of the vector-memory pipeline.
 #ifndef WF_LDS_ATLAS
 #define WF_LDS_ATLAS 1024
@@ -1112,17 +1122,17 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
   constexpr int U = WF_PRIMARY_U;
   __shared__ uint32_t s_cnt[U][NW];
   __shared__ uint32_t s_base;
-  __shared__ uint32_t s_atlas[LDSTAB ? WF_LDS_ATLAS : 1];
+  __shared__ uint2 s_atlas[LDSTAB ? WF_LDS_ATLAS : 1];
   __shared__ uint4 s_bins[LDSTAB ? WF_LDS_BINS : 1];
   __shared__ float s_rb[LDSTAB ? WF_MAX_BATCH : 1];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   DScene S = p.scene;
   if (LDSTAB) {
-    for (uint32_t i = threadIdx.x; i < S.atlas_layers; i += WF_LOGIC_THREADS) s_atlas[i] = p.scene.atlas[i];
+    for (uint32_t i = threadIdx.x; i < S.atlas_layers; i += WF_LOGIC_THREADS) s_atlas[i] = p.scene.layer_tab[i];
     for (uint32_t i = threadIdx.x; i < S.n_bins; i += WF_LOGIC_THREADS) s_bins[i] = p.scene.bins[i];
     if (threadIdx.x < WF_MAX_BATCH) s_rb[threadIdx.x] = p.rb_trace[threadIdx.x];
-    S.atlas = s_atlas;
+    S.layer_tab = s_atlas;
     S.bins = s_bins;
     __syncthreads();
   }
@@ -1210,17 +1220,17 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
   constexpr int U = WF_LOGIC_U;
   __shared__ uint16_t s_list[U * WF_LOGIC_THREADS];
   __shared__ uint32_t s_n, s_total, s_gbase;
-  __shared__ uint32_t s_atlas[LDSTAB ? WF_LDS_ATLAS : 1];
+  __shared__ uint2 s_atlas[LDSTAB ? WF_LDS_ATLAS : 1];
   __shared__ uint4 s_bins[LDSTAB ? WF_LDS_BINS : 1];
   __shared__ float s_rb[LDSTAB ? WF_MAX_BATCH : 1];
   const int lane = threadIdx.x & (WAVE - 1);
   DScene S = p.scene;
   if (threadIdx.x == 0) s_n = 0;
   if (LDSTAB) {
-    for (uint32_t i = threadIdx.x; i < S.atlas_layers; i += WF_LOGIC_THREADS) s_atlas[i] = p.scene.atlas[i];
+    for (uint32_t i = threadIdx.x; i < S.atlas_layers; i += WF_LOGIC_THREADS) s_atlas[i] = p.scene.layer_tab[i];
     for (uint32_t i = threadIdx.x; i < S.n_bins; i += WF_LOGIC_THREADS) s_bins[i] = p.scene.bins[i];
     if (threadIdx.x < WF_MAX_BATCH) s_rb[threadIdx.x] = p.rb_trace[threadIdx.x];
-    S.atlas = s_atlas;
+    S.layer_tab = s_atlas;
     S.bins = s_bins;
   }
   __syncthreads();
@@ -1638,7 +1648,7 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
 #undef FSPT_LAUNCH_TAIL
   } else if (kernel == WF_K_LOGIC || kernel == WF_K_PRIMARY) {
     uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * 4u);
-    const bool tab = WF_LOGIC_LDSTAB && p.scene.atlas_res == 1u && p.scene.atlas_layers <= WF_LDS_ATLAS && p.scene.n_bins <= WF_LDS_BINS;
+    const bool tab = WF_LOGIC_LDSTAB && p.scene.atlas_layers <= WF_LDS_ATLAS && p.scene.n_bins <= WF_LDS_BINS;
     if (kernel == WF_K_PRIMARY) {
       const size_t dyn = (size_t)(WF_LOGIC_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int);
 #define FSPT_LAUNCH_PRIMARY(C, T)                                                                          \
