@@ -63,6 +63,32 @@ for tag, wl in pairs:
         with open(os.path.join(P, f"{tag}_pmc_summary.txt"), "w") as o:
             for (k, c), v in agg.items():
                 o.write(f"{k:32s} {c:40s} launches={len(v):4d} sum={sum(v):.6g} mean={sum(v) / len(v):.6g}\n")
+    # derived per-kernel figures: vector-memory pipeline busy fractions (instances calibrated on the saturated
+    # microbenchmark, profiles/r01/l1_pipe.json), VALU lane utilisation, share of wave-cycles spent waiting, L2 hit rate
+    INST = 31.334512006803482
+    c = collections.defaultdict(dict)
+    for (k, name), v in agg.items():
+        c[k][name] = sum(v)
+    derived = {}
+    for k, v in c.items():
+        d = {}
+        if "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"]:
+            d["TA_busy"] = round(v.get("TA_TA_BUSY_sum", 0) / v["GRBM_GUI_ACTIVE"] / INST, 3)
+            d["TD_busy"] = round(v.get("TD_TD_BUSY_sum", 0) / v["GRBM_GUI_ACTIVE"] / INST, 3)
+        if v.get("SQ_ACTIVE_INST_VALU"):
+            d["valu_lane_utilisation"] = round(v["SQ_THREAD_CYCLES_VALU"] / (64 * v["SQ_ACTIVE_INST_VALU"]), 3)
+        if v.get("SQ_WAVE_CYCLES"):
+            d["wait_any_share"] = round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 3)
+            d["valu_active_share"] = round(v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"], 3)
+        if v.get("TCC_REQ_sum"):
+            d["l2_hit_rate"] = round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 3)
+        derived[k] = d
+    if derived:
+        json.dump({"note": "from <tag>_pmc_summary.txt: bench.py --steps 32 --batch 32 (one 32-tick batch); busy = *_BUSY_sum / "
+                           "GRBM_GUI_ACTIVE / 31.33 instances (profiles/r01/l1_pipe.json)", "kernels": derived},
+                  open(os.path.join(P, f"{tag}_derived.json"), "w"), indent=1)
+        for k, d in derived.items():
+            print(wl, k, d)
     for k, v in kern.items():
         print(wl, k, "launches", v["launches"], "GB/launch", round(v["hbm_bytes_per_launch"] / 1e9, 3), "B/sample", round(v["hbm_bytes_per_sample"], 1))
 json.dump(out, open(os.path.join("profiles", "hbm_traffic.json"), "w"), indent=1)
