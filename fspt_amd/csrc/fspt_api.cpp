@@ -68,13 +68,14 @@ struct fspt_target {
   // wavefront pipeline
   uint32_t vw = 0, vh = 0;    // viewport (gl.viewport of the two draws); default = the whole target
   int pipeline = 1;           // 0 = megakernel, 1 = wavefront (2 = wavefront with two overlapped lanes sets n_lanes)
-  uint32_t batch_ticks = 128; // ticks traced together by the wavefront pipeline (37 GB of path state at 1080p;
+  uint32_t batch_ticks = 128; // ticks traced together by the wavefront pipeline (58 GB of path state at 1080p;
                               // measured 64 / 128 / 256 -> 3 619 / 3 794 / 3 750 Msamples/s, profiles/r01)
   // Two lanes = two independent batches in flight on two HIP streams: while one batch sits in a latency-bound
   // kernel or in the tail of a late round, the other batch's kernels fill the idle SIMDs.
   struct WfLane {
     void *mem[WF_ARRAYS] = {};
     fspt::WfCounts *counts = nullptr;
+    uint32_t *heads = nullptr;             // trace pool heads (fspt_device.hpp)
     fspt::WfCounts *counts_host = nullptr; // pinned copy of the last batch's per-round counts (tail heuristic)
     hipEvent_t counts_ready = nullptr;
     bool counts_pending = false;
@@ -413,6 +414,7 @@ int fspt_scene_depth(const fspt_scene *s, uint32_t *depth) {
 static const uint32_t WORK_RING = 4096;
 static const uint32_t WF_ROUNDS_MAX = fspt::MAX_PATH_ITERS + 4;
 static const uint32_t EV_PAIRS = 4096;
+static const size_t WF_HEADS_BYTES = (size_t)(WF_ROUNDS_MAX + 2) * fspt::WF_HEADS * fspt::WF_HEAD_STRIDE * sizeof(uint32_t);
 static const uint64_t WF_SLOT_BUDGET = 448ull << 20; // path slots, 220 B each (up to 103 GB of the 288 GB HBM: a 4K frame x 56 ticks)
 
 int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **out) {
@@ -459,6 +461,7 @@ int fspt_target_destroy(fspt_target *t) {
   for (auto &ln : t->lanes) {
     for (void *m : ln.mem) hipFree(m);
     hipFree(ln.counts);
+    hipFree(ln.heads);
     if (ln.counts_host) hipHostFree(ln.counts_host);
     if (ln.counts_ready) hipEventDestroy(ln.counts_ready);
     if (ln.resolved) hipEventDestroy(ln.resolved);
@@ -586,6 +589,7 @@ static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots, ui
     HIP_TRY(hipMemsetAsync(ln.mem[i], 0, (size_t)slots * WF_ARRAY_BYTES[i], ln.stream)); // touch every page once, now
   }
   if (!ln.counts) HIP_TRY(hipMalloc((void **)&ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2)));
+  if (!ln.heads) HIP_TRY(hipMalloc((void **)&ln.heads, WF_HEADS_BYTES));
   if (!ln.counts_host) HIP_TRY(hipHostMalloc((void **)&ln.counts_host, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), hipHostMallocDefault));
   if (!ln.counts_ready) HIP_TRY(hipEventCreateWithFlags(&ln.counts_ready, hipEventDisableTiming));
   HIP_TRY(hipStreamSynchronize(ln.stream));
@@ -726,6 +730,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     p.hit = (float2 *)ln.mem[12]; p.shadow_hit = (int *)ln.mem[13];
     p.fin = (float4 *)ln.mem[14];
     p.counts = ln.counts;
+    p.heads = ln.heads;
     uint32_t nbt = n_ticks - done < batch ? n_ticks - done : batch;
     p.n_batch = nbt;
     p.first_tick = first_tick + done;
@@ -733,6 +738,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     // the previous batch's live-path counts, if their copy has landed: where the tail kernel takes over
     wf_collect_counts(t, ln);
     HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
+    HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, st));
     p.gen_rays = gen ? 1u : 0u;
     // Round 1 = the primary launch (ray generation + primary traversal + its shading); round r >= 2: logic consumes the
     // results of trace r-1 and shades bounce r-1.  After round nb+1 every path has finished unless a refraction kept `i`

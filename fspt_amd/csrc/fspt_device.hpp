@@ -126,12 +126,18 @@ constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17, WF_FLA
 #endif
 constexpr int WF_HEADS = FSPT_WF_HEADS; // work-pool heads of the trace kernel (one per item segment; waves steal from the others)
 
+#ifndef FSPT_WF_HEAD_STRIDE
+#define FSPT_WF_HEAD_STRIDE 64 // uint32 words between two pool heads (256 bytes)
+#endif
+constexpr int WF_HEAD_STRIDE = FSPT_WF_HEAD_STRIDE;
 struct alignas(128) WfCounts { // one per round, zeroed before the batch
   uint32_t n_ext;          // live paths written by this round's primary / logic launch
-  uint32_t pad[15];
-  uint32_t head[WF_HEADS]; // trace kernel work-pool heads: one same-address atomic stream sustains ~65 M/s
-                           // (profiles/r01), which capped small launches at 64 rays per 15 ns
+  uint32_t pad[31];
 };
+// Trace / tail kernel work-pool heads: WF_HEADS per round, each in a memory line (and channel) of its own
+// (WfP::heads[(round * WF_HEADS + stripe) * WF_HEAD_STRIDE]): device-scope atomics execute at the memory side and
+// same-LINE atomics serialise like same-address ones (~15 ns each) - 16 heads packed in one 64-byte line behaved
+// exactly like a single head (profiles/r02/ab_trace_pool_heads.log).
 
 struct WfSet { float4 *A, *B, *C, *E, *D, *P; };
 
@@ -144,6 +150,7 @@ struct WfP {
   float2 *hit;
   int *shadow_hit;
   WfCounts *counts;
+  uint32_t *heads; // pool heads, see above
   uint32_t round;
   uint32_t W, H;
   uint32_t vw, vh; // viewport, as in TraceP

@@ -5,12 +5,13 @@
 // arithmetic (advance_path / shade_hit / trace loops below) and give
 // bit-identical results:
 //
-//  * wavefront pipeline (default; k_wf_logic<first> / k_wf_trace / k_wf_logic / k_wf_resolve):
-//    path state in HBM, slot queues, one kernel per kind of work; the first launch of a batch does ray
-//    generation, the primary ray's traversal and its shading in one kernel.  k_wf_trace is a
-//    persistent while-while traversal with per-lane dynamic refill from the ray queue,
-//    its deferred-child stack in LDS; k_wf_logic does one S step per live path and
-//    compacts the survivors (one 64-bit atomic per 1024 paths).
+//  * wavefront pipeline (default; k_wf_primary / k_wf_trace / k_wf_logic [/ k_wf_tail] / k_wf_resolve):
+//    path state in HBM, compacted every round into consecutive indices of one of two state sets, one kernel per
+//    kind of work; the first launch of a batch does ray generation, the primary ray's traversal and its shading
+//    in one kernel.  k_wf_trace is a persistent while-while traversal with per-lane dynamic refill from the
+//    round's path list (one item per path: its shadow ray, then its extension ray), its deferred-child stack in
+//    LDS; k_wf_logic classifies the live paths, reserves the survivors' output range with one atomic per 4 096
+//    paths, finishes the others in place and shades the survivors with dense waves.
 //  * megakernel (k_trace): one persistent kernel per tick; a lane whose path has
 //    terminated pulls the next pixel in place (path regeneration); the wave alternates
 //      S  consume traversal results (tracer.fs:501-512), finish / regenerate
@@ -770,7 +771,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 // (layout and slot numbering: fspt_device.hpp)
 // ===========================================================================
 #ifndef WF_TRACE_CHUNK
-#define WF_TRACE_CHUNK 512u // cap of the pool chunk (paths).  Measured (profiles/r02, per-path items): 128 / 256 / 512 / 1024 -> 3 970 / 4 807 / 4 893 / 4 882 Msamples/s at 128-tick batches, 3 240 / 3 700 / 3 660 / 3 510 at 20 ticks (a draw stalls the wave for a memory-side atomic round trip)
+#define WF_TRACE_CHUNK 128u // cap of the pool chunk (paths).  With the pool heads in memory lines of their own a draw is cheap
+// (profiles/r02/ab_trace_pool_heads.log): caps 64 / 128 / 256 -> 3 810 / 3 828 / 3 750 Msamples/s at 20-tick batches,
+// 4 750 / 4 775 / 4 795 at 128.  (With all heads in ONE 64-byte line - same-line atomics serialise at the memory side -
+// 128 cost 20 % and 512 was the optimum.)
 #endif
 // measured on C2 (profiles/r01): 1 -> 0.462, 8 -> 0.348, 16 -> 0.338, 24 -> 0.336, 32 -> 0.343 ms per tick
 #ifndef WF_INTERIOR_MIN
@@ -909,6 +913,9 @@ FM_DEV uint32_t load_path(const WfSet &in, uint32_t k, Path &ps, const int *shad
 #ifndef WF_TRACE_WAVES
 #define WF_TRACE_WAVES 6
 #endif
+#ifndef WF_TRACE_FINE
+#define WF_TRACE_FINE 8u // the last 1/8 of a launch's paths are dealt out in 64-path chunks
+#endif
 template <bool COUNT, bool ANYHIT>
 __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(const WfP p) {
   extern __shared__ int lds_stack[];
@@ -921,6 +928,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   const uint32_t leaf_size = S.leaf_size;
   const WfSet st = p.set[p.round & 1];
   WfCounts *cn = p.counts + p.round;
+  const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
   const uint32_t total = cn->n_ext;
 
   // top of the tree in LDS (behind the waves' stacks): every ray walks these nodes, and a fetch from LDS does not
@@ -934,13 +942,22 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 
   // pool chunk: large while paths are plentiful (few atomics), one wave-load when they are scarce
   // (late rounds), so that every resident wave gets work
-  const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
   uint32_t chunk = (total / (n_waves * 4u)) & ~63u;
   chunk = chunk < 64u ? 64u : (chunk > WF_TRACE_CHUNK ? WF_TRACE_CHUNK : chunk);
-  const uint32_t n_chunks = (total + chunk - 1u) / chunk;
+  // Two chunk sizes: the first (1 - 1/WF_TRACE_FINE) of the paths in chunks of `chunk`, the rest in chunks of 64 - the
+  // chunks are handed out in order, so the launch ends on fine-grained work: the imbalance at the end of a launch is one
+  // chunk's worth of time (512 paths on one wave = 8 per lane, ~300 us) unless the last chunks are small.
+  const uint32_t big_paths = chunk > 64u ? ((total - total / WF_TRACE_FINE) / chunk) * chunk : 0u;
+  const uint32_t n_big = chunk > 64u ? big_paths / chunk : 0u;
+  const uint32_t n_chunks = n_big + (total - big_paths + 63u) / 64u;
+  auto chunk_range = [&](uint32_t c, uint32_t &lo, uint32_t &hi) {
+    if (c < n_big) { lo = c * chunk; hi = lo + chunk; }
+    else { lo = big_paths + (c - n_big) * 64u; hi = min(lo + 64u, total); }
+  };
   const uint32_t wave_id = blockIdx.x * WAVES_PER_BLOCK + wave;
   const uint32_t stripe = wave_id % WF_HEADS;
-  uint32_t pool_next = min(wave_id * chunk, total), pool_end = min(wave_id * chunk + chunk, total); // chunk `wave_id`
+  uint32_t pool_next = 0, pool_end = 0;
+  if (wave_id < n_chunks) chunk_range(wave_id, pool_next, pool_end); // chunk `wave_id` is the wave's own
   bool exhausted = n_chunks <= n_waves; // nothing beyond the waves' own chunks
 
   uint32_t c_rays = 0, c_steps = 0, c_leaves = 0;
@@ -960,12 +977,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
       if (avail == 0u) {
         if (exhausted) break;
         uint32_t j = 0;
-        if (lane == 0) j = atomicAdd(&cn->head[stripe], 1u);
+        if (lane == 0) j = atomicAdd(&p.heads[((size_t)p.round * WF_HEADS + stripe) * WF_HEAD_STRIDE], 1u);
         j = __builtin_amdgcn_readfirstlane(j);
         const unsigned long long c = (unsigned long long)n_waves + (unsigned long long)j * WF_HEADS + stripe;
         if (c >= n_chunks) { exhausted = true; break; }
-        pool_next = (uint32_t)c * chunk;
-        pool_end = min(pool_next + chunk, total);
+        chunk_range((uint32_t)c, pool_next, pool_end);
         continue;
       }
       uint32_t rank = lane_rank(need);
@@ -1342,7 +1358,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_tail(const WfP p) {
       if (avail == 0u) {
         if (exhausted) break;
         uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&cn->head[0], (uint32_t)WAVE);
+        if (lane == 0) b = atomicAdd(&p.heads[(size_t)p.round * WF_HEADS * WF_HEAD_STRIDE], (uint32_t)WAVE);
         b = __builtin_amdgcn_readfirstlane(b) + n_waves * WAVE;
         if (b >= total) { exhausted = true; break; }
         pool_next = b;

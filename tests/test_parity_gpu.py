@@ -744,6 +744,29 @@ def test_multi_device_target_bitwise(medium_scene, camera, n_dev):
     mp.close()
 
 
+def test_multi_device_eight_way_full_hd(medium_scene, camera):
+    """BASELINE configs[3]'s sharding (32x32 tiles dealt round-robin to 8 devices) through fspt_multi_* at 1920x1080:
+    eight targets (the box's devices cycled), one read-out gather of 7/8 of the frame - equal to the single-target
+    render of the same ticks (which the other tests pin to the oracle)."""
+    from fspt_amd import MultiPathTracer
+    n_real = max(1, min(8, L.lib().fspt_device_count()))
+    W, H = 1920, 1080
+    pt = make_pt(medium_scene, W, H, camera, 4, "wavefront", 0, tail=-1)
+    pt.seed(5)
+    pt.render(3)
+    want = pt.readRadiance()
+    pt.close()
+    mp = MultiPathTracer(medium_scene, W, H, [i % n_real for i in range(8)], num_bounces=4)
+    mp.set_camera(camera["P"], camera["I"], camera["fov_scale"], camera["env_theta"], camera["focal_depth"], camera["aperture"])
+    mp.seed(5)
+    mp.render(3)
+    got = mp.readRadiance()
+    assert np.array_equal(got, want)
+    n_tiles = 60 * 34
+    assert mp.last_gather_bytes() == (n_tiles - len(range(0, n_tiles, 8))) * 32 * 32 * 16  # 7/8 of the tiles, whole tiles
+    mp.close()
+
+
 def test_bound_torch_accumulator_and_tile_gather_on_gpu(small_scene, camera):
     """bench.py's multi-GPU plumbing on one GPU: the library accumulates into a torch tensor
     (fspt_target_bind_accumulator), two tile shards rendered by two targets, exchanged with TileGather's
