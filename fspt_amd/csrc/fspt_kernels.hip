@@ -1323,13 +1323,68 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
   flush_counters<COUNT>(cnt, p.counters, 4, lane);
 }
 
+// intersectScene (tracer.fs:366-404) for ONE ray per lane (the loop of trace_rays without the second ray); `anyhit`:
+// stop at the first hit (NEE shadow rays, tracer.fs:502).  Inactive lanes fall straight through.
+template <bool COUNT>
+FM_DEV void trace_one(const DScene &S, int *stack, V3 o, V3 d, bool anyhit, bool active, float &tOut, int &hitOut, Counters &cnt) {
+  const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  float t = MAX_T;
+  int hit = -1;
+  int cur = active ? S.root_ref : REF_SENTINEL;
+  int sp = 0;
+  if (COUNT && active) cnt.rays++;
+  const float4 *__restrict__ nodes = S.nodes;
+  const float *__restrict__ tris = S.tris;
+  const uint32_t leaf_size = S.leaf_size;
+  while (cur != REF_SENTINEL) {
+    while (cur >= 0) {
+      if (COUNT) cnt.steps++;
+      const float4 *n = nodes + (size_t)cur * NODE_F4;
+      float4 n0 = n[0], n1 = n[1], n2 = n[2];
+      int4 n3 = *reinterpret_cast<const int4 *>(n + 3);
+      float tl = ray_box(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv);
+      float tr = ray_box(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv);
+      bool hl = tl < t, hr = tr < t;
+      bool swap = tl > tr; // tracer.fs:384: right first only when strictly nearer
+      int nearRef = swap ? n3.y : n3.x;
+      int farRef = swap ? n3.x : n3.y;
+      if (hl && hr) {
+        stack[sp * WAVE] = farRef;
+        sp++;
+        cur = nearRef;
+      } else if (hl) {
+        cur = n3.x;
+      } else if (hr) {
+        cur = n3.y;
+      } else if (sp > 0) {
+        sp--;
+        cur = stack[sp * WAVE];
+      } else {
+        cur = REF_SENTINEL;
+      }
+    }
+    if (cur == REF_SENTINEL) break;
+    if (COUNT) { cnt.steps++; cnt.leaves++; }
+    process_leaf(tris, leaf_size, ~cur, o, d, t, hit);
+    if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
+    else cur = REF_SENTINEL;
+    if (anyhit && hit != -1) cur = REF_SENTINEL;
+  }
+  tOut = t;
+  hitOut = hit;
+}
+
+FM_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src, WAVE), __shfl(v.y, src, WAVE), __shfl(v.z, src, WAVE)); }
+
 // ---- tail: the live paths of a late round run to completion in ONE kernel ------------------------
 // After a few rounds only a few thousand paths are alive, and every further round costs a trace launch as long as its
 // longest ray plus a logic launch plus two launch gaps (~220 us per round at 1080p, whatever the path count).  This
-// kernel takes the survivors of round p.round and alternates T (trace the lane's shadow + extension ray) and S
-// (advance_path) per lane until the path ends, refilling finished lanes from the list: the rounds are no longer
-// synchronised, so the cost is the longest PATH, not the sum over rounds of the longest rays.  It also ends paths that
-// refraction keeps alive beyond NUM_BOUNCES rounds (tracer.fs:488) without any host round trip.
+// kernel takes the survivors of round p.round and alternates T (trace) and S (advance_path) per path until it ends,
+// refilling finished lanes from the list: the rounds are no longer synchronised.  A path lives on a PAIR of lanes: the
+// even lane owns the state and traces the extension ray, the odd lane traces the path's NEE shadow ray at the same
+// time (handed over and back with lane shuffles) - what such a launch costs is the longest chain of dependent rays,
+// and the shadow rays are off that chain this way.  It also ends paths that refraction keeps alive beyond NUM_BOUNCES
+// rounds (tracer.fs:488) without any host round trip.
 template <bool COUNT, bool ANYHIT>
 __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_tail(const WfP p) {
   extern __shared__ int lds_stack[];
@@ -1341,47 +1396,64 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_tail(const WfP p) {
   WfCounts *cn = p.counts + p.round;
   const uint32_t total = cn->n_ext;
   Counters cnt = {0, 0, 0, 0, 0, 0};
+  const bool is_main = (lane & 1) == 0;
+  constexpr uint32_t PAIRS = WAVE / 2;
   Path ps;
   ps.pix = -1;
+  ps.hasShadow = false;
+  ps.ro = ps.rd = ps.envDir = v3(0.0f, 0.0f, 1.0f);
   uint32_t slot = 0;
-  // pool as in k_wf_trace: every wave's first 64 paths are its own, the rest is dealt out by one head
+  // pool as in k_wf_trace: chunks of 32 paths; every wave's first chunk is its own, the rest is dealt out by the
+  // wave's stripe head
   const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
   const uint32_t wave_id = blockIdx.x * WAVES_PER_BLOCK + wave;
-  uint32_t pool_next = min(wave_id * WAVE, total), pool_end = min(wave_id * WAVE + WAVE, total);
-  bool exhausted = total <= n_waves * WAVE;
+  const uint32_t stripe = wave_id % WF_HEADS;
+  const uint32_t n_chunks = (total + PAIRS - 1u) / PAIRS;
+  uint32_t pool_next = min(wave_id * PAIRS, total), pool_end = min(wave_id * PAIRS + PAIRS, total);
+  bool exhausted = n_chunks <= n_waves;
   while (true) {
-    // ---- refill idle lanes with paths of the list ----
+    // ---- refill idle pairs with paths of the list ----
     while (true) {
-      unsigned long long need = __ballot(ps.pix < 0);
+      unsigned long long need = __ballot(is_main && ps.pix < 0);
       if (need == 0ull) break;
       uint32_t avail = pool_end - pool_next;
       if (avail == 0u) {
         if (exhausted) break;
         uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&p.heads[(size_t)p.round * WF_HEADS * WF_HEAD_STRIDE], (uint32_t)WAVE);
-        b = __builtin_amdgcn_readfirstlane(b) + n_waves * WAVE;
-        if (b >= total) { exhausted = true; break; }
-        pool_next = b;
-        pool_end = min(b + (uint32_t)WAVE, total);
+        if (lane == 0) b = atomicAdd(&p.heads[((size_t)p.round * WF_HEADS + stripe) * WF_HEAD_STRIDE], 1u);
+        b = __builtin_amdgcn_readfirstlane(b);
+        const unsigned long long c = (unsigned long long)n_waves + (unsigned long long)b * WF_HEADS + stripe;
+        if (c >= n_chunks) { exhausted = true; break; }
+        pool_next = (uint32_t)c * PAIRS;
+        pool_end = min(pool_next + PAIRS, total);
         continue;
       }
       uint32_t rank = lane_rank(need);
       uint32_t want = (uint32_t)__popcll(need);
       uint32_t take = want < avail ? want : avail;
-      if (ps.pix < 0 && rank < take) {
+      if (is_main && ps.pix < 0 && rank < take) {
         int unused;
         slot = load_path(in, pool_next + rank, ps, nullptr, unused);
         ps.pix = 0;
       }
       pool_next += take;
     }
-    if (__ballot(ps.pix >= 0) == 0ull) break;
-    if (ps.pix >= 0) {
-      // T: the lane's pending rays;  S: consume them
-      int hitA, hitB;
-      float tB;
-      trace_rays<COUNT, ANYHIT>(S, stack, ps.ro, ps.hasShadow, ps.envDir, ps.rd, hitA, tB, hitB, cnt);
-      if (advance_path<COUNT>(S, ps, hitA, tB, hitB, p.rb_trace[slot % p.n_batch], p.env_theta, p.num_bounces, cnt)) {
+    if (__ballot(is_main && ps.pix >= 0) == 0ull) break;
+    // ---- T: even lanes trace their path's extension ray, odd lanes the same path's shadow ray ----
+    const int src = lane & ~1;
+    const bool m_live = ps.pix >= 0; // (false on odd lanes)
+    const bool pair_live = __shfl((int)m_live, src, WAVE) != 0;
+    const bool pair_shadow = __shfl((int)(m_live && ps.hasShadow), src, WAVE) != 0;
+    const V3 o = shfl3(ps.ro, src);
+    const V3 d_sh = shfl3(ps.envDir, src);
+    const V3 d = is_main ? ps.rd : d_sh;
+    float tR;
+    int hitR;
+    trace_one<COUNT>(S, stack, o, d, ANYHIT && !is_main, is_main ? pair_live : pair_shadow, tR, hitR, cnt);
+    const int hitA = __shfl(hitR, lane | 1, WAVE); // the shadow ray's result, back on the even lane (-1 when there was none)
+    // ---- S: consume them ----
+    if (m_live) {
+      if (advance_path<COUNT>(S, ps, hitA, tR, hitR, p.rb_trace[slot % p.n_batch], p.env_theta, p.num_bounces, cnt)) {
         st4(p.fin + slot, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
         ps.pix = -1;
       }
@@ -1651,7 +1723,7 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
     else FSPT_LAUNCH_TRACE(false, true);
 #undef FSPT_LAUNCH_TRACE
   } else if (kernel == WF_K_TAIL) {
-    uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 3u);
+    uint32_t grid = min((2u * total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 4u); // two lanes per path, 4 blocks/CU at 128 VGPRs
     size_t lds = stack_bytes(p.scene);
 #define FSPT_LAUNCH_TAIL(C, A)                                                                             \
     do {                                                                                                     \

@@ -15,9 +15,10 @@
  *     console.log()s / throws: main.js:91-94, 564-569);
  *   - the library COPIES every host array it is given (caller may free after
  *     the call returns);
- *   - all calls for one target come from one host thread (the reference is a
- *     single JS thread: main.js:838-857); work is enqueued on a HIP stream,
- *     only fspt_read_*, fspt_sync and fspt_counters block;
+ *   - all calls for one target come from one host thread at a time (the reference
+ *     is a single JS thread: main.js:838-857); work is enqueued on HIP streams -
+ *     the two-call ticks even later, see fspt_camera - and only fspt_read_*,
+ *     fspt_draw*, fspt_sync, fspt_get_counters and the fspt_last_* timers block;
  *   - there is NO CPU fallback: without a HIP device every device entry point
  *     fails with FSPT_E_NO_DEVICE.
  */
@@ -89,7 +90,7 @@ typedef struct fspt_scene_desc {
 } fspt_scene_desc;
 
 /* device = HIP device ordinal.  Builds the MI355X-native layouts (64-byte
- * two-child nodes, 48-byte pre-edged triangles, 160-byte shading records). */
+ * two-child nodes, 36-byte pre-edged triangles, 192-byte hit records, textures in 128-byte tiles). */
 int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out);
 int fspt_scene_destroy(fspt_scene *scene);
 /* Maximum depth of the uploaded tree (root = 0); sizes the LDS stacks. */

@@ -949,7 +949,7 @@ def _fuzz_scene(seed):
     return arrays, cam, int(rng.integers(1, 7)), (int(rng.integers(1, 90)), int(rng.integers(1, 60))), int(rng.integers(1, 2 ** 31))
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FSPT_FUZZ_SEEDS", "16"))))  # soak: FSPT_FUZZ_SEEDS=128
 def test_fuzz_random_scenes_bitwise(seed):
     """Differential fuzzing, HIP (both pipelines) vs oracle: random triangle soups incl. degenerate / duplicate /
     sliver / huge triangles (NaN normals, equal-t ties), refractive + emissive + metallic MTL materials, leaf sizes
