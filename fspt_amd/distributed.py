@@ -63,8 +63,10 @@ def owned_pixel_index(rank, world, width, height, tile=TILE, device=None):
 
 class TileGather:
     """Read-out exchange that moves only what each rank owns (the cheaper alternative to reducing
-    the whole frame): every rank packs its own pixels (1/world of the frame), one gather to `dst`, `dst`
-    scatters the pieces into its full-size buffer.  Index tensors are built once, outside any timed region."""
+    the whole frame): every rank packs its own pixels (1/world of the frame), ONE gather to `dst` into slices of one
+    receive buffer, and `dst` scatters all pieces into its full-size buffer with ONE index_copy_ (rows a rank pads its
+    send buffer with repeat its last pixel, so their duplicate writes carry identical values).  Index tensors are built
+    once, outside any timed region."""
 
     def __init__(self, rank, world, width, height, device, tile=TILE, dst=0):
         import torch
@@ -75,20 +77,40 @@ class TileGather:
         self.send = torch.zeros((self.n_max, 4), dtype=torch.float32, device=device)
         self.recv, self.all_idx = None, None
         if rank == dst:
-            self.recv = [torch.zeros((self.n_max, 4), dtype=torch.float32, device=device) for _ in range(world)]
-            self.all_idx = [owned_pixel_index(r, world, width, height, tile, device) for r in range(world)]
+            self.big = torch.zeros((world * self.n_max, 4), dtype=torch.float32, device=device)
+            self.recv = list(self.big.split(self.n_max))  # views: the gather lands in one buffer
+            pieces = []
+            for r in range(world):
+                i = owned_pixel_index(r, world, width, height, tile, device)
+                if i.numel() == 0:  # a rank without tiles (tiny frames): its rows are never written by index_copy_
+                    i = self.idx[:1] if self.idx.numel() else torch.zeros(1, dtype=torch.int64, device=device)
+                    pieces.append(i.expand(self.n_max).clone() if r == dst else None)
+                    continue
+                pad = i[-1:].expand(self.n_max - i.numel())
+                pieces.append(torch.cat([i, pad]))
+            self.rows = [r for r in range(world) if pieces[r] is not None and r != dst]
+            self.all_idx = torch.cat([pieces[r] for r in self.rows]) if self.rows else None
+            self.sel = (torch.cat([torch.arange(r * self.n_max, (r + 1) * self.n_max, device=device) for r in self.rows])
+                        if self.rows else None)
+            self.contiguous_rows = self.rows == list(range(self.rows[0], self.rows[0] + len(self.rows))) if self.rows else True
 
     def exchange(self, accum):
         """accum: float32 [H, W, 4] on every rank (only own pixels non-zero); complete on `dst` afterwards."""
         import torch.distributed as dist
         flat = accum.view(-1, 4)
-        self.send[: self.idx.numel()] = flat.index_select(0, self.idx)
+        n = self.idx.numel()
+        if n:
+            self.send[:n] = flat.index_select(0, self.idx)
+            if n < self.n_max:
+                self.send[n:] = self.send[n - 1]
         if self.world > 1:
             dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst)
-            if self.rank == self.dst:
-                for r in range(self.world):
-                    if r != self.dst:
-                        flat.index_copy_(0, self.all_idx[r], self.recv[r][: self.all_idx[r].numel()])
+            if self.rank == self.dst and self.all_idx is not None:
+                if self.contiguous_rows:
+                    src = self.big[self.rows[0] * self.n_max:(self.rows[-1] + 1) * self.n_max]
+                else:
+                    src = self.big.index_select(0, self.sel)
+                flat.index_copy_(0, self.all_idx, src)
         return accum
 
 
