@@ -46,11 +46,11 @@ def owned_tiles(rank, world, width, height, tile=TILE):
 
 
 def owner_mask(rank, world, width, height, tile=TILE):
-    """Boolean [H, W] mask of the pixels `rank` traces."""
+    """Boolean [H, W] mask of the pixels `rank` traces (tile-level ownership, expanded to pixels)."""
     import numpy as np
-    tiles_x = (width + tile - 1) // tile
-    ys, xs = np.mgrid[0:height, 0:width]
-    return ((ys // tile) * tiles_x + xs // tile) % world == rank
+    tiles_x, tiles_y = (width + tile - 1) // tile, (height + tile - 1) // tile
+    g = (np.arange(tiles_y)[:, None] * tiles_x + np.arange(tiles_x)[None, :]) % world == rank
+    return np.repeat(np.repeat(g, tile, axis=0), tile, axis=1)[:height, :width]
 
 
 def owned_pixel_index(rank, world, width, height, tile=TILE, device=None):
