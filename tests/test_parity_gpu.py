@@ -462,6 +462,37 @@ def test_textured_bunny_scene_bitwise(camera, pipeline, tail):
     pt.close()
 
 
+@pytest.mark.parametrize("pipeline,tail", [("wavefront", 0), ("wavefront", 1), ("megakernel", 0)])
+def test_more_layers_than_the_lds_table_holds(camera, pipeline, tail):
+    """520 quads of distinct flat colours and roughnesses -> more atlas layers than the 1 024 entries the shading kernels
+    stage in LDS: the kernels' global-table variants (k_wf_primary / k_wf_logic<..., false>) give the oracle's frame."""
+    from fspt_amd import scene as S
+    rng = np.random.default_rng(12)
+    props = []
+    for i in range(520):
+        c = [round(float(x), 3) for x in rng.uniform(0.05, 1.0, 3)]
+        props.append({"path": "synthetic/quad.obj", "scale": 0.45, "rotate": [{"angle": float(rng.uniform(0, 6.28)), "axis": [1, 0.3, 0.2]}],
+                      "translate": [float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-1.5, 0.5))],
+                      "emittance": [0, 0, 0], "diffuse": c, "metallicRoughness": [round(i / 700, 4), round(0.1 + i / 500, 4), 0],
+                      "emission": [round(0.001 * i, 4), 0, 0], "normals": "flat"})
+    env, w, h = S.synthetic_env(64, 32)
+    arrays = S.build_scene(props, {"synthetic/quad.obj": S.QUAD_OBJ}, env=env, env_w=w, env_h=h)
+    assert arrays.atlas_res == 1 and arrays.atlas_layers > 1024
+    W, H = 96, 60
+    pt = make_pt(arrays, W, H, camera, 3, pipeline, tail=tail)
+    pt.enable_counters(True)
+    pt.clear()
+    pt.seed(4)
+    pt.render(2)
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(arrays, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 3, 0, 2, 4,
+             want, counters=oc)
+    assert np.array_equal(pt.readRadiance(), want)
+    assert pt.counters() == oc.as_dict()
+    pt.close()
+
+
 @pytest.mark.parametrize("aperture,sun", [(0.02, None), (0.1, None), (0.1, (0.5, 2000.0))])
 def test_baseline_c1_config_bitwise(aperture, sun):
     """BASELINE configs[0] - the reference's own CPU-runnable case: 256x256, depth 4, 16 spp on the 69 316-triangle
