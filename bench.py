@@ -43,8 +43,10 @@ KERNELS = {
     "resolve": ("fspt::k_wf_resolve", "hbm"),
     "tail": ("fspt::k_wf_tail<false, true>", "l1_gather"),
 }
-# the kernel the roofline block is about: the largest share of GPU time in the committed rocprofv3 kernel statistics
-# of the default workload (profiles/: kernel_stats.csv) - fixed, not re-decided per run
+# The kernel the roofline block is about - fixed, not re-decided per run: the HBM-bound kernel class with the largest
+# share of GPU time in the committed rocprofv3 kernel statistics of the default workload (profiles/r02/
+# final_kernel_stats.csv: logic 32.7 %, primary 28.4 %; the trace class, 33.4 %, is bound by the CU's L1 gather
+# pipeline, not by HBM - its figures are in roofline.kernels.trace).
 ROOFLINE_CLASS = "logic"
 
 CONFIGS = {  # BASELINE.json configs[1..4]
