@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4  # 614.4 G wave64 VALU instructions per second
 L1_GATHER_PEAK_GBS = 19000.0  # measured: coalesced dwordx4 loads from L1/L2, all CUs (profiles/r01/l1_pipe.json);
                               # divergent per-lane 64-byte records reach 13 800
 
@@ -391,6 +392,16 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
             num = kj["traffic_GBps"] if (bound == "hbm" and kj["traffic_GBps"] is not None) else gbps
             kj["frac"] = round(num / peak, 4)
             kernels[k] = kj
+        # What the pipeline as a whole runs against: the chip's VALU issue rate.  Wave-instructions per sample of every
+        # kernel class (SQ_INSTS_VALU, same stamped profile) x samples/s against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
+        # per wave64 instruction (the non-packed FP32 vector rate, half of the guide's 157.3 TFLOP/s packed figure).
+        valu = None
+        if prof and all("valu_wave_instr_per_sample" in v for v in prof["kernels"].values()):
+            wips = sum(v["valu_wave_instr_per_sample"] for v in prof["kernels"].values())
+            ach = wips * spt * steps / (kernel_ms / 1e3) / 1e9
+            valu = {"wave_instr_per_sample": round(wips, 1), "achieved_Ginstr_per_s": round(ach, 1),
+                    "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": round(ach / VALU_PEAK_GINSTR, 4),
+                    "per_kernel": {k.split("<")[0]: round(v["valu_wave_instr_per_sample"], 1) for k, v in prof["kernels"].items()}}
         dom = kernels[ROOFLINE_CLASS]
         d_ms, d_n = stages[ROOFLINE_CLASS]
         roofline = {"bound": dom["bound"], "achieved": dom["alg_GBps"], "peak": dom["peak_GBps"], "unit": "GB/s",
@@ -403,7 +414,7 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
                                        if dom["traffic_bytes_per_launch"] is not None else None),
                     "bytes_per_sample": round(bps, 1), "per_sample": per_sample,
                     "per_sample_timed_variant": {k: round(act[k] / max(1, spt), 4) for k in ("rays", "steps", "leaves")},
-                    "kernels": kernels,
+                    "kernels": kernels, "valu": valu,
                     "pipeline_alg_GBps": round(sum(alg.values()) * steps / (kernel_ms / 1e3) / 1e9, 1)}
     else:
         avg_launch_ms = kernel_ms / max(1, launches)

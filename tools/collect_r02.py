@@ -83,6 +83,18 @@ for tag, wl in pairs:
         if v.get("TCC_REQ_sum"):
             d["l2_hit_rate"] = round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 3)
         derived[k] = d
+    # VALU wave-instructions per sample (SQ_INSTS_VALU over the one 32-tick batch of the SQ pass)
+    sq_samples = None
+    for l in (open(f"{G}/{tag}_sq1.log") if os.path.exists(f"{G}/{tag}_sq1.log") else []):
+        if l.startswith("{"):
+            j = json.loads(l)
+            w, h = re.search(r"(\d+)x(\d+)", j["metric"]).groups()
+            sq_samples = int(w) * int(h) * j["steps"]
+    if sq_samples:
+        for k, v in c.items():
+            if "SQ_INSTS_VALU" in v and k in kern:
+                kern[k]["valu_wave_instr_per_sample"] = v["SQ_INSTS_VALU"] / sq_samples
+                derived[k]["valu_wave_instr_per_sample"] = round(v["SQ_INSTS_VALU"] / sq_samples, 2)
     if derived:
         json.dump({"note": "from <tag>_pmc_summary.txt: bench.py --steps 32 --batch 32 (one 32-tick batch); busy = *_BUSY_sum / "
                            "GRBM_GUI_ACTIVE / 31.33 instances (profiles/r01/l1_pipe.json)", "kernels": derived},
