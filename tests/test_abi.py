@@ -53,6 +53,11 @@ def test_no_cpu_fallback(small_scene):
     assert b"no CPU fallback" in lib.fspt_last_error()
     a = np.zeros(4, np.float32)
     assert lib.fspt_math_eval(0, 0, L.fptr(a), None, 4, L.fptr(a)) == -2
+    # the multi-device target: same, and its half-built state is torn down without a crash
+    m = C.c_void_p()
+    devs = (C.c_int * 2)(0, 1)
+    assert lib.fspt_multi_create(C.byref(d), devs, 2, 64, 48, C.byref(m)) == -2 and not m.value
+    assert lib.fspt_multi_create(C.byref(d), devs, 0, 64, 48, C.byref(m)) == -1  # no devices listed
 
 
 def test_scene_validation_errors(small_scene):
