@@ -13,7 +13,9 @@ the environment) the script is one rank; started plainly with --gpus N > 1 it la
 equal the number of ranks RCCL sees, or the run fails.  The frame is cut into 32x32 tiles dealt round-robin to the
 ranks (no data-path collective); ONE exchange of the RGBA32F radiance buffer to rank 0 closes every timed region
 (SURVEY 8e): a gather of each rank's own tiles (default) or a sum-reduce of the full frame (--exchange reduce).
-  --scaling weak   (default) the frame grows with N (1920*a x 1080*b, a*b = N): fixed work per GPU;
+  --scaling weak   (default) the same picture at sqrt(N) times the linear resolution (1920x1080, 2712x1526, 3840x2160,
+                   5432x3056 for N = 1, 2, 4, 8: same aspect ratio, so the same mix of sky / floor / mesh pixels): fixed
+                   work per GPU;
   --scaling strong the frame is fixed (--width x --height; --config c4 = BASELINE configs[3]: 3840x2160 over the GPUs).
 
 The timed region (exactly K steps between barriers) is run --reps times (default 5) and the MEDIAN is reported

@@ -77,9 +77,12 @@ def test_tile_ownership_partitions_frame():
 
 
 def test_weak_frame_keeps_per_gpu_pixels():
+    """Weak scaling keeps the picture (aspect ratio) and the per-GPU pixel count: sqrt(N) times the linear resolution."""
     for n in (1, 2, 4, 8):
         w, h = D.weak_frame(n, 1920, 1080)
-        assert w * h == n * 1920 * 1080
+        assert abs(w * h - n * 1920 * 1080) <= 0.003 * n * 1920 * 1080, (n, w, h)
+        assert abs(w / h - 1920 / 1080) < 2e-3
+    assert D.weak_frame(1, 1920, 1080) == (1920, 1080) and D.weak_frame(4, 1920, 1080) == (3840, 2160)
 
 
 def _run_bench(argv, env_extra=None, timeout=240):
@@ -122,7 +125,7 @@ def test_bench_under_torchrun_and_rank_mismatch():
     out = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0, p.stderr[-2000:]
     assert len(out) == 1 and out[0]["n_gpus"] == 2 and out[0]["world_size_seen"] == 2 and not out[0]["self_launched"]
-    assert out[0]["scaling"] == "weak" and out[0]["frame"] == [2 * 1920 // 16, 1080 // 16]
+    assert out[0]["scaling"] == "weak" and out[0]["frame"] == [D.weak_frame(2, 1920, 1080)[0] // 16, D.weak_frame(2, 1920, 1080)[1] // 16]
     # WORLD_SIZE says 2 ranks, --gpus says 4
     p, out = _run_bench(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in p.stderr and not out
