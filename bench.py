@@ -202,7 +202,7 @@ def dry_run(args, rank, local_rank, world):
     acc[mask] = float(rank + 1)
     t0 = time.perf_counter()
     if args.exchange == "gather":
-        D.TileGather(rank, world, W, H, torch.device("cpu")).exchange(acc)
+        D.TileGather(rank, world, W, H, torch.device("cpu"), channels=3).exchange(acc)
     else:
         D.reduce_radiance(acc, dst=0)
     dt = time.perf_counter() - t0
@@ -274,7 +274,8 @@ def main():
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     pt.bind_accumulator(accum.data_ptr(), keep=accum)
     pt.seed(1)
-    exch = D.TileGather(rank, n_gpus, W, H, accum.device) if (n_gpus > 1 and args.exchange == "gather") else None
+    # RGB only: the alpha of a traced pixel is the constant 1 (tracer.fs:517), the whole frame is traced here
+    exch = D.TileGather(rank, n_gpus, W, H, accum.device, channels=3) if (n_gpus > 1 and args.exchange == "gather") else None
     pt.prepare()  # path-state allocation happens here, never inside a timed region (even with --warmup 0)
 
     def barrier():

@@ -43,7 +43,7 @@ struct fspt_scene {
   int device = 0;
   int num_cus = 256;
   fspt::DScene d{};
-  void *nodes = nullptr, *tris = nullptr, *shade = nullptr, *atlas = nullptr, *layer_tab = nullptr, *env = nullptr, *bins = nullptr;
+  void *nodes = nullptr, *tris = nullptr /* leaf records */, *slot_tri = nullptr, *shade = nullptr, *atlas = nullptr, *layer_tab = nullptr, *env = nullptr, *bins = nullptr;
   uint32_t depth = 0, n_nodes = 0, n_tris = 0, n_interior = 0;
   bool has_dielectric = false; // some triangle can refract (tracer.fs:481-488: unbounded path length)
 };
@@ -204,12 +204,14 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   // The first TOP_BFS interior nodes in breadth-first order get the lowest numbers (every ray walks the top of
   // the tree: the traversal kernel keeps a prefix of them in LDS); the rest keep their pre-order.
   std::vector<int32_t> ref(N);
+  std::vector<uint32_t> leaf_first; // first triangle of every leaf, in node order
   uint32_t n_interior = 0;
   for (uint32_t i = 0; i < N; ++i) {
     int32_t l = word(i, 0), r = word(i, 1), ts = word(i, 2);
     if (ts > -1) {
       if ((uint32_t)ts > T) { fspt_set_error("node %u: triStart %d > n_tris %u", i, ts, T); return FSPT_E_INVALID; }
-      ref[i] = ~ts;
+      ref[i] = ~(int32_t)leaf_first.size(); // leaf record index
+      leaf_first.push_back((uint32_t)ts);
     } else {
       // serializeTree is pre-order (bvh.js:33-50): children come after their parent.
       if (l <= (int32_t)i || r <= (int32_t)i || (uint32_t)l >= N || (uint32_t)r >= N) {
@@ -281,8 +283,9 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     if (depth[i] + 1 > max_depth) max_depth = depth[i] + 1;
     float *n = &nodes[(size_t)ref[i] * 16];
     const float *lb = desc->bvh + (size_t)l * 9 + 3, *rb = desc->bvh + (size_t)r * 9 + 3;
-    n[0] = lb[0]; n[1] = lb[1]; n[2] = lb[2]; n[3] = lb[3]; n[4] = lb[4]; n[5] = lb[5];
-    n[6] = rb[0]; n[7] = rb[1]; n[8] = rb[2]; n[9] = rb[3]; n[10] = rb[4]; n[11] = rb[5];
+    n[0] = lb[0]; n[1] = lb[1]; n[2] = lb[3]; n[3] = lb[4];   // lmin.xy lmax.xy
+    n[4] = rb[0]; n[5] = rb[1]; n[6] = rb[3]; n[7] = rb[4];   // rmin.xy rmax.xy
+    n[8] = lb[2]; n[9] = lb[5]; n[10] = rb[2]; n[11] = rb[5]; // lmin.z lmax.z rmin.z rmax.z
     int32_t lr[4] = {ref[l], ref[r], 0, 0};
     std::memcpy(n + 12, lr, 16);
   }
@@ -294,7 +297,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   }
   // ---- pre-edged triangles, padded by leaf_size "-1" triangles (main.js:150-152) ----
   const uint32_t TP = T + desc->leaf_size;
-  std::vector<float> tris((size_t)TP * 9 + 4, 0.0f); // +4: the last 16-byte load of a leaf may run 12 B past it
+  std::vector<float> tris((size_t)TP * 9, 0.0f);
   for (uint32_t i = 0; i < TP; ++i) {
     float v[9];
     if (i < T) std::memcpy(v, desc->tri + (size_t)i * 9, 36);
@@ -304,19 +307,36 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     o[3] = v[3] - v[0]; o[4] = v[4] - v[1]; o[5] = v[5] - v[2]; // e1 = v2 - v1 (tracer.fs:301)
     o[6] = v[6] - v[0]; o[7] = v[7] - v[1]; o[8] = v[8] - v[2]; // e2 = v3 - v1 (tracer.fs:302)
   }
-  // ---- 192-byte hit records -----------------------------------------------------
+  // ---- leaf records: the leaf_size triangles processLeaf reads from each leaf's first one, component-major ----
+  const uint32_t LS = desc->leaf_size;
+  const size_t n_leaves = leaf_first.size();
+  std::vector<float> leaves((n_leaves ? n_leaves : 1) * (size_t)LS * 9, 0.0f);
+  std::vector<uint32_t> slot_tri((n_leaves ? n_leaves : 1) * (size_t)LS, 0u);
+  for (size_t L = 0; L < n_leaves; ++L) {
+    float *rec = &leaves[L * LS * 9];
+    for (uint32_t k = 0; k < LS; ++k) {
+      const uint32_t ti = leaf_first[L] + k; // <= T - 1 + leaf_size: inside the padded array
+      for (int c = 0; c < 9; ++c) rec[(size_t)c * LS + k] = tris[(size_t)ti * 9 + c];
+      slot_tri[L * LS + k] = ti;
+    }
+  }
+  // ---- 192-byte hit records, one per leaf SLOT (what the traversal reports): slot (L, k) holds triangle leaf_first[L] + k ----
   bool has_dielectric = false;
-  std::vector<float> shade((size_t)T * 48, 0.0f);
-  for (uint32_t i = 0; i < T; ++i) {
-    float *o = &shade[(size_t)i * 48];
+  const size_t n_slots = (n_leaves ? n_leaves : 1) * (size_t)LS;
+  std::vector<float> shade(n_slots * 48, 0.0f);
+  for (size_t sl = 0; sl < n_leaves * LS; ++sl) {
+    const uint32_t i = slot_tri[sl];
+    if (i >= T) continue; // "-1" padding: never hit (det = 0)
+    float *o = &shade[sl * 48];
     std::memcpy(o, &tris[(size_t)i * 9], 36);
     std::memcpy(o + 9, desc->norm + (size_t)i * 27, 27 * 4);
     std::memcpy(o + 36, desc->uv + (size_t)i * 6, 6 * 4);
     const float *m = desc->mat + (size_t)i * 12;
     o[42] = m[0]; o[43] = m[1]; o[44] = m[2]; o[45] = m[3]; // diffuse, emissive("specular"), normal, mr layers
     o[46] = m[9]; o[47] = m[10];                             // ior, dielectric
-    if (m[10] >= 0.0f) has_dielectric = true;
   }
+  for (uint32_t i = 0; i < T; ++i)
+    if (desc->mat[(size_t)i * 12 + 10] >= 0.0f) has_dielectric = true;
 
   int rc = check_device(device);
   if (rc) return rc;
@@ -332,7 +352,8 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   };
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = upload(&s->nodes, nodes.data(), nodes.size() * 4);
-  if (e == hipSuccess) e = upload(&s->tris, tris.data(), tris.size() * 4);
+  if (e == hipSuccess) e = upload(&s->tris, leaves.data(), leaves.size() * 4);
+  if (e == hipSuccess) e = upload(&s->slot_tri, slot_tri.data(), slot_tri.size() * 4);
   if (e == hipSuccess) e = upload(&s->shade, shade.data(), shade.size() * 4);
   // Atlas: a layer table + the non-constant layers in 8 x 4-texel tiles (one 128-byte line per tile).  A layer whose
   // texels are all equal - every flat colour: TexturePacker fills whole layers with them (texture_packer.js:36-42),
@@ -369,7 +390,8 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     return FSPT_E_HIP;
   }
   s->d.nodes = (const float4 *)s->nodes;
-  s->d.tris = (const float *)s->tris;
+  s->d.leaves = (const float *)s->tris;
+  s->d.slot_tri = (const uint32_t *)s->slot_tri;
   s->d.hitrec = (const float4 *)s->shade;
   s->d.atlas = (const uint32_t *)s->atlas;
   s->d.layer_tab = (const uint2 *)s->layer_tab;
@@ -397,7 +419,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
 int fspt_scene_destroy(fspt_scene *s) {
   if (!s) return FSPT_OK;
   hipSetDevice(s->device);
-  hipFree(s->nodes); hipFree(s->tris); hipFree(s->shade); hipFree(s->atlas); hipFree(s->layer_tab); hipFree(s->env); hipFree(s->bins);
+  hipFree(s->nodes); hipFree(s->tris); hipFree(s->slot_tri); hipFree(s->shade); hipFree(s->atlas); hipFree(s->layer_tab); hipFree(s->env); hipFree(s->bins);
   delete s;
   return FSPT_OK;
 }

@@ -7,7 +7,7 @@
 namespace fspt {
 
 // Traversal references.  ref >= 0: interior node index (native numbering,
-// root = 0); ref < 0: leaf, first triangle = ~ref; REF_SENTINEL: empty stack.
+// root = 0); ref < 0: leaf, leaf record = ~ref; REF_SENTINEL: empty stack.
 constexpr int REF_SENTINEL = (int)0x80000000;
 
 constexpr float MAX_T = 100000.0f;       // tracer.fs:10
@@ -29,23 +29,29 @@ constexpr int TEX_TILE_W = 1 << TEX_TILE_W_LOG2, TEX_TILE_H = 1 << TEX_TILE_H_LO
 constexpr uint32_t LAYER_CONST = 0xFFFFFFFFu;
 
 constexpr int NODE_F4 = 4;   // 64-byte two-child node = 4 x float4
-constexpr int TRI_FLOATS = 9;  // 36-byte packed pre-edged triangle (traversal)
+constexpr int TRI_FLOATS = 9;  // pre-edged triangle: v1, e1 = v2 - v1, e2 = v3 - v1 (tracer.fs:301-302 precomputed)
 constexpr int HITREC_F4 = 12; // 192-byte hit record (shading) = 12 x float4 = exactly 3 cache lines
 
-// Node (64 B):   f4[0] = lmin.xyz lmax.x   f4[1] = lmax.yz rmin.xy
-//                f4[2] = rmin.z rmax.xyz   f4[3] = (int) left_ref right_ref 0 0
+// Node (64 B), the slab bounds of both children in the pairs the packed-FP32 box test consumes (fspt_kernels.hip node_test):
+//                f4[0] = lmin.xy lmax.xy   f4[1] = rmin.xy rmax.xy
+//                f4[2] = lmin.z lmax.z rmin.z rmax.z   f4[3] = (int) left_ref right_ref 0 0
 //   (tracer.fs:374-378 fetches the header of `current` and then, dependently,
 //    the boxes of both children: 3 round trips; here one.)
-// Tri (36 B, packed): v1.xyz e1.xyz e2.xyz; e1 = v2 - v1, e2 = v3 - v1 in binary32 =
-//   tracer.fs:301-302 precomputed.  A leaf visit reads LEAF_SIZE consecutive records
-//   (tracer.fs:355-364): 4 x 36 B = 144 contiguous bytes = 9 dword-aligned 16-byte loads.
-// HitRec (192 B, 64-byte aligned = exactly 3 cache lines per shaded hit):
+// Leaf record (LEAF_SIZE x 36 B = 144 B for LEAF_SIZE 4): the LEAF_SIZE consecutive triangles the reference's processLeaf
+//   reads from the leaf's first one (tracer.fs:355-364 - a leaf with fewer triangles reads on into its successors, the
+//   last leaves into the "-1" padding, main.js:150-152), pre-edged, COMPONENT-major: floats [c * LEAF_SIZE + i] =
+//   component c (v1.xyz e1.xyz e2.xyz) of triangle i.  For LEAF_SIZE 4 that is nine 16-byte loads whose halves are the
+//   operand pairs of the two-triangles-at-once intersection (ray_tri2).  A leaf's ref is ~(its record index);
+//   slot_tri[record * LEAF_SIZE + i] = that triangle's index in the reference's order (what tracer.fs:360 reports).
+// HitRec (192 B, 64-byte aligned = exactly 3 cache lines per shaded hit), one per leaf SLOT - the traversal's hit index
+//   addresses it directly, no translation on the path (a triangle that is also an earlier leaf's over-read has a copy there):
 //   floats 0..8 the same v1,e1,e2; 9..35 normTex record (n,t,bt per vertex,
 //   main.js:383-385); 36..41 uv (main.js:386); 42..45 layers diffuse/emissive/normal/mr
 //   (main.js:377-379); 46 ior; 47 dielectric.
 struct DScene {
   const float4 *nodes;
-  const float *tris;    // packed 9-float triangles (+ LEAF_SIZE padding records)
+  const float *leaves;  // leaf records (see above)
+  const uint32_t *slot_tri; // leaf slot -> triangle index
   const float4 *hitrec; // 12 x float4 per triangle
   const uint32_t *atlas; // RGBA8 texels of the STORED (non-constant) layers, each tiled (TEX_TILE_*), atlas_layer_stride texels apart
   const uint2 *layer_tab; // per atlas layer: x = index of the stored layer, or LAYER_CONST: every texel equals y

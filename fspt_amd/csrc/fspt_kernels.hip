@@ -43,15 +43,34 @@ using namespace fm;
 #define WORK_CHUNK 256u
 
 // ---------------------------------------------------------------------------
-// rayBoxIntersect (tracer.fs:317-326); 1/dir hoisted (same value every call)
+// rayBoxIntersect (tracer.fs:317-326) for BOTH child boxes of a node; 1/dir hoisted (same value every call).
+// Packed FP32: gfx950 issues v_pk_add_f32 / v_pk_mul_f32 (two IEEE binary32 operations per lane) at the rate of one
+// scalar operation, and the traversal kernels are bound by VALU issue (profiles/r02: 0.85-0.98 of the issue rate), so
+// the node stores the slab bounds in the pairs the arithmetic wants (fspt_device.hpp): the 12 subtractions and 12
+// multiplications of a step are 6 + 6 instructions.  Same operations on the same operands as the scalar form:
+// bit-identical results.
 // ---------------------------------------------------------------------------
-FM_DEV float ray_box(V3 bmin, V3 bmax, V3 o, V3 inv) {
-  float t1x = (bmin.x - o.x) * inv.x, t2x = (bmax.x - o.x) * inv.x;
-  float t1y = (bmin.y - o.y) * inv.y, t2y = (bmax.y - o.y) * inv.y;
-  float t1z = (bmin.z - o.z) * inv.z, t2z = (bmax.z - o.z) * inv.z;
-  float tMax = min_(min_(max_(t1x, t2x), max_(t1y, t2y)), max_(t1z, t2z));
-  float tMin = max_(max_(min_(t1x, t2x), min_(t1y, t2y)), min_(t1z, t2z));
+typedef float f2 __attribute__((ext_vector_type(2)));
+FM_DEV f2 mk2(float a, float b) { return (f2){a, b}; }
+FM_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+FM_DEV float slab(f2 txy1, f2 txy2, f2 tz) {
+  float tMax = min_(min_(max_(txy1.x, txy2.x), max_(txy1.y, txy2.y)), max_(tz.x, tz.y));
+  float tMin = max_(max_(min_(txy1.x, txy2.x), min_(txy1.y, txy2.y)), min_(tz.x, tz.y));
   return (tMax >= tMin && tMax > 0.0f) ? tMin : MAX_T;
+}
+FM_DEV void node_test(float4 n0, float4 n1, float4 n2, V3 o, V3 inv, float &tl, float &tr) {
+  const f2 oxy = mk2(o.x, o.y), ixy = mk2(inv.x, inv.y), oz = mk2(o.z, o.z), iz = mk2(inv.z, inv.z);
+  const f2 l1 = (mk2(n0.x, n0.y) - oxy) * ixy, l2 = (mk2(n0.z, n0.w) - oxy) * ixy; // left: (t1x, t1y), (t2x, t2y)
+  const f2 r1 = (mk2(n1.x, n1.y) - oxy) * ixy, r2 = (mk2(n1.z, n1.w) - oxy) * ixy; // right
+  const f2 lz = (mk2(n2.x, n2.y) - oz) * iz, rz = (mk2(n2.z, n2.w) - oz) * iz;     // (t1z, t2z) left, right
+  tl = slab(l1, l2, lz);
+  tr = slab(r1, r2, rz);
+}
+// The two child references of a node (f4[3].xy): ONE 8-byte load.  (Written as an int2 / int4 access the compiler
+// widens it to 16 bytes.)
+FM_DEV int2 node_refs(const float4 *n) {
+  const long long rr = *reinterpret_cast<const long long *>(n + 3);
+  return make_int2((int)(rr & 0xffffffffll), (int)(rr >> 32));
 }
 
 // rayTriangleIntersect (tracer.fs:300-315) on a pre-edged triangle; the early
@@ -69,34 +88,55 @@ FM_DEV float ray_tri(V3 o, V3 d, V3 v1, V3 e1, V3 e2) {
   return miss ? MAX_T : dist;
 }
 
+// Two triangles at once (packed FP32, see node_test): component c of the pair is (tri_a.c, tri_b.c).  Every
+// operation is ray_tri's, on the same operands, in the same order.
+FM_DEV f2 ray_tri2(V3 o, V3 d, f2 v1x, f2 v1y, f2 v1z, f2 e1x, f2 e1y, f2 e1z, f2 e2x, f2 e2y, f2 e2z) {
+  const f2 dx = mk2(d.x, d.x), dy = mk2(d.y, d.y), dz = mk2(d.z, d.z);
+  const f2 px = fma2(dy, e2z, -(dz * e2y)), py = fma2(dz, e2x, -(dx * e2z)), pz = fma2(dx, e2y, -(dy * e2x)); // cross(d, e2)
+  const f2 det = fma2(e1z, pz, fma2(e1y, py, e1x * px));
+  const f2 invDet = mk2(1.0f / det.x, 1.0f / det.y);
+  const f2 tx = mk2(o.x, o.x) - v1x, ty = mk2(o.y, o.y) - v1y, tz = mk2(o.z, o.z) - v1z;
+  const f2 u = fma2(tz, pz, fma2(ty, py, tx * px)) * invDet;
+  const f2 qx = fma2(ty, e1z, -(tz * e1y)), qy = fma2(tz, e1x, -(tx * e1z)), qz = fma2(tx, e1y, -(ty * e1x)); // cross(t, e1)
+  const f2 v = fma2(dz, qz, fma2(dy, qy, dx * qx)) * invDet;
+  const f2 dist = fma2(e2z, qz, fma2(e2y, qy, e2x * qx)) * invDet;
+  const f2 uv = u + v;
+  const bool m0 = (abs_(det.x) < EPSILON) || (u.x < 0.0f) || (u.x > 1.0f) || (v.x < 0.0f) || (uv.x > 1.0f) || !(dist.x > EPSILON);
+  const bool m1 = (abs_(det.y) < EPSILON) || (u.y < 0.0f) || (u.y > 1.0f) || (v.y < 0.0f) || (uv.y > 1.0f) || !(dist.y > EPSILON);
+  return mk2(m0 ? MAX_T : dist.x, m1 ? MAX_T : dist.y);
+}
+
 // ---------------------------------------------------------------------------
-// processLeaf (tracer.fs:355-364): always LEAF_SIZE triangles from `ts`, strict `<` update.
-// LEAF_SIZE = 4: the 4 packed 36-byte records are 144 contiguous bytes = 9 dword-aligned
-// 16-byte loads (gfx950 global loads only need dword alignment).
+// processLeaf (tracer.fs:355-364): always LEAF_SIZE triangles from the leaf's first one, strict `<` update in
+// triangle order.  Leaf record `leaf` (fspt_device.hpp): the LEAF_SIZE pre-edged triangles the reference would read,
+// component-major - for LEAF_SIZE = 4 nine 16-byte loads whose halves are the operand pairs of ray_tri2.
+// `hit` becomes the leaf SLOT (leaf * LEAF_SIZE + i): the index the hit records are stored under; slot_to_tri gives
+// the reference's triangle index where one is reported (fspt_intersect).
 // ---------------------------------------------------------------------------
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-FM_DEV void process_leaf(const float *__restrict__ tris, uint32_t leaf_size, int ts, V3 o, V3 d, float &t, int &hit) {
-  const float *tp = tris + (size_t)ts * TRI_FLOATS;
+typedef float f4u __attribute__((ext_vector_type(4)));
+FM_DEV void process_leaf(const float *__restrict__ leaves, uint32_t leaf_size, int leaf, V3 o, V3 d, float &t, int &hit) {
   if (leaf_size == 4) {
-    const f4u *q = reinterpret_cast<const f4u *>(tp);
-    f4u r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5], r6 = q[6], r7 = q[7], r8 = q[8];
-    float res;
-    res = ray_tri(o, d, v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y), v3(r1.z, r1.w, r2.x));
-    if (res < t) { t = res; hit = ts; }
-    res = ray_tri(o, d, v3(r2.y, r2.z, r2.w), v3(r3.x, r3.y, r3.z), v3(r3.w, r4.x, r4.y));
-    if (res < t) { t = res; hit = ts + 1; }
-    res = ray_tri(o, d, v3(r4.z, r4.w, r5.x), v3(r5.y, r5.z, r5.w), v3(r6.x, r6.y, r6.z));
-    if (res < t) { t = res; hit = ts + 2; }
-    res = ray_tri(o, d, v3(r6.w, r7.x, r7.y), v3(r7.z, r7.w, r8.x), v3(r8.y, r8.z, r8.w));
-    if (res < t) { t = res; hit = ts + 3; }
+    const f4u *q = reinterpret_cast<const f4u *>(leaves) + (size_t)leaf * TRI_FLOATS;
+    const f4u c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3], c4 = q[4], c5 = q[5], c6 = q[6], c7 = q[7], c8 = q[8];
+    const f2 a = ray_tri2(o, d, c0.xy, c1.xy, c2.xy, c3.xy, c4.xy, c5.xy, c6.xy, c7.xy, c8.xy);
+    const f2 b = ray_tri2(o, d, c0.zw, c1.zw, c2.zw, c3.zw, c4.zw, c5.zw, c6.zw, c7.zw, c8.zw);
+    const int s0 = leaf * 4;
+    if (a.x < t) { t = a.x; hit = s0; }
+    if (a.y < t) { t = a.y; hit = s0 + 1; }
+    if (b.x < t) { t = b.x; hit = s0 + 2; }
+    if (b.y < t) { t = b.y; hit = s0 + 3; }
   } else {
+    const float *a = leaves + (size_t)leaf * leaf_size * TRI_FLOATS;
     for (uint32_t i = 0; i < leaf_size; ++i) {
-      const float *a = tp + (size_t)i * TRI_FLOATS;
-      float res = ray_tri(o, d, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]));
-      if (res < t) { t = res; hit = ts + (int)i; }
+      float res = ray_tri(o, d, v3(a[i], a[leaf_size + i], a[2 * leaf_size + i]),
+                          v3(a[3 * leaf_size + i], a[4 * leaf_size + i], a[5 * leaf_size + i]),
+                          v3(a[6 * leaf_size + i], a[7 * leaf_size + i], a[8 * leaf_size + i]));
+      if (res < t) { t = res; hit = leaf * (int)leaf_size + (int)i; }
     }
   }
 }
+// leaf slot -> the reference's triangle index (first triangle of the leaf + i, tracer.fs:360); -1 stays -1
+FM_DEV int slot_to_tri(const DScene &S, int slot) { return slot < 0 ? -1 : (int)S.slot_tri[slot]; }
 
 struct Counters {
   uint32_t samples, rays, steps, leaves, shades, envs;
@@ -122,7 +162,7 @@ FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 d
   hitA = -1;
   if (COUNT) cnt.rays++;
   const float4 *__restrict__ nodes = S.nodes;
-  const float *__restrict__ tris = S.tris;
+  const float *__restrict__ leaves = S.leaves;
   const uint32_t leaf_size = S.leaf_size;
   while (true) {
     // ---- interior nodes ----------------------------------------------------
@@ -130,9 +170,9 @@ FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 d
       if (COUNT) cnt.steps++;
       const float4 *n = nodes + (size_t)cur * NODE_F4;
       float4 n0 = n[0], n1 = n[1], n2 = n[2];
-      int4 n3 = *reinterpret_cast<const int4 *>(n + 3);
-      float tl = ray_box(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv);
-      float tr = ray_box(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv);
+      const int2 n3 = node_refs(n);
+      float tl, tr;
+      node_test(n0, n1, n2, o, inv, tl, tr);
       bool hl = tl < t, hr = tr < t;
       bool swap = tl > tr; // tracer.fs:384: right first only when strictly nearer
       int nearRef = swap ? n3.y : n3.x;
@@ -170,7 +210,7 @@ FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 d
     {
       if (COUNT) { cnt.steps++; cnt.leaves++; }
       int ts = ~cur;
-      process_leaf(tris, leaf_size, ts, o, d, t, hit);
+      process_leaf(leaves, leaf_size, ts, o, d, t, hit);
       if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
       else cur = REF_SENTINEL;
       if (ANYHIT && slot == 0 && hit != -1) cur = REF_SENTINEL;
@@ -924,7 +964,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   const DScene &S = p.scene;
   int *stack = lds_stack + (size_t)wave * S.stack_n * WAVE + lane;
   const float4 *__restrict__ nodes = S.nodes;
-  const float *__restrict__ tris = S.tris;
+  const float *__restrict__ leaves = S.leaves;
   const uint32_t leaf_size = S.leaf_size;
   const WfSet st = p.set[p.round & 1];
   WfCounts *cn = p.counts + p.round;
@@ -1034,10 +1074,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
       } else {
         const float4 *n = nodes + (size_t)cur * NODE_F4;
         n0 = n[0]; n1 = n[1]; n2 = n[2];
-        n3 = *reinterpret_cast<const int2 *>(n + 3);
+        n3 = node_refs(n);
       }
-      float tl = ray_box(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv);
-      float tr = ray_box(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv);
+      float tl, tr;
+      node_test(n0, n1, n2, o, inv, tl, tr);
       bool hl = tl < t, hr = tr < t;
       bool swap = tl > tr;
       int nearRef = swap ? n3.y : n3.x;
@@ -1062,7 +1102,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     if (!idle && cur < 0 && cur != REF_SENTINEL) {
       if (COUNT) { c_steps++; c_leaves++; }
       int ts = ~cur;
-      process_leaf(tris, leaf_size, ts, o, d, t, hit);
+      process_leaf(leaves, leaf_size, ts, o, d, t, hit);
       if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
       else cur = REF_SENTINEL;
       // NEE shadow rays: only `shadow.index == -1` is consumed (tracer.fs:502), so the first hit settles
@@ -1334,16 +1374,16 @@ FM_DEV void trace_one(const DScene &S, int *stack, V3 o, V3 d, bool anyhit, bool
   int sp = 0;
   if (COUNT && active) cnt.rays++;
   const float4 *__restrict__ nodes = S.nodes;
-  const float *__restrict__ tris = S.tris;
+  const float *__restrict__ leaves = S.leaves;
   const uint32_t leaf_size = S.leaf_size;
   while (cur != REF_SENTINEL) {
     while (cur >= 0) {
       if (COUNT) cnt.steps++;
       const float4 *n = nodes + (size_t)cur * NODE_F4;
       float4 n0 = n[0], n1 = n[1], n2 = n[2];
-      int4 n3 = *reinterpret_cast<const int4 *>(n + 3);
-      float tl = ray_box(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv);
-      float tr = ray_box(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv);
+      const int2 n3 = node_refs(n);
+      float tl, tr;
+      node_test(n0, n1, n2, o, inv, tl, tr);
       bool hl = tl < t, hr = tr < t;
       bool swap = tl > tr; // tracer.fs:384: right first only when strictly nearer
       int nearRef = swap ? n3.y : n3.x;
@@ -1365,7 +1405,7 @@ FM_DEV void trace_one(const DScene &S, int *stack, V3 o, V3 d, bool anyhit, bool
     }
     if (cur == REF_SENTINEL) break;
     if (COUNT) { cnt.steps++; cnt.leaves++; }
-    process_leaf(tris, leaf_size, ~cur, o, d, t, hit);
+    process_leaf(leaves, leaf_size, ~cur, o, d, t, hit);
     if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
     else cur = REF_SENTINEL;
     if (anyhit && hit != -1) cur = REF_SENTINEL;
@@ -1385,8 +1425,13 @@ FM_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src, WAVE), __shfl(v.y, s
 // time (handed over and back with lane shuffles) - what such a launch costs is the longest chain of dependent rays,
 // and the shadow rays are off that chain this way.  It also ends paths that refraction keeps alive beyond NUM_BOUNCES
 // rounds (tracer.fs:488) without any host round trip.
+// 4 waves/SIMD (<= 128 VGPRs; 133 unbounded = 3): the kernel is a bundle of dependent chains, more of them in flight
+// is all that speeds it up - K=20 +1.3 %, 5 waves (spills) no better (profiles/r02/ab_ref8_tail_waves.log)
+#ifndef WF_TAIL_WAVES
+#define WF_TAIL_WAVES 4
+#endif
 template <bool COUNT, bool ANYHIT>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_wf_tail(const WfP p) {
+__global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const WfP p) {
   extern __shared__ int lds_stack[];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
@@ -1600,7 +1645,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_intersect(const IntersectP p)
   float tB;
   trace_rays<true, false>(p.scene, stack, o, false, d, d, hitA, tB, hitB, cnt);
   p.t_out[i] = tB;
-  p.index_out[i] = hitB;
+  p.index_out[i] = slot_to_tri(p.scene, hitB); // the reference's triangle index (tracer.fs:360)
   if (p.steps_out) p.steps_out[i] = cnt.steps;
   if (p.leaves_out) p.leaves_out[i] = cnt.leaves;
 }
@@ -1723,7 +1768,7 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
     else FSPT_LAUNCH_TRACE(false, true);
 #undef FSPT_LAUNCH_TRACE
   } else if (kernel == WF_K_TAIL) {
-    uint32_t grid = min((2u * total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 4u); // two lanes per path, 4 blocks/CU at 128 VGPRs
+    uint32_t grid = min((2u * total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * (WF_TAIL_WAVES > 4 ? WF_TAIL_WAVES : 4)); // two lanes per path
     size_t lds = stack_bytes(p.scene);
 #define FSPT_LAUNCH_TAIL(C, A)                                                                             \
     do {                                                                                                     \

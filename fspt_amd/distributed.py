@@ -74,18 +74,25 @@ class TileGather:
     the whole frame): every rank packs its own pixels (1/world of the frame), ONE gather to `dst` into slices of one
     receive buffer, and `dst` scatters all pieces into its full-size buffer with ONE index_copy_ (rows a rank pads its
     send buffer with repeat its last pixel, so their duplicate writes carry identical values).  Index tensors are built
-    once, outside any timed region."""
+    once, outside any timed region.
 
-    def __init__(self, rank, world, width, height, device, tile=TILE, dst=0):
+    channels = 3 ships RGB only: tracer.fs:517 writes vec4(rgb, 1), so the alpha of every traced pixel is the constant
+    1 - a quarter of the bytes on the links carried no information.  `dst` then sets the alpha of the gathered pixels
+    to 1 itself (once: nothing overwrites it).  Only valid when every owned pixel is traced (full-frame viewport);
+    channels = 4 (default) ships the buffer as it is."""
+
+    def __init__(self, rank, world, width, height, device, tile=TILE, dst=0, channels=4):
         import torch
-        self.rank, self.world, self.dst = rank, world, dst
+        assert channels in (3, 4)
+        self.rank, self.world, self.dst, self.C = rank, world, dst, channels
         self.idx = owned_pixel_index(rank, world, width, height, tile, device)
         counts = [int(owner_mask(r, world, width, height, tile).sum()) for r in range(world)]
         self.n_max = max(counts)
-        self.send = torch.zeros((self.n_max, 4), dtype=torch.float32, device=device)
-        self.recv, self.all_idx = None, None
+        self.send = torch.zeros((self.n_max, channels), dtype=torch.float32, device=device)
+        self.tmp = torch.zeros((self.n_max, 4), dtype=torch.float32, device=device) if channels != 4 else None
+        self.recv, self.all_idx, self.alpha_set = None, None, False
         if rank == dst:
-            self.big = torch.zeros((world * self.n_max, 4), dtype=torch.float32, device=device)
+            self.big = torch.zeros((world * self.n_max, channels), dtype=torch.float32, device=device)
             self.recv = list(self.big.split(self.n_max))  # views: the gather lands in one buffer
             pieces = []
             for r in range(world):
@@ -102,23 +109,47 @@ class TileGather:
                         if self.rows else None)
             self.contiguous_rows = self.rows == list(range(self.rows[0], self.rows[0] + len(self.rows))) if self.rows else True
 
-    def exchange(self, accum):
-        """accum: float32 [H, W, 4] on every rank (only own pixels non-zero); complete on `dst` afterwards."""
-        import torch.distributed as dist
+    def pack(self, accum):
+        """Own pixels of accum ([H, W, 4]) -> self.send ([n_max, channels])."""
+        import torch
         flat = accum.view(-1, 4)
         n = self.idx.numel()
         if n:
-            self.send[:n] = flat.index_select(0, self.idx)
+            if self.C == 4:
+                torch.index_select(flat, 0, self.idx, out=self.send[:n])
+            else:
+                torch.index_select(flat, 0, self.idx, out=self.tmp[:n])
+                self.send[:n].copy_(self.tmp[:n, :self.C])
             if n < self.n_max:
                 self.send[n:] = self.send[n - 1]
+        return self.send
+
+    def unpack(self, accum):
+        """`dst` only: the other ranks' rows of self.big -> their pixels of accum."""
+        if self.all_idx is None:
+            return accum
+        flat = accum.view(-1, 4)
+        if self.contiguous_rows:
+            src = self.big[self.rows[0] * self.n_max:(self.rows[-1] + 1) * self.n_max]
+        else:
+            src = self.big.index_select(0, self.sel)
+        if self.C == 4:
+            flat.index_copy_(0, self.all_idx, src)
+        else:
+            flat[:, :self.C].index_copy_(0, self.all_idx, src)
+            if not self.alpha_set:
+                flat[:, 3].index_fill_(0, self.all_idx, 1.0)
+                self.alpha_set = True
+        return accum
+
+    def exchange(self, accum):
+        """accum: float32 [H, W, 4] on every rank (only own pixels non-zero); complete on `dst` afterwards."""
+        import torch.distributed as dist
+        self.pack(accum)
         if self.world > 1:
             dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst)
-            if self.rank == self.dst and self.all_idx is not None:
-                if self.contiguous_rows:
-                    src = self.big[self.rows[0] * self.n_max:(self.rows[-1] + 1) * self.n_max]
-                else:
-                    src = self.big.index_select(0, self.sel)
-                flat.index_copy_(0, self.all_idx, src)
+            if self.rank == self.dst:
+                self.unpack(accum)
         return accum
 
 

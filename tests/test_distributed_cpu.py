@@ -44,9 +44,14 @@ def _worker(rank, world, port, tmp):
     D.reduce_radiance(t, dst=0)
     t2 = torch.from_numpy(acc.copy())
     D.TileGather(rank, world, W, H, torch.device("cpu")).exchange(t2)
+    t3 = torch.from_numpy(acc.copy())
+    g3 = D.TileGather(rank, world, W, H, torch.device("cpu"), channels=3)  # RGB only, alpha set by rank 0
+    g3.exchange(t3)
+    g3.exchange(t3)  # a second read-out of the same target (alpha is set once)
     if rank == 0:
         np.save(os.path.join(tmp, "reduced.npy"), t.numpy())
         np.save(os.path.join(tmp, "gathered.npy"), t2.numpy())
+        np.save(os.path.join(tmp, "gathered_rgb.npy"), t3.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,6 +69,7 @@ def test_two_rank_tile_shard_and_reduce(tmp_path):
     O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], lens, cam["env_theta"], 4, 0, TICKS, SEED, want)
     assert np.array_equal(got, want)
     assert np.array_equal(np.load(os.path.join(str(tmp_path), "gathered.npy")), want)  # tile-gather exchange
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "gathered_rgb.npy")), want)  # ... shipping RGB only
 
 
 def test_tile_ownership_partitions_frame():

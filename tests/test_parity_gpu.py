@@ -825,6 +825,18 @@ def test_bound_torch_accumulator_and_tile_gather_on_gpu(small_scene, camera):
     assert np.array_equal(full.cpu().numpy(), want)
     g = D.TileGather(0, 1, W, H, full.device)
     assert np.array_equal(g.exchange(full.clone()).cpu().numpy(), want)
+    # the two halves of a 2-rank exchange on this one GPU (the collective itself is the gloo test's): rank 1 packs,
+    # rank 0 scatters what it received - as RGBA and as RGB with the alpha set by rank 0
+    for ch in (4, 3):
+        accs = []
+        for r in range(2):
+            m = torch.from_numpy(D.owner_mask(r, 2, W, H)).to(full.device)
+            a = torch.zeros_like(full)
+            a[m] = full[m]
+            accs.append(a)
+        g0, g1 = D.TileGather(0, 2, W, H, full.device, channels=ch), D.TileGather(1, 2, W, H, full.device, channels=ch)
+        g0.recv[1].copy_(g1.pack(accs[1]))
+        assert np.array_equal(g0.unpack(accs[0]).cpu().numpy(), want)
 
 
 def test_frame_sequence_from_scene_files(tmp_path):
