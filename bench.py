@@ -120,6 +120,8 @@ def parse_args(argv=None):
     ap.add_argument("--sun-deg", type=float, default=None, help="angular radius of the environment's sun (default 1.5)")
     ap.add_argument("--sun-gain", type=float, default=None, help="sun radiance / sky radiance scale (default 60)")
     ap.add_argument("--textured", action="store_true", help="2048^2 image maps on the floor quads (scene/bunny.json:18-41)")
+    ap.add_argument("--tex-interleave-budget", type=int, default=None,
+                    help="bytes of interleaved material textures the scene may use (A/B: 0 = single-layer images only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "wavefront2"])
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
@@ -267,6 +269,8 @@ def main():
         cam["aperture"] = args.aperture
     lens = S.lens_features(cam["focal_depth"], cam["aperture"])
 
+    if args.tex_interleave_budget is not None:
+        fspt_amd.set_texture_interleave_budget(args.tex_interleave_budget)
     pt = fspt_amd.PathTracer(arrays, W, H, device=local_rank, num_bounces=args.bounces)
     pt.set_camera(**cam)
     pt.set_shard(rank, n_gpus, D.TILE)

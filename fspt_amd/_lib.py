@@ -80,6 +80,7 @@ _U32 = C.POINTER(C.c_uint32)
 SIGNATURES = {
     "fspt_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(_VP)]),
     "fspt_scene_destroy": (C.c_int, [_VP]),
+    "fspt_set_texture_interleave_budget": (C.c_int, [C.c_uint64]),
     "fspt_scene_depth": (C.c_int, [_VP, _U32]),
     "fspt_target_create": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "fspt_target_destroy": (C.c_int, [_VP]),

@@ -14,6 +14,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <cmath>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -43,7 +46,7 @@ struct fspt_scene {
   int device = 0;
   int num_cus = 256;
   fspt::DScene d{};
-  void *nodes = nullptr, *tris = nullptr /* leaf records */, *slot_tri = nullptr, *shade = nullptr, *atlas = nullptr, *layer_tab = nullptr, *env = nullptr, *bins = nullptr;
+  void *nodes = nullptr, *tris = nullptr /* leaf records */, *slot_tri = nullptr, *shade = nullptr, *atlas = nullptr, *atlas4 = nullptr, *tex_sets = nullptr, *env = nullptr, *bins = nullptr;
   uint32_t depth = 0, n_nodes = 0, n_tris = 0, n_interior = 0;
   bool has_dielectric = false; // some triangle can refract (tracer.fs:481-488: unbounded path length)
 };
@@ -108,6 +111,10 @@ struct fspt_target {
 
 // RGBA8 image (row-major, w x h) -> 8 x 4-texel tiles (fspt_device.hpp: TEX_TILE_*), padded to whole tiles.
 // Returns the number of texels of the tiled image; with src == nullptr only that.
+// Bytes of interleaved four-layer texture images (TEXSET_QUAD) a scene may allocate; sets beyond it fetch their image
+// layers from single-layer images (fspt_set_texture_interleave_budget).
+static uint64_t g_texset_budget = 8ull << 30;
+
 static size_t tile_image(const uint8_t *src, uint32_t w, uint32_t h, std::vector<uint32_t> &out) {
   const uint32_t tx = (w + fspt::TEX_TILE_W - 1) / fspt::TEX_TILE_W, ty = (h + fspt::TEX_TILE_H - 1) / fspt::TEX_TILE_H;
   const size_t n = (size_t)tx * ty * fspt::TEX_TILE_W * fspt::TEX_TILE_H;
@@ -171,6 +178,11 @@ float fspt_rand_base_next(uint64_t *state) {
 // ---------------------------------------------------------------------------
 // scene
 // ---------------------------------------------------------------------------
+int fspt_set_texture_interleave_budget(uint64_t bytes) {
+  g_texset_budget = bytes;
+  return FSPT_OK;
+}
+
 int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out) {
   if (!desc || !out) { fspt_set_error("fspt_scene_create: NULL argument"); return FSPT_E_INVALID; }
   *out = nullptr;
@@ -320,6 +332,28 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
       slot_tri[L * LS + k] = ti;
     }
   }
+  // ---- material texture sets: the four atlas layers a triangle samples at one uv (tracer.fs:453-456) ----
+  // layer = clamp(floor(id + 0.5), 0, layers - 1) as texture(sampler2DArray) selects it; same binary32 arithmetic here
+  const uint32_t n_layers = desc->atlas_layers;
+  auto layer_of = [&](float id) -> uint32_t {
+    const float x = std::floor(id + 0.5f);
+    if (!(x >= 0.0f)) return 0u; // negative, NaN (the device's float -> int conversion gives 0 for NaN)
+    if (x >= (float)(n_layers - 1u)) return n_layers - 1u;
+    return (uint32_t)x;
+  };
+  std::map<std::array<uint32_t, 4>, uint32_t> set_ids;
+  std::vector<std::array<uint32_t, 4>> set_keys;
+  std::vector<uint32_t> tri_set(T);
+  for (uint32_t i = 0; i < T; ++i) {
+    const float *m = desc->mat + (size_t)i * 12;
+    const std::array<uint32_t, 4> key = {layer_of(m[0]), layer_of(m[1]), layer_of(m[3]), layer_of(m[2])}; // diffuse, emissive, mr, normal
+    auto it = set_ids.find(key);
+    if (it == set_ids.end()) {
+      it = set_ids.emplace(key, (uint32_t)set_keys.size()).first;
+      set_keys.push_back(key);
+    }
+    tri_set[i] = it->second;
+  }
   // ---- 192-byte hit records, one per leaf SLOT (what the traversal reports): slot (L, k) holds triangle leaf_first[L] + k ----
   bool has_dielectric = false;
   const size_t n_slots = (n_leaves ? n_leaves : 1) * (size_t)LS;
@@ -332,7 +366,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     std::memcpy(o + 9, desc->norm + (size_t)i * 27, 27 * 4);
     std::memcpy(o + 36, desc->uv + (size_t)i * 6, 6 * 4);
     const float *m = desc->mat + (size_t)i * 12;
-    o[42] = m[0]; o[43] = m[1]; o[44] = m[2]; o[45] = m[3]; // diffuse, emissive("specular"), normal, mr layers
+    std::memcpy(&o[42], &tri_set[i], 4);                     // material texture set (diffuse, emissive, mr, normal layers)
     o[46] = m[9]; o[47] = m[10];                             // ior, dielectric
   }
   for (uint32_t i = 0; i < T; ++i)
@@ -355,28 +389,94 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   if (e == hipSuccess) e = upload(&s->tris, leaves.data(), leaves.size() * 4);
   if (e == hipSuccess) e = upload(&s->slot_tri, slot_tri.data(), slot_tri.size() * 4);
   if (e == hipSuccess) e = upload(&s->shade, shade.data(), shade.size() * 4);
-  // Atlas: a layer table + the non-constant layers in 8 x 4-texel tiles (one 128-byte line per tile).  A layer whose
-  // texels are all equal - every flat colour: TexturePacker fills whole layers with them (texture_packer.js:36-42),
-  // and a colours-only atlas is 1 x 1 - is not stored at all: its texel sits in the table.
-  uint32_t layer_stride = 0, n_stored = 0;
+  // Atlas.  A layer whose texels are all equal - every flat colour: TexturePacker fills whole layers with them
+  // (texture_packer.js:36-42), and a colours-only atlas is 1 x 1 - is never stored: its texel sits in the sets that use
+  // it.  A set with two or more image layers gets ONE interleaved image (16-byte texels: diffuse, emissive, mr, normal;
+  // 4 x 2-texel tiles = 128 bytes), as long as the interleaving budget lasts; the image layers of the other sets are
+  // stored once each as single-layer images in 8 x 4-texel tiles.
+  uint32_t n_sets = (uint32_t)set_keys.size();
   if (e == hipSuccess) {
-    const size_t per_layer = (size_t)desc->atlas_res * desc->atlas_res;
-    std::vector<uint32_t> tab((size_t)desc->atlas_layers * 2), all, tiled;
-    layer_stride = (uint32_t)tile_image(nullptr, desc->atlas_res, desc->atlas_res, tiled);
-    for (uint32_t l = 0; l < desc->atlas_layers; ++l) {
+    const uint32_t res = desc->atlas_res;
+    const size_t per_layer = (size_t)res * res;
+    std::vector<uint8_t> is_const(n_layers, 1);
+    std::vector<uint32_t> first(n_layers, 0u);
+    for (uint32_t l = 0; l < n_layers; ++l) {
       const uint8_t *src = desc->atlas + (size_t)l * per_layer * 4;
-      uint32_t first;
-      std::memcpy(&first, src, 4);
-      bool constant = true;
-      for (size_t k = 1; k < per_layer && constant; ++k) constant = std::memcmp(src + k * 4, &first, 4) == 0;
-      tab[2 * l + 1] = first;
-      if (constant) { tab[2 * l] = fspt::LAYER_CONST; continue; }
-      tab[2 * l] = n_stored++;
-      tile_image(src, desc->atlas_res, desc->atlas_res, tiled);
-      all.insert(all.end(), tiled.begin(), tiled.end());
+      std::memcpy(&first[l], src, 4);
+      for (size_t k = 1; k < per_layer && is_const[l]; ++k) is_const[l] = std::memcmp(src + k * 4, &first[l], 4) == 0;
     }
-    e = upload(&s->layer_tab, tab.data(), tab.size() * 4);
-    if (e == hipSuccess) e = upload(&s->atlas, all.data(), all.size() * 4);
+    const uint32_t qtx = (res + 3u) / 4u, qty = (res + 1u) / 2u;
+    const size_t quad_tiles = (size_t)qtx * qty;             // 128-byte tiles per interleaved image
+    std::vector<uint32_t> tab((size_t)n_sets * 12, 0u), kind(n_sets, fspt::TEXSET_CONST);
+    std::vector<int64_t> layer_base(n_layers, -1);            // single-layer image of a layer, in tiles (-1: not stored)
+    std::vector<uint32_t> single;                              // the single-layer images, tiled
+    std::vector<uint32_t> tiled;
+    const size_t single_tiles = tile_image(nullptr, res, res, tiled) / (fspt::TEX_TILE_W * fspt::TEX_TILE_H);
+    uint64_t quad_bytes = 0;
+    uint32_t n_quad = 0;
+    for (uint32_t si = 0; si < n_sets; ++si) {
+      const auto &key = set_keys[si];
+      uint32_t n_img = 0, distinct[4];
+      for (int k = 0; k < 4; ++k) {
+        if (is_const[key[k]]) continue;
+        bool seen = false;
+        for (uint32_t q = 0; q < n_img; ++q) seen = seen || distinct[q] == key[k];
+        if (!seen) distinct[n_img++] = key[k];
+      }
+      if (n_img >= 2 && quad_bytes + quad_tiles * 128u <= g_texset_budget && (n_quad + 1ull) * quad_tiles < 0xFFFFFFFFull) {
+        kind[si] = fspt::TEXSET_QUAD;
+        quad_bytes += quad_tiles * 128u;
+        n_quad++;
+      } else if (n_img >= 1) {
+        kind[si] = fspt::TEXSET_SEPARATE;
+      }
+    }
+    // single-layer images: the image layers of SEPARATE sets
+    for (uint32_t si = 0; si < n_sets; ++si) {
+      if (kind[si] != fspt::TEXSET_SEPARATE) continue;
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t l = set_keys[si][k];
+        if (is_const[l] || layer_base[l] >= 0) continue;
+        layer_base[l] = (int64_t)(single.size() / (fspt::TEX_TILE_W * fspt::TEX_TILE_H));
+        tile_image(desc->atlas + (size_t)l * per_layer * 4, res, res, tiled);
+        single.insert(single.end(), tiled.begin(), tiled.end());
+      }
+    }
+    (void)single_tiles;
+    if (single.size() / (fspt::TEX_TILE_W * fspt::TEX_TILE_H) >= 0xFFFFFFFFull) {
+      fspt_set_error("atlas too large: %zu texels of image layers", single.size());
+      fspt_scene_destroy(s);
+      return FSPT_E_INVALID;
+    }
+    if (e == hipSuccess) e = upload(&s->atlas, single.data(), single.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&s->atlas4, quad_bytes ? quad_bytes : 16);
+    std::vector<uint32_t> quad;
+    uint32_t qi = 0;
+    for (uint32_t si = 0; si < n_sets && e == hipSuccess; ++si) {
+      const auto &key = set_keys[si];
+      uint32_t *q = &tab[(size_t)si * 12];
+      q[0] = kind[si];
+      for (int k = 0; k < 4; ++k) {
+        q[4 + k] = first[key[k]];
+        q[8 + k] = (kind[si] == fspt::TEXSET_SEPARATE && !is_const[key[k]]) ? (uint32_t)layer_base[key[k]] : fspt::LAYER_CONST;
+      }
+      if (kind[si] != fspt::TEXSET_QUAD) continue;
+      q[1] = (uint32_t)(qi * quad_tiles);
+      quad.assign(quad_tiles * 32, 0u);
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t l = key[k];
+        const uint8_t *src = desc->atlas + (size_t)l * per_layer * 4;
+        for (uint32_t jy = 0; jy < res; ++jy)
+          for (uint32_t ix = 0; ix < res; ++ix) {
+            uint32_t v = first[l];
+            if (!is_const[l]) std::memcpy(&v, src + ((size_t)jy * res + ix) * 4, 4);
+            quad[(((size_t)(jy >> 1) * qtx + (ix >> 2)) * 8 + ((jy & 1u) << 2) + (ix & 3u)) * 4 + k] = v;
+          }
+      }
+      e = hipMemcpy((char *)s->atlas4 + (size_t)qi * quad_tiles * 128u, quad.data(), quad.size() * 4, hipMemcpyHostToDevice);
+      qi++;
+    }
+    if (e == hipSuccess) e = upload(&s->tex_sets, tab.data(), tab.size() * 4);
   }
   if (e == hipSuccess && desc->env) {
     std::vector<uint32_t> tiled;
@@ -394,11 +494,12 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   s->d.slot_tri = (const uint32_t *)s->slot_tri;
   s->d.hitrec = (const float4 *)s->shade;
   s->d.atlas = (const uint32_t *)s->atlas;
-  s->d.layer_tab = (const uint2 *)s->layer_tab;
+  s->d.atlas4 = (const uint4 *)s->atlas4;
+  s->d.tex_sets = (const uint4 *)s->tex_sets;
+  s->d.n_tex_sets = n_sets;
   s->d.env = (const uint32_t *)s->env;
   s->d.bins = (const uint4 *)s->bins;
   s->d.atlas_res = desc->atlas_res;
-  s->d.atlas_layer_stride = layer_stride;
   s->d.atlas_layers = desc->atlas_layers;
   s->d.env_w = desc->env ? desc->env_w : 0;
   s->d.env_h = desc->env ? desc->env_h : 0;
@@ -419,7 +520,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
 int fspt_scene_destroy(fspt_scene *s) {
   if (!s) return FSPT_OK;
   hipSetDevice(s->device);
-  hipFree(s->nodes); hipFree(s->tris); hipFree(s->slot_tri); hipFree(s->shade); hipFree(s->atlas); hipFree(s->layer_tab); hipFree(s->env); hipFree(s->bins);
+  hipFree(s->nodes); hipFree(s->tris); hipFree(s->slot_tri); hipFree(s->shade); hipFree(s->atlas); hipFree(s->atlas4); hipFree(s->tex_sets); hipFree(s->env); hipFree(s->bins);
   delete s;
   return FSPT_OK;
 }

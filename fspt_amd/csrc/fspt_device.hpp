@@ -27,6 +27,15 @@ constexpr int TEX_TILE_W_LOG2 = FSPT_TEX_TILE_W_LOG2, TEX_TILE_H_LOG2 = FSPT_TEX
 constexpr int TEX_TILE_W = 1 << TEX_TILE_W_LOG2, TEX_TILE_H = 1 << TEX_TILE_H_LOG2;
 
 constexpr uint32_t LAYER_CONST = 0xFFFFFFFFu;
+// Material texture set (3 x uint4 per set, DScene::tex_sets; a triangle's hit record names its set): the four atlas
+// layers a shading event samples at one uv (tracer.fs:453-456: diffuse, emissive, metallic-roughness, normal), resolved
+// at scene creation (layer = clamp(floor(id + 0.5)), the same binary32 arithmetic):
+//   [0] = kind, base of the interleaved image (in 128-byte tiles), 0, 0
+//   [1] = the four layers' texel where the layer is constant (every flat colour)
+//   [2] = SEPARATE form: per layer the base of its tiled single-layer image (in 128-byte tiles) or LAYER_CONST
+constexpr uint32_t TEXSET_CONST = 0u;    // four flat colours: no fetch at all
+constexpr uint32_t TEXSET_SEPARATE = 1u; // image layers fetched from single-layer images (8 x 4-texel tiles)
+constexpr uint32_t TEXSET_QUAD = 2u;     // the four layers interleaved texel by texel: 4 x 2-texel tiles of 16-byte texels
 
 constexpr int NODE_F4 = 4;   // 64-byte two-child node = 4 x float4
 constexpr int TRI_FLOATS = 9;  // pre-edged triangle: v1, e1 = v2 - v1, e2 = v3 - v1 (tracer.fs:301-302 precomputed)
@@ -46,19 +55,20 @@ constexpr int HITREC_F4 = 12; // 192-byte hit record (shading) = 12 x float4 = e
 // HitRec (192 B, 64-byte aligned = exactly 3 cache lines per shaded hit), one per leaf SLOT - the traversal's hit index
 //   addresses it directly, no translation on the path (a triangle that is also an earlier leaf's over-read has a copy there):
 //   floats 0..8 the same v1,e1,e2; 9..35 normTex record (n,t,bt per vertex,
-//   main.js:383-385); 36..41 uv (main.js:386); 42..45 layers diffuse/emissive/normal/mr
-//   (main.js:377-379); 46 ior; 47 dielectric.
+//   main.js:383-385); 36..41 uv (main.js:386); 42 (uint bits) the material texture set of the triangle's four
+//   layer ids (main.js:377-379); 46 ior; 47 dielectric.
 struct DScene {
   const float4 *nodes;
   const float *leaves;  // leaf records (see above)
   const uint32_t *slot_tri; // leaf slot -> triangle index
   const float4 *hitrec; // 12 x float4 per triangle
-  const uint32_t *atlas; // RGBA8 texels of the STORED (non-constant) layers, each tiled (TEX_TILE_*), atlas_layer_stride texels apart
-  const uint2 *layer_tab; // per atlas layer: x = index of the stored layer, or LAYER_CONST: every texel equals y
+  const uint32_t *atlas; // RGBA8 texels of the single-layer images (SEPARATE sets), each tiled (TEX_TILE_*)
+  const uint4 *atlas4;   // interleaved four-layer images (QUAD sets)
+  const uint4 *tex_sets; // 3 x uint4 per material texture set
   const uint32_t *env;   // RGBE texels, tiled (NULL = black default environment)
   const uint4 *bins;
   uint32_t atlas_res, atlas_layers;
-  uint32_t atlas_layer_stride;
+  uint32_t n_tex_sets;
   uint32_t env_w, env_h;
   uint32_t n_bins;
   uint32_t leaf_size;

@@ -240,35 +240,43 @@ FM_DEV float safe_floor_coord(float u) {
   return f;
 }
 struct Tap4 { uint32_t t00, t10, t01, t11; float a, b; };
-// Texel (i, j) of a w-wide image stored in 8 x 4-texel tiles (fspt_device.hpp: TEX_TILE_*): one tile = one 128-byte
-// cache line, so the 2 x 2 footprint of a bilinear fetch lies in 1.4 lines on average instead of 2 rows = 2 lines.
-FM_DEV uint32_t tex_offset(int i, int j, int tiles_x) {
-  return (uint32_t)(((j >> TEX_TILE_H_LOG2) * tiles_x + (i >> TEX_TILE_W_LOG2)) << (TEX_TILE_W_LOG2 + TEX_TILE_H_LOG2)) +
-         (uint32_t)(((j & (TEX_TILE_H - 1)) << TEX_TILE_W_LOG2) + (i & (TEX_TILE_W - 1)));
+// Texel (i, j) of a w-wide image stored in tiles of 2^WL2 x 2^HL2 texels (fspt_device.hpp): one tile = one 128-byte
+// cache line, so the 2 x 2 footprint of a bilinear fetch lies in 1.4 lines on average (8 x 4 tiles) instead of 2 rows = 2 lines.
+template <int WL2, int HL2>
+FM_DEV uint32_t tile_offset(int i, int j, int tiles_x) {
+  return (uint32_t)(((j >> HL2) * tiles_x + (i >> WL2)) << (WL2 + HL2)) + (uint32_t)(((j & ((1 << HL2) - 1)) << WL2) + (i & ((1 << WL2) - 1)));
 }
-// Footprint of a bilinear fetch at (s, t): the four texel offsets and the two weights.  Shared by the four atlas layers
-// a shading event reads at the same uv (tracer.fs:453-456): the wrap / floor / tile arithmetic is done once.
-struct TapGeom { uint32_t o00, o10, o01, o11; float a, b; bool pair; };
-FM_DEV TapGeom bilinear_geom(int w, int h, float s, float t, bool repeat_t) {
-  TapGeom g;
+// Footprint of a bilinear fetch at (s, t): the wrapped texel coordinates and the two weights.  Shared by the four atlas
+// layers a shading event reads at the same uv (tracer.fs:453-456): the wrap / floor arithmetic is done once.
+struct TexCoord { int i0, i1, j0, j1; float a, b; };
+FM_DEV TexCoord bilinear_coord(int w, int h, float s, float t, bool repeat_t) {
+  TexCoord c;
   float u = fma_(s, (float)w, -0.5f), v = fma_(t, (float)h, -0.5f);
   float fu = safe_floor_coord(u), fv = safe_floor_coord(v);
   float a = u - fu, b = v - fv;
   if (!(a >= 0.0f && a <= 1.0f)) a = 0.0f;
   if (!(b >= 0.0f && b <= 1.0f)) b = 0.0f;
   int i0 = (int)fu, j0 = (int)fv;
-  int i1 = wrap_repeat(i0 + 1, w);
-  i0 = wrap_repeat(i0, w);
-  int j1, j0w;
-  if (repeat_t) { j1 = wrap_repeat(j0 + 1, h); j0w = wrap_repeat(j0, h); }
-  else { j1 = wrap_clamp(j0 + 1, h); j0w = wrap_clamp(j0, h); }
+  c.i1 = wrap_repeat(i0 + 1, w);
+  c.i0 = wrap_repeat(i0, w);
+  if (repeat_t) { c.j1 = wrap_repeat(j0 + 1, h); c.j0 = wrap_repeat(j0, h); }
+  else { c.j1 = wrap_clamp(j0 + 1, h); c.j0 = wrap_clamp(j0, h); }
+  c.a = a; c.b = b;
+  return c;
+}
+// ... and its four texel offsets in a single-layer image (8 x 4-texel tiles)
+struct TapGeom { uint32_t o00, o10, o01, o11; float a, b; bool pair; };
+FM_DEV TapGeom tap_geom(const TexCoord &c, int w) {
+  TapGeom g;
   const int tiles_x = (w + TEX_TILE_W - 1) >> TEX_TILE_W_LOG2;
-  g.o00 = tex_offset(i0, j0w, tiles_x); g.o01 = tex_offset(i0, j1, tiles_x);
-  g.o10 = tex_offset(i1, j0w, tiles_x); g.o11 = tex_offset(i1, j1, tiles_x);
+  g.o00 = tile_offset<TEX_TILE_W_LOG2, TEX_TILE_H_LOG2>(c.i0, c.j0, tiles_x);
+  g.o01 = tile_offset<TEX_TILE_W_LOG2, TEX_TILE_H_LOG2>(c.i0, c.j1, tiles_x);
+  g.o10 = tile_offset<TEX_TILE_W_LOG2, TEX_TILE_H_LOG2>(c.i1, c.j0, tiles_x);
+  g.o11 = tile_offset<TEX_TILE_W_LOG2, TEX_TILE_H_LOG2>(c.i1, c.j1, tiles_x);
   // the two taps of a row are neighbours unless the column wraps or leaves the tile: one 8-byte load (dword-aligned)
   // instead of two 4-byte loads - half the lane-requests on the vector-memory pipeline, same texel values
-  g.pair = FSPT_TAP2 && i1 == i0 + 1 && (TEX_TILE_W == 1 || (i0 & (TEX_TILE_W - 1)) != TEX_TILE_W - 1);
-  g.a = a; g.b = b;
+  g.pair = FSPT_TAP2 && c.i1 == c.i0 + 1 && (TEX_TILE_W == 1 || (c.i0 & (TEX_TILE_W - 1)) != TEX_TILE_W - 1);
+  g.a = c.a; g.b = c.b;
   return g;
 }
 FM_DEV Tap4 fetch_taps(const uint32_t *texels, const TapGeom &g) {
@@ -285,29 +293,25 @@ FM_DEV Tap4 fetch_taps(const uint32_t *texels, const TapGeom &g) {
   return r;
 }
 FM_DEV Tap4 bilinear_taps(const uint32_t *texels, int w, int h, float s, float t, bool repeat_t) {
-  return fetch_taps(texels, bilinear_geom(w, h, s, t, repeat_t));
+  return fetch_taps(texels, tap_geom(bilinear_coord(w, h, s, t, repeat_t), w));
 }
 FM_DEV float tap_channel(const Tap4 &tp, int ch) {
   float t00 = unorm8((tp.t00 >> (8 * ch)) & 255u), t10 = unorm8((tp.t10 >> (8 * ch)) & 255u);
   float t01 = unorm8((tp.t01 >> (8 * ch)) & 255u), t11 = unorm8((tp.t11 >> (8 * ch)) & 255u);
   return lerp_(lerp_(t00, t10, tp.a), lerp_(t01, t11, tp.a), tp.b);
 }
-// texture(texArray, vec3(uv, layer)) (tracer.fs:453-456): the layer's texels for a footprint computed once per uv.
-// A layer whose texels are all equal (TexturePacker fills a whole res x res layer for every flat colour once one image
-// is in the atlas, texture_packer.js:36-42) is not stored: its one texel comes from the layer table, and
-// lerp(x, x, a) = fma(a, 0, x) = x exactly, so the four equal taps give the same bits as the fetch would.
-FM_DEV Tap4 atlas_taps(const DScene &S, const TapGeom &g, float layer) {
-  int l = (int)floor_(layer + 0.5f);
-  if (l < 0) l = 0;
-  if (l > (int)S.atlas_layers - 1) l = (int)S.atlas_layers - 1;
-  const uint2 info = S.layer_tab[l];
-  if (info.x == LAYER_CONST) {
+// One atlas layer of a material texture set in SEPARATE form: its tiled image, or - a layer whose texels are all equal
+// (TexturePacker fills a whole res x res layer for every flat colour once one image is in the atlas,
+// texture_packer.js:36-42) is not stored - its one texel: lerp(x, x, a) = fma(a, 0, x) = x exactly, so four equal taps
+// give the same bits as the fetch would.
+FM_DEV Tap4 layer_taps(const DScene &S, const TapGeom &g, uint32_t base_tiles, uint32_t texel) {
+  if (base_tiles == LAYER_CONST) {
     Tap4 r;
-    r.t00 = r.t10 = r.t01 = r.t11 = info.y;
+    r.t00 = r.t10 = r.t01 = r.t11 = texel;
     r.a = g.a; r.b = g.b;
     return r;
   }
-  return fetch_taps(S.atlas + (size_t)info.x * S.atlas_layer_stride, g);
+  return fetch_taps(S.atlas + (size_t)base_tiles * (TEX_TILE_W * TEX_TILE_H), g);
 }
 // envSample + envColor (tracer.fs:410-419)
 template <bool COUNT>
@@ -498,7 +502,7 @@ FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randB
   V3 n2 = v3(h4.z, h4.w, h5.x), t2 = v3(h5.y, h5.z, h5.w), b2 = v3(h6.x, h6.y, h6.z);
   V3 n3 = v3(h6.w, h7.x, h7.y), t3 = v3(h7.z, h7.w, h8.x), b3 = v3(h8.y, h8.z, h8.w);
   float uv0x = h9.x, uv0y = h9.y, uv1x = h9.z, uv1y = h9.w, uv2x = h10.x, uv2y = h10.y;
-  float layDiffuse = h10.z, laySpec = h10.w, layNormal = h11.x, layRough = h11.y;
+  float layDiffuse = h10.z; // (bits) the triangle's material texture set
   float ior = h11.z, dielectric = h11.w;
 
   V3 rd = ps.rd;
@@ -518,39 +522,53 @@ FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randB
   float tcy = fma_(w.z, uv2y, fma_(w.y, uv1y, w.x * uv0y));
   V3 texDiffuse, texEmissive, texNormal;
   float metallic, rough;
-  if (S.atlas_res == 1u) {
-    // flat-colour layers (texture_packer.js:36-42: colours only -> 1x1): the four bilinear taps are the same
-    // texel and lerp(x, x, a) = fma(a, 0, x) = x exactly, so the filter arithmetic is skipped (bit-identical)
-    const uint32_t nl = S.atlas_layers - 1u;
-    auto layer_of = [&](float layer) -> uint32_t {
-      int l = (int)floor_(layer + 0.5f);
-      return l < 0 ? 0u : ((uint32_t)l > nl ? nl : (uint32_t)l);
-    };
-    uint32_t q = S.layer_tab[layer_of(layDiffuse)].y;
+  // texture(texArray, vec3(uv, layer)) x 4 (tracer.fs:453-456) through the triangle's material texture set (hit
+  // record word 42; fspt_device.hpp TexSet): the four layers' texels of ONE footprint
+  const uint4 *tset = S.tex_sets + (size_t)__float_as_uint(layDiffuse) * 3;
+  const uint4 ts0 = tset[0], ts1 = tset[1];
+  if (ts0.x == TEXSET_CONST) {
+    // four flat colours (texture_packer.js:36-42; every material of a colours-only atlas): the four bilinear taps are
+    // the same texel and lerp(x, x, a) = fma(a, 0, x) = x exactly, so the filter arithmetic is skipped (bit-identical)
+    uint32_t q = ts1.x;
     texDiffuse = v3(unorm8(q & 255u), unorm8((q >> 8) & 255u), unorm8((q >> 16) & 255u));
-    q = S.layer_tab[layer_of(laySpec)].y;
+    q = ts1.y;
     texEmissive = v3(unorm8(q & 255u), unorm8((q >> 8) & 255u), unorm8((q >> 16) & 255u));
-    q = S.layer_tab[layer_of(layRough)].y;
+    q = ts1.z;
     metallic = unorm8(q & 255u);
     rough = unorm8((q >> 8) & 255u);
-    q = S.layer_tab[layer_of(layNormal)].y;
+    q = ts1.w;
     texNormal = v3((unorm8(q & 255u) - 0.5f) * 2.0f, (unorm8((q >> 8) & 255u) - 0.5f) * 2.0f,
                    (unorm8((q >> 16) & 255u) - 0.0f) * 1.0f);
   } else {
-    const TapGeom tg = bilinear_geom((int)S.atlas_res, (int)S.atlas_res, tcx, tcy, true);
-    // all eight loads of the four layers are issued before the first texel is decoded
-    const Tap4 qd = atlas_taps(S, tg, layDiffuse), qe = atlas_taps(S, tg, laySpec), qr = atlas_taps(S, tg, layRough),
-               qn = atlas_taps(S, tg, layNormal);
-    Tap4 q = qd;
-    texDiffuse = v3(tap_channel(q, 0), tap_channel(q, 1), tap_channel(q, 2));
-    q = qe;
-    texEmissive = v3(tap_channel(q, 0), tap_channel(q, 1), tap_channel(q, 2));
-    q = qr;
-    metallic = tap_channel(q, 0);
-    rough = tap_channel(q, 1);
-    q = qn;
-    texNormal = v3((tap_channel(q, 0) - 0.5f) * 2.0f, (tap_channel(q, 1) - 0.5f) * 2.0f,
-                   (tap_channel(q, 2) - 0.0f) * 1.0f);
+    const TexCoord tc = bilinear_coord((int)S.atlas_res, (int)S.atlas_res, tcx, tcy, true);
+    Tap4 qd, qe, qr, qn;
+    if (ts0.x == TEXSET_QUAD) {
+      // the four layers interleaved texel by texel (4 x 2-texel tiles of 16-byte texels): one 16-byte load per tap
+      // brings all four layers, and the footprint lies in 1.9 lines instead of 4 x 1.4
+      const uint4 *img = S.atlas4 + (size_t)ts0.y * 8u;
+      const int tiles_x = ((int)S.atlas_res + 3) >> 2;
+      const uint4 t00 = img[tile_offset<2, 1>(tc.i0, tc.j0, tiles_x)], t10 = img[tile_offset<2, 1>(tc.i1, tc.j0, tiles_x)];
+      const uint4 t01 = img[tile_offset<2, 1>(tc.i0, tc.j1, tiles_x)], t11 = img[tile_offset<2, 1>(tc.i1, tc.j1, tiles_x)];
+      qd = Tap4{t00.x, t10.x, t01.x, t11.x, tc.a, tc.b};
+      qe = Tap4{t00.y, t10.y, t01.y, t11.y, tc.a, tc.b};
+      qr = Tap4{t00.z, t10.z, t01.z, t11.z, tc.a, tc.b};
+      qn = Tap4{t00.w, t10.w, t01.w, t11.w, tc.a, tc.b};
+    } else {
+      // separate single-layer images (a set with one image layer, or sets beyond the interleaving budget): all loads
+      // of the image layers are issued before the first texel is decoded
+      const uint4 ts2 = tset[2];
+      const TapGeom tg = tap_geom(tc, (int)S.atlas_res);
+      qd = layer_taps(S, tg, ts2.x, ts1.x);
+      qe = layer_taps(S, tg, ts2.y, ts1.y);
+      qr = layer_taps(S, tg, ts2.z, ts1.z);
+      qn = layer_taps(S, tg, ts2.w, ts1.w);
+    }
+    texDiffuse = v3(tap_channel(qd, 0), tap_channel(qd, 1), tap_channel(qd, 2));
+    texEmissive = v3(tap_channel(qe, 0), tap_channel(qe, 1), tap_channel(qe, 2));
+    metallic = tap_channel(qr, 0);
+    rough = tap_channel(qr, 1);
+    texNormal = v3((tap_channel(qn, 0) - 0.5f) * 2.0f, (tap_channel(qn, 1) - 0.5f) * 2.0f,
+                   (tap_channel(qn, 2) - 0.0f) * 1.0f);
   }
   rough = rough * rough;
   float seed = fma_(origin.z, 4761.52835f, ((origin.x * randBase) * origin.y) * 1.396529836f);
@@ -1142,8 +1160,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 // LDS-staged tables of the shading kernels: the small read-only tables every shading event gathers from - the
 // atlas layer table (the texel of every flat-colour layer), the environment's importance bins and the batch's randBase values - are
 // staged in LDS once per block, so those gathers go through the LDS pipeline instead of the vector-memory pipeline.
-#ifndef WF_LDS_ATLAS
-#define WF_LDS_ATLAS 1024
+#ifndef WF_LDS_SETS
+#define WF_LDS_SETS 256 // material texture sets (48 B each) staged in LDS
 #endif
 #ifndef WF_LDS_BINS
 #define WF_LDS_BINS 1024
@@ -1178,17 +1196,17 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
   constexpr int U = WF_PRIMARY_U;
   __shared__ uint32_t s_cnt[U][NW];
   __shared__ uint32_t s_base;
-  __shared__ uint2 s_atlas[LDSTAB ? WF_LDS_ATLAS : 1];
+  __shared__ uint4 s_sets[LDSTAB ? WF_LDS_SETS * 3 : 1];
   __shared__ uint4 s_bins[LDSTAB ? WF_LDS_BINS : 1];
   __shared__ float s_rb[LDSTAB ? WF_MAX_BATCH : 1];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   DScene S = p.scene;
   if (LDSTAB) {
-    for (uint32_t i = threadIdx.x; i < S.atlas_layers; i += WF_LOGIC_THREADS) s_atlas[i] = p.scene.layer_tab[i];
+    for (uint32_t i = threadIdx.x; i < S.n_tex_sets * 3u; i += WF_LOGIC_THREADS) s_sets[i] = p.scene.tex_sets[i];
     for (uint32_t i = threadIdx.x; i < S.n_bins; i += WF_LOGIC_THREADS) s_bins[i] = p.scene.bins[i];
     if (threadIdx.x < WF_MAX_BATCH) s_rb[threadIdx.x] = p.rb_trace[threadIdx.x];
-    S.layer_tab = s_atlas;
+    S.tex_sets = s_sets;
     S.bins = s_bins;
     __syncthreads();
   }
@@ -1276,17 +1294,17 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
   constexpr int U = WF_LOGIC_U;
   __shared__ uint16_t s_list[U * WF_LOGIC_THREADS];
   __shared__ uint32_t s_n, s_total, s_gbase;
-  __shared__ uint2 s_atlas[LDSTAB ? WF_LDS_ATLAS : 1];
+  __shared__ uint4 s_sets[LDSTAB ? WF_LDS_SETS * 3 : 1];
   __shared__ uint4 s_bins[LDSTAB ? WF_LDS_BINS : 1];
   __shared__ float s_rb[LDSTAB ? WF_MAX_BATCH : 1];
   const int lane = threadIdx.x & (WAVE - 1);
   DScene S = p.scene;
   if (threadIdx.x == 0) s_n = 0;
   if (LDSTAB) {
-    for (uint32_t i = threadIdx.x; i < S.atlas_layers; i += WF_LOGIC_THREADS) s_atlas[i] = p.scene.layer_tab[i];
+    for (uint32_t i = threadIdx.x; i < S.n_tex_sets * 3u; i += WF_LOGIC_THREADS) s_sets[i] = p.scene.tex_sets[i];
     for (uint32_t i = threadIdx.x; i < S.n_bins; i += WF_LOGIC_THREADS) s_bins[i] = p.scene.bins[i];
     if (threadIdx.x < WF_MAX_BATCH) s_rb[threadIdx.x] = p.rb_trace[threadIdx.x];
-    S.layer_tab = s_atlas;
+    S.tex_sets = s_sets;
     S.bins = s_bins;
   }
   __syncthreads();
@@ -1781,7 +1799,7 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
 #undef FSPT_LAUNCH_TAIL
   } else if (kernel == WF_K_LOGIC || kernel == WF_K_PRIMARY) {
     uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * 4u);
-    const bool tab = WF_LOGIC_LDSTAB && p.scene.atlas_layers <= WF_LDS_ATLAS && p.scene.n_bins <= WF_LDS_BINS;
+    const bool tab = WF_LOGIC_LDSTAB && p.scene.n_tex_sets <= WF_LDS_SETS && p.scene.n_bins <= WF_LDS_BINS;
     if (kernel == WF_K_PRIMARY) {
       const size_t dyn = (size_t)(WF_LOGIC_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int);
 #define FSPT_LAUNCH_PRIMARY(C, T)                                                                          \

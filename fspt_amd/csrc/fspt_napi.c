@@ -27,7 +27,7 @@
  *   builderCreate / builderParseObj / builderCommit / builderNormalize / builderBuild / builderAutofocus /
  *   builderDestroy                                                   (native obj_loader.js + bvh.js, 1:1 fspt_builder_*)
  *   envBins(Uint8Array rgbe, w, h) -> Uint32Array                    (native env_sampler.js)
- *   sceneDestroy / targetDestroy / deviceCount / abiVersion
+ *   sceneDestroy / targetDestroy / deviceCount / abiVersion / setTextureInterleaveBudget
  */
 #include <node_api.h>
 #include <stdint.h>
@@ -524,6 +524,13 @@ static napi_value SetMemoryLimit(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_target_set_memory_limit((fspt_target *)h, (uint64_t)bytes));
   return undefined(env);
 }
+static napi_value SetTextureInterleaveBudget(napi_env env, napi_callback_info info) {
+  napi_value a[1]; double bytes;
+  if (get_args(env, info, 1, a) || get_f64(env, a[0], &bytes)) return NULL;
+  if (!(bytes >= 0.0 && bytes < 1.8e19)) { napi_throw_range_error(env, NULL, "fspt_napi: budget must be >= 0 bytes"); return NULL; }
+  FSPT_OK_OR_THROW(fspt_set_texture_interleave_budget((uint64_t)bytes));
+  return undefined(env);
+}
 static napi_value PathStateBytes(napi_env env, napi_callback_info info) {
   napi_value a[1], o, v; void *h; uint64_t bytes = 0; uint32_t batch = 0;
   if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
@@ -813,7 +820,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"traceTest", TraceTest}, {"render", Render}, {"clear", Clear},
       {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline},
-      {"setMemoryLimit", SetMemoryLimit}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail}, {"setDeferred", SetDeferred},
+      {"setMemoryLimit", SetMemoryLimit}, {"setTextureInterleaveBudget", SetTextureInterleaveBudget}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail}, {"setDeferred", SetDeferred},
       {"renderAsync", RenderAsync}, {"multiCreate", MultiCreate}, {"multiDestroy", MultiDestroy}, {"multiTarget", MultiTarget},
       {"multiCamera", MultiCamera}, {"multiTrace", MultiTrace}, {"multiRender", MultiRender}, {"multiRenderAsync", MultiRenderAsync},
       {"multiClear", MultiClear}, {"multiSync", MultiSync}, {"multiReadRadiance", MultiReadRadiance}, {"multiDraw", MultiDraw},

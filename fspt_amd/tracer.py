@@ -18,6 +18,11 @@ import numpy as np
 from . import _lib as L
 
 
+def set_texture_interleave_budget(nbytes):
+    """Memory later Scene()s may spend on interleaved material textures (fspt_set_texture_interleave_budget)."""
+    L.check(L.lib().fspt_set_texture_interleave_budget(int(nbytes)))
+
+
 class Scene:
     """Device-resident scene (initBVH's texture uploads, main.js:408-437,548-560)."""
 

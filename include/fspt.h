@@ -90,9 +90,15 @@ typedef struct fspt_scene_desc {
 } fspt_scene_desc;
 
 /* device = HIP device ordinal.  Builds the MI355X-native layouts (64-byte
- * two-child nodes, 36-byte pre-edged triangles, 192-byte hit records, textures in 128-byte tiles). */
+ * two-child nodes, 144-byte leaf records, 192-byte hit records, material texture sets in 128-byte tiles). */
 int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out);
 int fspt_scene_destroy(fspt_scene *scene);
+/* Memory fspt_scene_create may spend on INTERLEAVED material textures (process-wide; applies to scenes created
+ * afterwards; default 8 GiB).  A material that samples two or more image layers at one uv (tracer.fs:453-456) gets one
+ * image with 16-byte texels (its four layers side by side), res^2 * 16 bytes, so that a shading event's 16 taps lie in
+ * ~2 cache lines instead of ~6; materials beyond the budget (or bytes = 0) read their layers from single-layer images.
+ * The rendered values do not depend on it. */
+int fspt_set_texture_interleave_budget(uint64_t bytes);
 /* Maximum depth of the uploaded tree (root = 0); sizes the LDS stacks. */
 int fspt_scene_depth(const fspt_scene *scene, uint32_t *depth);
 

@@ -462,9 +462,32 @@ def test_textured_bunny_scene_bitwise(camera, pipeline, tail):
     pt.close()
 
 
+@pytest.mark.parametrize("budget", [0, 512 * 512 * 16, 3 * 512 * 512 * 16])
+def test_textured_scene_any_interleave_budget(camera, budget):
+    """The image layers of a material are fetched from one interleaved image (16-byte texels) or, beyond
+    fspt_set_texture_interleave_budget, from single-layer images: none / one / all of the textured scene's materials
+    interleaved give the oracle's frame."""
+    import fspt_amd
+    from fspt_amd import scene as S
+    arrays = S.bunny_scene_textured(n=12, env_size=(128, 64), res=512)
+    W, H = 128, 80
+    fspt_amd.set_texture_interleave_budget(budget)
+    try:
+        pt = make_pt(arrays, W, H, camera, 4, "wavefront")
+    finally:
+        fspt_amd.set_texture_interleave_budget(8 << 30)
+    pt.clear()
+    pt.seed(21)
+    pt.render(2)
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(arrays, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4, 0, 2, 21, want)
+    assert np.array_equal(pt.readRadiance(), want)
+    pt.close()
+
+
 @pytest.mark.parametrize("pipeline,tail", [("wavefront", 0), ("wavefront", 1), ("megakernel", 0)])
 def test_more_layers_than_the_lds_table_holds(camera, pipeline, tail):
-    """520 quads of distinct flat colours and roughnesses -> more atlas layers than the 1 024 entries the shading kernels
+    """520 quads of distinct flat colours and roughnesses -> more material texture sets than the 256 the shading kernels
     stage in LDS: the kernels' global-table variants (k_wf_primary / k_wf_logic<..., false>) give the oracle's frame."""
     from fspt_amd import scene as S
     rng = np.random.default_rng(12)
