@@ -136,6 +136,7 @@ struct IntersectP {
 // fin[slot]: the finished sample colour, slot-major (a wave's finishing paths are neighbours).
 // ---------------------------------------------------------------------------
 constexpr int WF_MAX_BATCH = 128;
+constexpr int WF_HIT_TERMINAL = -2; // hit[k].index of an extension ray that hit something but whose path has no bounce left
 constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17, WF_FLAG_COLZERO = 1u << 18;
 #ifndef FSPT_WF_HEADS
 #define FSPT_WF_HEADS 16

@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   uint32_t c_rays = 0, c_steps = 0, c_leaves = 0;
   bool idle = true;
   bool is_shadow = false;
-  uint32_t path = 0;
+  uint32_t path = 0; // state index; bit 31: the path's bounce budget is used up (a hit of its extension ray will not be shaded)
   V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0), d_ext = v3(0, 0, 1);
   float t = MAX_T;
   int hit = -1, cur = REF_SENTINEL, sp = 0;
@@ -1058,7 +1058,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
         hit = -1;
         cur = S.root_ref;
         sp = 0;
-        path = k;
+        const bool live = (__float_as_uint(rd.w) & 255u) < p.num_bounces && ((__float_as_uint(rd.w) >> 8) & 255u) < (uint32_t)MAX_PATH_ITERS;
+        path = live ? k : (k | 0x80000000u);
         idle = false;
         if (COUNT) c_rays++;
       }
@@ -1131,7 +1132,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     // ---- finished rays: write the result; after the shadow ray comes the path's extension ray, then the lane is idle ----
     if (!idle && cur == REF_SENTINEL) {
       if (is_shadow) {
-        sti(p.shadow_hit + path, hit);
+        sti(p.shadow_hit + (path & 0x7fffffffu), hit);
         is_shadow = false;
         d = d_ext;
         inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -1141,7 +1142,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
         sp = 0;
         if (COUNT) c_rays++;
       } else {
-        st2(p.hit + path, make_float2(t, __int_as_float(hit)));
+        // index < -1 = hit, but the path ends here (tracer.fs:446 bound): the logic kernel classifies from this word alone
+        st2(p.hit + (path & 0x7fffffffu), make_float2(t, __int_as_float(hit != -1 && (path >> 31) ? WF_HIT_TERMINAL : hit)));
         idle = true;
       }
     }
@@ -1283,8 +1285,9 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
 
 // ---- logic: one S step for every live path of the round (rounds >= 2) ---------------------------
 // Input: the n paths of state set (round-1)&1 with the results of their rays.  Per block iteration (U*512 paths):
-//   1  classify from 8 bytes per path (hit index + flags): a path is shaded - and survives - iff its extension ray hit
-//      something and its bounce budget is not used up (tracer.fs:446,509); everything else finishes here.  The shaded
+//   1  classify from ONE word per path, the hit index (the trace kernel stores WF_HIT_TERMINAL for a hit whose path has
+//      no bounce left): a path is shaded - and survives - iff its extension ray hit something and its bounce budget is
+//      not used up (tracer.fs:446,509); everything else finishes here.  The shaded
 //      ones are listed in LDS, and ONE atomic reserves their consecutive output indices BEFORE any shading;
 //   2a every thread finishes its own non-shaded paths (NEE result, environment on a miss -> fin[slot]);
 //   2b the listed paths are shaded by consecutive threads - whole waves of shading work, instead of the 1-in-5 lanes
@@ -1325,9 +1328,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
       const uint32_t i = base + loc;
       bool shade = false;
       if (i < n_in) {
-        const int hidx = __float_as_int(ld2(p.hit + i).y);
-        const uint32_t flags = __float_as_uint(in.B[i].w);
-        shade = hidx != -1 && (flags & 255u) < p.num_bounces && ((flags >> 8) & 255u) < (uint32_t)MAX_PATH_ITERS;
+        shade = __float_as_int(ld2(p.hit + i).y) >= 0; // -1: miss; WF_HIT_TERMINAL: hit with the bounce budget used up
         if (!shade) own_fin |= 1u << u;
       }
       const unsigned long long m = __ballot(shade);
