@@ -789,17 +789,21 @@ static void wf_collect_counts(fspt_target *t, fspt_target::WfLane &ln) {
 //   staying in the wavefront: every further round is a trace launch + a logic launch at their latency floors;
 //   the tail kernel: one chain of dependent extension rays per remaining round, times how often its resident lane
 //   pairs (4 blocks/CU x 4 waves x 32 pairs) have to be re-filled to get through the n_r live paths.
-// Hand over at the first r with  n_r <= 0.62 * (last - r) * resident pairs.  The constant is fitted to hand-over scans
+// Hand over at the first r with  n_r <= 0.9 * (last - r) * resident pairs.  The constant is fitted to hand-over scans
 // on two scenes at 1920x1080 (profiles/r02/probe_tail_round_paired.log, probe_tail_round_c3.log): 70 k triangles:
 // 1 tick -> after round 2 (562 K paths, 7 rounds to go: 1.74 ms vs 1.93 after round 3), 20 ticks -> round 5, 128 ticks
-// -> never (all equal there); 1 M triangles, 20 ticks: round 6 (round 5, 386 K paths with 4 rounds to go, costs 3 %).
+// -> never (all equal there); 1 M triangles, 20 ticks: round 6 (round 5, 386 K paths with 4 rounds to go, costs 3 %);
+// re-scanned with the tail kernel at 4 waves/SIMD: 0.62 / 0.9 / 1.25 / 1.6 (profiles/r02/ab_tail_handover_coefficient.log).
+#ifndef FSPT_TAIL_COEF
+#define FSPT_TAIL_COEF 0.9
+#endif
 static uint32_t wf_tail_round(const fspt_target *t, uint64_t slots, uint32_t last) {
   if (t->tail_round == 0) return last + 1;
   if (t->tail_round > 0) return (uint32_t)t->tail_round;
   if (!t->live_known) return last + 1;
   const double pairs = (double)t->scene->num_cus * 4.0 * 4.0 * 32.0;
   for (uint32_t r = 1; r < last && r < 80; ++r)
-    if ((double)t->live_frac[r] * (double)slots <= 0.62 * (double)(last - r) * pairs) return r;
+    if ((double)t->live_frac[r] * (double)slots <= FSPT_TAIL_COEF * (double)(last - r) * pairs) return r;
   return last + 1;
 }
 
