@@ -54,6 +54,23 @@ def test_math_bitwise(op, name):
         assert np.array_equal(ref, a / b)
 
 
+@pytest.mark.parametrize("op,name", [(0, "sin"), (1, "cos"), (7, "rnd")])
+def test_trig_reduction_huge_arguments(op, name):
+    """The quadrant of the pi/2 reduction is taken from the low bits of an int32 while |k| < 2^31 and from the general
+    double-precision form beyond (|x| > 3.37e9, infinities, NaN): both sides of that switch equal the oracle."""
+    rng = np.random.default_rng(100 + op)
+    edge = 2147483648.0 * (np.pi / 2)
+    a = np.concatenate([edge + rng.uniform(-4e3, 4e3, 4096), -edge + rng.uniform(-4e3, 4e3, 4096),
+                        rng.choice([-1.0, 1.0], 8192) * 10 ** rng.uniform(8, 38.5, 8192),
+                        [np.inf, -np.inf, np.nan, 3.4028235e38, -3.4028235e38, 0.0, -0.0]]).astype(np.float32)
+    out = np.zeros(a.size, np.float32)
+    L.check(L.lib().fspt_math_eval(0, op, L.fptr(a), None, a.size, L.fptr(out)))
+    ref = O.math_eval(op, a, None)
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(out), nan)
+    assert np.array_equal(out[~nan].view(np.uint32), ref[~nan].view(np.uint32)), name
+
+
 @pytest.mark.parametrize("name", ["sin", "cos", "atan2", "asin", "exp2", "log2", "pow", "sqrt", "div"])
 def test_math_accuracy_vs_float64(name):
     """The DEVICE results against numpy float64, not against the oracle (tests/mathref.py): oracle_math.h and
