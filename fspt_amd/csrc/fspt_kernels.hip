@@ -971,6 +971,9 @@ FM_DEV uint32_t load_path(const WfSet &in, uint32_t k, Path &ps, const int *shad
 #ifndef WF_TRACE_WAVES
 #define WF_TRACE_WAVES 6
 #endif
+#ifndef WF_TRACE_RAY_ITEMS
+#define WF_TRACE_RAY_ITEMS 4u // x resident lanes: the last paths of a launch whose two rays are separate items
+#endif
 #ifndef WF_TRACE_FINE
 #define WF_TRACE_FINE 8u // the last 1/8 of a launch's paths are dealt out in 64-path chunks
 #endif
@@ -998,19 +1001,30 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     __syncthreads();
   }
 
+  // The LAST paths of a launch are dealt out as RAY items (item 2i = the extension ray of path i, item 2i + 1 = its NEE
+  // shadow ray, empty when it has none): a launch ends on the dependent chain of its longest-running item, and a path
+  // item is two rays one after the other.  Split, the two rays of the late paths run side by side on two lanes (any two:
+  // their results go to hit[] and shadow_hit[] independently), and the launch ends after ONE long ray, not two.  Small
+  // launches consist of ray items only.  (Costs a second state fetch per split path; WF_TRACE_RAY_ITEMS x the resident lanes.)
+  const uint32_t split_paths = min(total, (uint32_t)WF_TRACE_RAY_ITEMS * n_waves * (uint32_t)WAVE);
+  const uint32_t path_items = total - split_paths; // paths [0, path_items): one item per path
   // pool chunk: large while paths are plentiful (few atomics), one wave-load when they are scarce
   // (late rounds), so that every resident wave gets work
   uint32_t chunk = (total / (n_waves * 4u)) & ~63u;
   chunk = chunk < 64u ? 64u : (chunk > WF_TRACE_CHUNK ? WF_TRACE_CHUNK : chunk);
-  // Two chunk sizes: the first (1 - 1/WF_TRACE_FINE) of the paths in chunks of `chunk`, the rest in chunks of 64 - the
-  // chunks are handed out in order, so the launch ends on fine-grained work: the imbalance at the end of a launch is one
-  // chunk's worth of time (512 paths on one wave = 8 per lane, ~300 us) unless the last chunks are small.
-  const uint32_t big_paths = chunk > 64u ? ((total - total / WF_TRACE_FINE) / chunk) * chunk : 0u;
+  // Three kinds of chunk, handed out in this order: the first (1 - 1/WF_TRACE_FINE) of the path items in chunks of
+  // `chunk`, the rest of them in chunks of 64, then the ray items in chunks of 64 - the launch ends on fine-grained work:
+  // the imbalance at its end is one chunk's worth of time (512 paths on one wave = 8 per lane, ~300 us) unless the last
+  // chunks are small.
+  const uint32_t big_paths = chunk > 64u ? ((path_items - path_items / WF_TRACE_FINE) / chunk) * chunk : 0u;
   const uint32_t n_big = chunk > 64u ? big_paths / chunk : 0u;
-  const uint32_t n_chunks = n_big + (total - big_paths + 63u) / 64u;
+  const uint32_t n_fine = (path_items - big_paths + 63u) / 64u;
+  const uint32_t item_end = path_items + 2u * split_paths; // items [path_items, item_end): ray items
+  const uint32_t n_chunks = n_big + n_fine + (2u * split_paths + 63u) / 64u;
   auto chunk_range = [&](uint32_t c, uint32_t &lo, uint32_t &hi) {
     if (c < n_big) { lo = c * chunk; hi = lo + chunk; }
-    else { lo = big_paths + (c - n_big) * 64u; hi = min(lo + 64u, total); }
+    else if (c < n_big + n_fine) { lo = big_paths + (c - n_big) * 64u; hi = min(lo + 64u, path_items); }
+    else { lo = path_items + (c - n_big - n_fine) * 64u; hi = min(lo + 64u, item_end); }
   };
   const uint32_t wave_id = blockIdx.x * WAVES_PER_BLOCK + wave;
   const uint32_t stripe = wave_id % WF_HEADS;
@@ -1021,7 +1035,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   uint32_t c_rays = 0, c_steps = 0, c_leaves = 0;
   bool idle = true;
   bool is_shadow = false;
-  uint32_t path = 0; // state index; bit 31: the path's bounce budget is used up (a hit of its extension ray will not be shaded)
+  // state index of the lane's path; bit 31: the path's bounce budget is used up (a hit of its extension ray will not be
+  // shaded); bits 29-30: what the item covers - 0 both rays, 1 the extension ray, 2 the shadow ray, 3 nothing (the shadow
+  // item of a path without one; the lane still goes through the finish step below)
+  uint32_t path = 0;
   V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0), d_ext = v3(0, 0, 1);
   float t = MAX_T;
   int hit = -1, cur = REF_SENTINEL, sp = 0;
@@ -1046,22 +1063,29 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
       uint32_t want = (uint32_t)__popcll(need);
       uint32_t take = want < avail ? want : avail;
       if (idle && rank < take) {
-        const uint32_t k = pool_next + rank;
+        uint32_t k = pool_next + rank, mode = 0u;
+        if (k >= path_items) { // ray item
+          const uint32_t j = k - path_items;
+          k = path_items + (j >> 1);
+          mode = 1u + (j & 1u);
+        }
         const float4 ro = ld4(st.A + k), rd = ld4(st.B + k);
         const float4 sd = ld4(st.D + k); // fetched alongside (only meaningful when the path has a shadow ray)
         o = v3(ro.x, ro.y, ro.z);
         d_ext = v3(rd.x, rd.y, rd.z);
-        is_shadow = (__float_as_uint(rd.w) & WF_FLAG_SHADOW) != 0u;
+        const bool has_shadow = (__float_as_uint(rd.w) & WF_FLAG_SHADOW) != 0u;
+        if (mode == 2u && !has_shadow) mode = 3u;
+        is_shadow = has_shadow && mode != 1u;
         d = is_shadow ? v3(sd.x, sd.y, sd.z) : d_ext;
         inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         t = MAX_T;
         hit = -1;
-        cur = S.root_ref;
+        cur = mode == 3u ? REF_SENTINEL : S.root_ref;
         sp = 0;
         const bool live = (__float_as_uint(rd.w) & 255u) < p.num_bounces && ((__float_as_uint(rd.w) >> 8) & 255u) < (uint32_t)MAX_PATH_ITERS;
-        path = live ? k : (k | 0x80000000u);
+        path = k | (mode << 29) | (live ? 0u : 0x80000000u);
         idle = false;
-        if (COUNT) c_rays++;
+        if (COUNT && mode != 3u) c_rays++;
       }
       pool_next += take;
     }
@@ -1129,21 +1153,28 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
       // work counters equal the oracle's (the algorithmic work of the reference algorithm).
       if (ANYHIT && is_shadow && hit != -1) cur = REF_SENTINEL;
     }
-    // ---- finished rays: write the result; after the shadow ray comes the path's extension ray, then the lane is idle ----
+    // ---- finished rays: write the result; after the shadow ray of a path item comes its extension ray, then the lane is idle ----
     if (!idle && cur == REF_SENTINEL) {
-      if (is_shadow) {
-        sti(p.shadow_hit + (path & 0x7fffffffu), hit);
-        is_shadow = false;
-        d = d_ext;
-        inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        t = MAX_T;
-        hit = -1;
-        cur = S.root_ref;
-        sp = 0;
-        if (COUNT) c_rays++;
+      const uint32_t k = path & 0x1fffffffu, mode = (path >> 29) & 3u;
+      if (mode == 3u) {
+        idle = true; // empty item
+      } else if (is_shadow) {
+        sti(p.shadow_hit + k, hit);
+        if (mode == 2u) {
+          idle = true; // the extension ray is another lane's item
+        } else {
+          is_shadow = false;
+          d = d_ext;
+          inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          t = MAX_T;
+          hit = -1;
+          cur = S.root_ref;
+          sp = 0;
+          if (COUNT) c_rays++;
+        }
       } else {
         // index < -1 = hit, but the path ends here (tracer.fs:446 bound): the logic kernel classifies from this word alone
-        st2(p.hit + (path & 0x7fffffffu), make_float2(t, __int_as_float(hit != -1 && (path >> 31) ? WF_HIT_TERMINAL : hit)));
+        st2(p.hit + k, make_float2(t, __int_as_float(hit != -1 && (path >> 31) ? WF_HIT_TERMINAL : hit)));
         idle = true;
       }
     }
