@@ -34,7 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4  # 614.4 G wave64 VALU instructions per second
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2  # 1 228.8 G wave64 VALU instructions per second: CDNA4's SIMDs are 32 lanes wide, a
+                                      # wave64 instruction issues over 2 cycles (MI355X_MICROARCH.md 'Wave scheduling')
 L1_GATHER_PEAK_GBS = 19000.0  # measured: coalesced dwordx4 loads from L1/L2, all CUs (profiles/r01/l1_pipe.json);
                               # divergent per-lane 64-byte records reach 13 800
 
@@ -399,9 +400,9 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
             num = kj["traffic_GBps"] if (bound == "hbm" and kj["traffic_GBps"] is not None) else gbps
             kj["frac"] = round(num / peak, 4)
             kernels[k] = kj
-        # What the pipeline as a whole runs against: the chip's VALU issue rate.  Wave-instructions per sample of every
-        # kernel class (SQ_INSTS_VALU, same stamped profile) x samples/s against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
-        # per wave64 instruction (the non-packed FP32 vector rate, half of the guide's 157.3 TFLOP/s packed figure).
+        # The pipeline's instruction work against the chip's VALU issue rate.  Wave-instructions per sample of every
+        # kernel class (SQ_INSTS_VALU, same stamped profile) x samples/s against 256 CUs x 4 SIMD-32s x 2.4 GHz / 2 cycles
+        # per wave64 instruction (= the guide's 157.3 TFLOP/s FP32 vector peak; ONE wave sustains one per 4 cycles).
         valu = None
         if prof and all("valu_wave_instr_per_sample" in v for v in prof["kernels"].values()):
             wips = sum(v["valu_wave_instr_per_sample"] for v in prof["kernels"].values())
