@@ -480,7 +480,22 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   }
   if (e == hipSuccess && desc->env) {
     std::vector<uint32_t> tiled;
+#if FSPT_ENV_APRON
+    // overlapping 8 x 4-texel tiles: tile (a, b) = texels [7a, 7a + 8) x [3b, 3b + 4), REPEAT in s, CLAMP in t (main.js:174-178)
+    const uint32_t w = desc->env_w, h = desc->env_h, tx = (w + 6u) / 7u, ty = (h + 2u) / 3u;
+    tiled.assign((size_t)tx * ty * 32u, 0u);
+    for (uint32_t b = 0; b < ty; ++b)
+      for (uint32_t a = 0; a < tx; ++a)
+        for (uint32_t lb = 0; lb < 4; ++lb)
+          for (uint32_t la = 0; la < 8; ++la) {
+            const uint32_t i = (7u * a + la) % w;
+            uint32_t j = 3u * b + lb;
+            if (j > h - 1u) j = h - 1u;
+            std::memcpy(&tiled[((size_t)b * tx + a) * 32u + lb * 8u + la], desc->env + ((size_t)j * w + i) * 4, 4);
+          }
+#else
     tile_image(desc->env, desc->env_w, desc->env_h, tiled);
+#endif
     e = upload(&s->env, tiled.data(), tiled.size() * 4);
   }
   if (e == hipSuccess) e = upload(&s->bins, desc->bins, (size_t)desc->n_bins * 16);

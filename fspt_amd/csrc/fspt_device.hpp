@@ -26,6 +26,9 @@ constexpr int MAX_PATH_ITERS = 64;       // cap on tracer.fs:488's unbounded i--
 constexpr int TEX_TILE_W_LOG2 = FSPT_TEX_TILE_W_LOG2, TEX_TILE_H_LOG2 = FSPT_TEX_TILE_H_LOG2; // 0, 0 = plain row-major (A/B)
 constexpr int TEX_TILE_W = 1 << TEX_TILE_W_LOG2, TEX_TILE_H = 1 << TEX_TILE_H_LOG2;
 
+#ifndef FSPT_ENV_APRON
+#define FSPT_ENV_APRON 1 // the environment map in overlapping tiles (fspt_kernels.hip env_taps); 0: disjoint tiles (A/B)
+#endif
 constexpr uint32_t LAYER_CONST = 0xFFFFFFFFu;
 // Material texture set (3 x uint4 per set, DScene::tex_sets; a triangle's hit record names its set): the four atlas
 // layers a shading event samples at one uv (tracer.fs:453-456: diffuse, emissive, metallic-roughness, normal), resolved
