@@ -875,7 +875,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 #define WF_LOGIC_U 8
 #endif
 #ifndef WF_PRIMARY_U
-#define WF_PRIMARY_U 2 // measured (r01): U = 1 / 2 / 4 / 8 -> 0.327 / 0.320 / 0.331 / 0.357 ms per tick (spills grow with U)
+#define WF_PRIMARY_U 1 // paths per thread and block iteration.  r01: U = 1 / 2 / 4 / 8 -> 0.327 / 0.320 / 0.331 / 0.357 ms per tick;
+                       // re-measured on this round's kernel: 1 / 2 / 4 -> 15.0 / 15.4 / 16.9 ms per 128 ticks (U = 1 is the
+                       // only one without register spills at 4 waves/SIMD; profiles/r02/ab_primary_paths_per_thread.log).
+                       // (The top of the tree in LDS, as in k_wf_trace, makes this launch 10 % SLOWER: its rays are coherent,
+                       // their node fetches hit L1 anyway; profiles/r02/ab_primary_lds_top.log)
 #endif
 
 // Path state is streamed (touched once per round).  FSPT_NT=1 builds the non-temporal variant for A/B
