@@ -16,13 +16,26 @@ out = {"source_sha": bench.source_sha(),
               " (MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B)", "workloads": {}}
 
 
+def newest(paths):
+    """gpurun merges a session's files into directories that may still hold an older session's: keep, per directory,
+    the files written within a minute of its newest one."""
+    by_dir = collections.defaultdict(list)
+    for f in paths:
+        by_dir[os.path.dirname(f)].append(f)
+    out = []
+    for d, fs in by_dir.items():
+        t = max(os.path.getmtime(f) for f in fs)
+        out += [f for f in fs if t - os.path.getmtime(f) < 60]
+    return sorted(out)
+
+
 def kname(n):
     m = re.search(r"(k_wf_\w+|k_trace)(<[^>]*>)?", n)
     return m.group(0) if m else None
 
 
 for tag, wl in pairs:
-    ks = glob.glob(f"{G}/{tag}_kt/**/*kernel_stats.csv", recursive=True)
+    ks = newest(glob.glob(f"{G}/{tag}_kt/**/*kernel_stats.csv", recursive=True))
     if ks:
         shutil.copy(ks[0], os.path.join(P, f"{tag}_kernel_stats.csv"))
     log = f"{G}/{tag}_kt.log"
@@ -37,7 +50,7 @@ for tag, wl in pairs:
     res = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         agg = collections.defaultdict(list)
-        for f in glob.glob(f"{G}/{tag}_{c}/**/*counter_collection.csv", recursive=True):
+        for f in newest(glob.glob(f"{G}/{tag}_{c}/**/*counter_collection.csv", recursive=True)):
             for r in csv.DictReader(open(f)):
                 k = kname(r["Kernel_Name"])
                 if k and r["Counter_Name"] == c:
@@ -54,7 +67,7 @@ for tag, wl in pairs:
     out["workloads"][wl] = {"samples_per_batch": samples, "kernels": kern}
     # SQ / TA / TD summaries
     agg = collections.OrderedDict()
-    for f in sorted(glob.glob(f"{G}/{tag}_sq*/**/*counter_collection.csv", recursive=True)):
+    for f in newest(glob.glob(f"{G}/{tag}_sq*/**/*counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(f)):
             k = kname(r["Kernel_Name"])
             if k and "<true" not in k:
