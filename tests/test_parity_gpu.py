@@ -479,6 +479,23 @@ def test_textured_bunny_scene_bitwise(camera, pipeline, tail):
     pt.close()
 
 
+@pytest.mark.parametrize("env_size", [(1, 1), (2, 3), (7, 3), (8, 4), (13, 5), (29, 17), (100, 37)])
+def test_environment_map_sizes_around_the_tile_grid(camera, env_size):
+    """The environment map is stored in overlapping 8 x 4-texel tiles (7 x 3 new texels each, columns wrapped, rows
+    clamped): widths and heights below, at and across the tile grid - incl. a single texel - give the oracle's frame."""
+    from fspt_amd import scene as S
+    arrays = S.bunny_scene(n=6, env_size=env_size)
+    W, H = 96, 64
+    pt = make_pt(arrays, W, H, camera, 3, "wavefront")
+    pt.clear()
+    pt.seed(5)
+    pt.render(2)
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(arrays, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 3, 0, 2, 5, want)
+    assert np.array_equal(pt.readRadiance(), want)
+    pt.close()
+
+
 @pytest.mark.parametrize("budget", [0, 512 * 512 * 16, 3 * 512 * 512 * 16])
 def test_textured_scene_any_interleave_budget(camera, budget):
     """The image layers of a material are fetched from one interleaved image (16-byte texels) or, beyond
