@@ -554,6 +554,7 @@ static const uint32_t WF_ROUNDS_MAX = fspt::MAX_PATH_ITERS + 4;
 static const uint32_t EV_PAIRS = 4096;
 static const size_t WF_HEADS_BYTES = (size_t)(WF_ROUNDS_MAX + 2) * fspt::WF_HEADS * fspt::WF_HEAD_STRIDE * sizeof(uint32_t);
 static const uint64_t WF_SLOT_BUDGET = 448ull << 20; // path slots, 220 B each (up to 103 GB of the 288 GB HBM: a 4K frame x 56 ticks)
+static_assert(WF_SLOT_BUDGET < (1ull << 29), "k_wf_trace keeps a path's state index in 29 bits");
 
 int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **out) {
   if (!scene || !out || W == 0 || H == 0) { fspt_set_error("fspt_target_create: bad argument"); return FSPT_E_INVALID; }
@@ -763,7 +764,10 @@ static int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ti
   uint32_t lanes_max = t->n_lanes;
   while (true) {
     wf_plan(t, work_total, n_ticks, lanes_max, n_lanes, per_lane);
-    if ((uint64_t)per_lane * work_total > 0xFFFFFFF0ull) { fspt_set_error("frame too large for the wavefront pipeline"); return FSPT_E_INVALID; }
+    // the trace kernel carries a path's state index in 29 bits (fspt_kernels.hip k_wf_trace: item kind and the
+    // no-bounce-left flag share the word); WF_SLOT_BUDGET keeps every batch below that, a single tick of a frame beyond
+    // 2^29 pixels does not fit
+    if ((uint64_t)per_lane * work_total > 0x1FFFFFFFull) { fspt_set_error("frame too large for the wavefront pipeline (more than 2^29 paths per batch)"); return FSPT_E_INVALID; }
     const uint64_t budget = t->mem_limit ? t->mem_limit / wf_slot_bytes() / n_lanes : ~0ull;
     int rc = FSPT_OK;
     for (uint32_t l = 0; l < n_lanes && rc == FSPT_OK; ++l) rc = wf_ensure(t, t->lanes[l], (uint32_t)(per_lane * work_total), budget);
