@@ -386,5 +386,8 @@ class MultiPathTracer {
   close() { if (this._multi) { addon.multiDestroy(this._multi); this._multi = null; } }
 }
 
-module.exports = { addon, MultiPathTracer, TexturePacker, getMaterial, parseMaterials, mergeSceneProps, resampleImage, packReferenceScene, buildScene,
+// memory later scenes may spend on interleaved material textures (fspt_set_texture_interleave_budget; results do not depend on it)
+function setTextureInterleaveBudget(bytes) { addon.setTextureInterleaveBudget(bytes); }
+
+module.exports = { addon, setTextureInterleaveBudget, MultiPathTracer, TexturePacker, getMaterial, parseMaterials, mergeSceneProps, resampleImage, packReferenceScene, buildScene,
   PathTracer, saveBlob, loadBlob };
