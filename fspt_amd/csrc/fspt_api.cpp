@@ -411,7 +411,6 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     std::vector<int64_t> layer_base(n_layers, -1);            // single-layer image of a layer, in tiles (-1: not stored)
     std::vector<uint32_t> single;                              // the single-layer images, tiled
     std::vector<uint32_t> tiled;
-    const size_t single_tiles = tile_image(nullptr, res, res, tiled) / (fspt::TEX_TILE_W * fspt::TEX_TILE_H);
     uint64_t quad_bytes = 0;
     uint32_t n_quad = 0;
     for (uint32_t si = 0; si < n_sets; ++si) {
@@ -442,7 +441,6 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
         single.insert(single.end(), tiled.begin(), tiled.end());
       }
     }
-    (void)single_tiles;
     if (single.size() / (fspt::TEX_TILE_W * fspt::TEX_TILE_H) >= 0xFFFFFFFFull) {
       fspt_set_error("atlas too large: %zu texels of image layers", single.size());
       fspt_scene_destroy(s);

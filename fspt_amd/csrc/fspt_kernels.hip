@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 }
 
 // LDS-staged tables of the shading kernels: the small read-only tables every shading event gathers from - the
-// atlas layer table (the texel of every flat-colour layer), the environment's importance bins and the batch's randBase values - are
+// material texture sets (fspt_device.hpp), the environment's importance bins and the batch's randBase values - are
 // staged in LDS once per block, so those gathers go through the LDS pipeline instead of the vector-memory pipeline.
 #ifndef WF_LDS_SETS
 #define WF_LDS_SETS 256 // material texture sets (48 B each) staged in LDS
