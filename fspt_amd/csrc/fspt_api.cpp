@@ -551,7 +551,7 @@ static const uint32_t WORK_RING = 4096;
 static const uint32_t WF_ROUNDS_MAX = fspt::MAX_PATH_ITERS + 4;
 static const uint32_t EV_PAIRS = 4096;
 static const size_t WF_HEADS_BYTES = (size_t)(WF_ROUNDS_MAX + 2) * fspt::WF_HEADS * fspt::WF_HEAD_STRIDE * sizeof(uint32_t);
-static const uint64_t WF_SLOT_BUDGET = 448ull << 20; // path slots, 220 B each (up to 103 GB of the 288 GB HBM: a 4K frame x 56 ticks)
+static const uint64_t WF_SLOT_BUDGET = 448ull << 20; // path slots, 216 B each (up to 101 GB of the 288 GB HBM: a 4K frame x 56 ticks)
 static_assert(WF_SLOT_BUDGET < (1ull << 29), "k_wf_trace keeps a path's state index in 29 bits");
 
 int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **out) {
@@ -692,8 +692,8 @@ static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
 }
 
 // bytes per path slot of every path-state array (fspt_device.hpp: WfP)
-// two state sets of A B C E D P (float4) | hit (float2) | shadow_hit (int) | fin (float4)   = 220 bytes per slot
-static const size_t WF_ARRAY_BYTES[WF_ARRAYS] = {16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 8, 4, 16};
+// two state sets of A B C E D P (float4) | hit (float2) | shadow_hit (int) | fin (3 floats)   = 216 bytes per slot
+static const size_t WF_ARRAY_BYTES[WF_ARRAYS] = {16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 8, 4, 12};
 static size_t wf_slot_bytes() {
   size_t b = 0;
   for (size_t x : WF_ARRAY_BYTES) b += x;
@@ -878,7 +878,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
       ws.E = (float4 *)ln.mem[6 * k + 3]; ws.D = (float4 *)ln.mem[6 * k + 4]; ws.P = (float4 *)ln.mem[6 * k + 5];
     }
     p.hit = (float2 *)ln.mem[12]; p.shadow_hit = (int *)ln.mem[13];
-    p.fin = (float4 *)ln.mem[14];
+    p.fin = (float *)ln.mem[14];
     p.counts = ln.counts;
     p.heads = ln.heads;
     uint32_t nbt = n_ticks - done < batch ? n_ticks - done : batch;

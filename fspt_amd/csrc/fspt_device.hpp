@@ -166,7 +166,7 @@ struct WfP {
   uint32_t lds_top; // top-of-tree nodes k_wf_trace keeps in LDS (<= scene.n_top; set by launch_wf)
   DScene scene;
   WfSet set[2];
-  float4 *fin; // finished sample colours [slot]
+  float *fin;  // finished sample colours [slot][3]
   float2 *hit;
   int *shadow_hit;
   WfCounts *counts;

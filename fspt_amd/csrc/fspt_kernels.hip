@@ -921,6 +921,16 @@ FM_DEV void st2(float2 *p, float2 v) {
   *p = v;
 #endif
 }
+// 12-byte (RGB) elements of the finished-sample array: dword-aligned three-dword accesses
+typedef float nt_f3 __attribute__((ext_vector_type(3), aligned(4)));
+FM_DEV void st3(float *p, V3 v) {
+  nt_f3 w = {v.x, v.y, v.z};
+  *reinterpret_cast<nt_f3 *>(p) = w;
+}
+FM_DEV V3 ld3(const float *p) {
+  const nt_f3 v = *reinterpret_cast<const nt_f3 *>(p);
+  return v3(v.x, v.y, v.z);
+}
 FM_DEV int ldi(const int *p) {
 #if FSPT_NT
   return __builtin_nontemporal_load(p);
@@ -1338,7 +1348,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
       const uint32_t j = i % p.n_batch;
       const bool finished = advance_path<COUNT>(S, ps, -1, t_u[u], hit_u[u], LDSTAB ? s_rb[j] : p.rb_trace[j], p.env_theta,
                                                 p.num_bounces, cnt);
-      if (finished) st4(p.fin + i, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
+      if (finished) st3(p.fin + 3 * (size_t)i, ps.color);
       else store_path(out, s_base + s_cnt[u][wave] + lane_rank(m_surv[u]), ps, i);
     }
     __syncthreads();
@@ -1436,7 +1446,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
         const uint32_t j = slot % p.n_batch;
         const bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), LDSTAB ? s_rb[j] : p.rb_trace[j],
                                                   p.env_theta, p.num_bounces, cnt);
-        if (finished) st4(p.fin + slot, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
+        if (finished) st3(p.fin + 3 * (size_t)slot, ps.color);
         else store_path(out, k_out, ps, slot);
       }
     }
@@ -1581,7 +1591,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
     // ---- S: consume them ----
     if (m_live) {
       if (advance_path<COUNT>(S, ps, hitA, tR, hitR, p.rb_trace[slot % p.n_batch], p.env_theta, p.num_bounces, cnt)) {
-        st4(p.fin + slot, make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f));
+        st3(p.fin + 3 * (size_t)slot, ps.color);
         ps.pix = -1;
       }
     }
@@ -1612,7 +1622,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
         const uint32_t pp = (uint32_t)q * (WAVE / WF_RESOLVE_TICKS) + ((uint32_t)lane / WF_RESOLVE_TICKS);
         const uint32_t w2 = w0 + pp;
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (w2 < p.work_total && tt < p.n_batch) v = ld4(p.fin + (size_t)w2 * p.n_batch + tt);
+        if (w2 < p.work_total && tt < p.n_batch) { const V3 c = ld3(p.fin + 3 * ((size_t)w2 * p.n_batch + tt)); v = make_float4(c.x, c.y, c.z, 0.0f); }
         s_t[wave][pp * (WF_RESOLVE_TICKS + 1) + ((uint32_t)lane & (WF_RESOLVE_TICKS - 1))] = v;
       }
       __syncthreads();

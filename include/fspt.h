@@ -197,7 +197,7 @@ int fspt_target_set_viewport(fspt_target *target, uint32_t w, uint32_t h);
  *   pipeline 2 "wavefront, two lanes": pipeline 1 with the batch split in two halves that run
  *              concurrently on two HIP streams (separate path state, resolves chained in tick order). */
 int fspt_target_set_pipeline(fspt_target *target, int pipeline, uint32_t batch_ticks);
-/* Wavefront path state lives in device memory: 220 bytes per (pixel, tick) of a batch.  It is sized for the largest
+/* Wavefront path state lives in device memory: 216 bytes per (pixel, tick) of a batch.  It is sized for the largest
  * n_ticks any call on this target has asked for so far (at most batch_ticks; fspt_trace = 1 tick = 0.46 GB at
  * 1920x1080, a 128-tick fspt_render = 58 GB) and grows when a longer call arrives.  fspt_target_set_memory_limit caps
  * it (bytes; 0 = no cap): a batch that does not fit the cap - or the free device memory - is halved until it does,
