@@ -88,6 +88,7 @@ SIGNATURES = {
     "fspt_target_set_shard": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32]),
     "fspt_target_bind_accumulator": (C.c_int, [_VP, _VP]),
     "fspt_target_accumulator": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "fspt_target_size": (C.c_int, [_VP, _U32, _U32]),
     "fspt_camera": (C.c_int, [_VP, _F, _F, C.c_float, _F, C.c_float]),
     "fspt_set_rays": (C.c_int, [_VP, _F, _F]),
     "fspt_read_rays": (C.c_int, [_VP, _F, _F]),
@@ -125,6 +126,8 @@ SIGNATURES = {
     "fspt_multi_read_radiance": (C.c_int, [_VP, _F]),
     "fspt_multi_draw": (C.c_int, [_VP, C.c_float, C.c_float, C.c_int, C.c_float, C.POINTER(C.c_uint8)]),
     "fspt_multi_last_gather_bytes": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    "fspt_multi_size": (C.c_int, [_VP, _U32, _U32]),
+    "fspt_multi_peer_access": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_int)]),
     "fspt_builder_create": (C.c_int, [C.POINTER(_VP)]),
     "fspt_builder_destroy": (C.c_int, [_VP]),
     "fspt_builder_add_obj": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(PropDesc)]),

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <map>
 #include <string>
@@ -113,7 +114,7 @@ struct fspt_target {
 // Returns the number of texels of the tiled image; with src == nullptr only that.
 // Bytes of interleaved four-layer texture images (TEXSET_QUAD) a scene may allocate; sets beyond it fetch their image
 // layers from single-layer images (fspt_set_texture_interleave_budget).
-static uint64_t g_texset_budget = 8ull << 30;
+static std::atomic<uint64_t> g_texset_budget{8ull << 30};
 
 static size_t tile_image(const uint8_t *src, uint32_t w, uint32_t h, std::vector<uint32_t> &out) {
   const uint32_t tx = (w + fspt::TEX_TILE_W - 1) / fspt::TEX_TILE_W, ty = (h + fspt::TEX_TILE_H - 1) / fspt::TEX_TILE_H;
@@ -591,8 +592,11 @@ int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **
 
 int fspt_target_destroy(fspt_target *t) {
   if (!t) return FSPT_OK;
-  t->pending.clear(); // recorded ticks nobody can observe any more
   hipSetDevice(t->scene->device);
+  // recorded ticks: with the library's own accumulator nobody can observe them any more; a caller-owned accumulator
+  // (fspt_target_bind_accumulator) outlives the target, so they are executed
+  if (t->accum != t->accum_own && t->accum_own) (void)flush_pending(t);
+  t->pending.clear();
   if (t->stream) hipStreamSynchronize(t->stream);
   hipFree(t->accum_own); hipFree(t->ray_pos); hipFree(t->ray_dir); hipFree(t->work_counters); hipFree(t->counters);
   for (auto &ln : t->lanes) {
@@ -626,6 +630,12 @@ int fspt_target_bind_accumulator(fspt_target *t, void *device_ptr) {
   if (!t) { fspt_set_error("fspt_target_bind_accumulator: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
   t->accum = device_ptr ? (float4 *)device_ptr : t->accum_own;
+  return FSPT_OK;
+}
+
+int fspt_target_size(fspt_target *t, uint32_t *W, uint32_t *H) {
+  if (!t || !W || !H) { fspt_set_error("fspt_target_size: NULL argument"); return FSPT_E_INVALID; }
+  *W = t->W; *H = t->H;
   return FSPT_OK;
 }
 
@@ -1259,6 +1269,7 @@ struct fspt_multi {
   std::vector<float4 *> packed;   // per target: its own pixels in work-index order (on its device)
   std::vector<float4 *> staging;  // per target: the same, on devices[0]
   std::vector<hipEvent_t> arrived;
+  std::vector<int> peer_direct;   // per target: bit 0 = its device can write devices[0]'s memory directly, bit 1 = the reverse
   uint64_t gather_bytes = 0;
 };
 
@@ -1292,7 +1303,7 @@ int fspt_multi_create(const fspt_scene_desc *desc, const int *devices, uint32_t 
   fspt_multi *m = new fspt_multi();
   m->W = W; m->H = H;
   m->devices.assign(devices, devices + n_devices);
-  m->packed.assign(n_devices, nullptr); m->staging.assign(n_devices, nullptr); m->arrived.assign(n_devices, nullptr);
+  m->packed.assign(n_devices, nullptr); m->staging.assign(n_devices, nullptr); m->arrived.assign(n_devices, nullptr); m->peer_direct.assign(n_devices, 3);
   int rc = FSPT_OK;
   for (uint32_t i = 0; i < n_devices && rc == FSPT_OK; ++i) {
     // one scene copy per DISTINCT device (a device listed twice shares it)
@@ -1312,12 +1323,17 @@ int fspt_multi_create(const fspt_scene_desc *desc, const int *devices, uint32_t 
       if (e == hipSuccess) e = hipSetDevice(devices[0]);
       if (e == hipSuccess) e = hipMalloc((void **)&m->staging[i], bytes ? bytes : 16);
       if (e == hipSuccess && devices[i] != devices[0]) {
-        // direct xGMI copies when the devices can reach each other; hipMemcpyPeerAsync stages through the host otherwise
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can) {
-          hipError_t pe = hipDeviceEnablePeerAccess(devices[i], 0);
-          if (pe != hipSuccess) (void)hipGetLastError(); // already enabled
-        }
+        // The gather copy is issued on the SENDING device's stream and writes devices[0]'s memory (multi_gather), so
+        // the mapping that matters is devices[i] -> devices[0]; the reverse one is enabled too (hipMemcpyPeerAsync may
+        // pick either end's copy engine).  Without peer access the copy still works, staged through the host.
+        int can_out = 0, can_in = 0;
+        (void)hipDeviceCanAccessPeer(&can_out, devices[i], devices[0]);
+        (void)hipDeviceCanAccessPeer(&can_in, devices[0], devices[i]);
+        if (can_out && hipSetDevice(devices[i]) == hipSuccess && hipDeviceEnablePeerAccess(devices[0], 0) != hipSuccess) (void)hipGetLastError(); // already enabled
+        if (can_in && hipSetDevice(devices[0]) == hipSuccess && hipDeviceEnablePeerAccess(devices[i], 0) != hipSuccess) (void)hipGetLastError();
+        m->peer_direct[i] = (can_out ? 1 : 0) | (can_in ? 2 : 0);
+      } else if (e == hipSuccess) {
+        m->peer_direct[i] = 3; // the same device
       }
       if (e != hipSuccess) { fspt_set_error("fspt_multi_create: %s", hipGetErrorString(e)); rc = FSPT_E_HIP; }
     }
@@ -1394,6 +1410,18 @@ int fspt_multi_draw(fspt_multi *m, float exposure, float saturation, int denoise
   int rc = multi_gather(m);
   if (rc) return rc;
   return fspt_draw(m->targets[0], exposure, saturation, denoise, max_sigma, out_rgba8);
+}
+
+int fspt_multi_size(fspt_multi *m, uint32_t *W, uint32_t *H) {
+  if (!m || !W || !H) { fspt_set_error("fspt_multi_size: NULL argument"); return FSPT_E_INVALID; }
+  *W = m->W; *H = m->H;
+  return FSPT_OK;
+}
+
+int fspt_multi_peer_access(fspt_multi *m, uint32_t i, int *mask) {
+  if (!m || !mask || i >= m->targets.size()) { fspt_set_error("fspt_multi_peer_access: bad argument"); return FSPT_E_INVALID; }
+  *mask = m->peer_direct[i];
+  return FSPT_OK;
 }
 
 int fspt_multi_last_gather_bytes(fspt_multi *m, uint64_t *bytes) {

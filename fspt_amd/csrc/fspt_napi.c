@@ -429,9 +429,28 @@ static napi_value MultiSync(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_multi_sync((fspt_multi *)h));
   return undefined(env);
 }
+/* The library writes W*H*4 elements into the caller's TypedArray: a shorter one is a heap overflow. */
+static int check_frame_len(napi_env env, size_t n, uint32_t W, uint32_t H) {
+  if (n == (size_t)W * H * 4u) return 0;
+  char msg[160];
+  snprintf(msg, sizeof msg, "fspt_napi: array of %zu elements, the %ux%u frame needs %zu", n, W, H, (size_t)W * H * 4u);
+  napi_throw_range_error(env, NULL, msg);
+  return 1;
+}
+static int check_target_len(napi_env env, void *h, size_t n) {
+  uint32_t W = 0, H = 0;
+  if (fspt_target_size((fspt_target *)h, &W, &H) != FSPT_OK) { napi_throw_error(env, NULL, fspt_last_error()); return 1; }
+  return check_frame_len(env, n, W, H);
+}
+static int check_multi_len(napi_env env, void *h, size_t n) {
+  uint32_t W = 0, H = 0;
+  if (fspt_multi_size((fspt_multi *)h, &W, &H) != FSPT_OK) { napi_throw_error(env, NULL, fspt_last_error()); return 1; }
+  return check_frame_len(env, n, W, H);
+}
 static napi_value MultiReadRadiance(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h, *p; size_t n;
   if (get_args(env, info, 2, a) || unwrap(env, a[0], &h) || typed(env, a[1], napi_float32_array, 0, &p, &n)) return NULL;
+  if (check_multi_len(env, h, n)) return NULL;
   FSPT_OK_OR_THROW(fspt_multi_read_radiance((fspt_multi *)h, (float *)p));
   return a[1];
 }
@@ -441,6 +460,7 @@ static napi_value MultiDraw(napi_env env, napi_callback_info info) {
   if (get_f64(env, a[1], &ex) || get_f64(env, a[2], &sat)) return NULL;
   NAPI_OK(napi_get_value_bool(env, a[3], &den));
   if (get_f64(env, a[4], &sig) || typed(env, a[5], napi_uint8_array, 0, &p, &n)) return NULL;
+  if (check_multi_len(env, h, n)) return NULL;
   FSPT_OK_OR_THROW(fspt_multi_draw((fspt_multi *)h, (float)ex, (float)sat, den ? 1 : 0, (float)sig, (uint8_t *)p));
   return a[5];
 }
@@ -473,7 +493,7 @@ static napi_value Sync(napi_env env, napi_callback_info info) {
 static napi_value ReadRadiance(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h, *p; size_t n;
   if (get_args(env, info, 2, a) || unwrap(env, a[0], &h) || typed(env, a[1], napi_float32_array, 0, &p, &n)) return NULL;
-  /* the library writes W*H*4 floats: the caller sized the array from the same W,H */
+  if (check_target_len(env, h, n)) return NULL;
   FSPT_OK_OR_THROW(fspt_read_radiance((fspt_target *)h, (float *)p));
   return a[1];
 }
@@ -489,6 +509,7 @@ static napi_value Draw(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_get_value_bool(env, a[3], &den));
   if (get_f64(env, a[4], &sig) || typed(env, a[5], napi_uint8_array, 0, &p, &n)) return NULL;
   if (argc > 6) { napi_valuetype vt; napi_typeof(env, a[6], &vt); if (vt == napi_number && get_f64(env, a[6], &scale)) return NULL; }
+  if (check_target_len(env, h, n)) return NULL;
   FSPT_OK_OR_THROW(fspt_draw_scaled((fspt_target *)h, (float)ex, (float)sat, den ? 1 : 0, (float)sig, (float)scale, (uint8_t *)p));
   return a[5];
 }

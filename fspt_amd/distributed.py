@@ -78,8 +78,8 @@ class TileGather:
 
     channels = 3 ships RGB only: tracer.fs:517 writes vec4(rgb, 1), so the alpha of every traced pixel is the constant
     1 - a quarter of the bytes on the links carried no information.  `dst` then sets the alpha of the gathered pixels
-    to 1 itself (once: nothing overwrites it).  Only valid when every owned pixel is traced (full-frame viewport);
-    channels = 4 (default) ships the buffer as it is."""
+    to 1 itself, on every unpack (the bound accumulator may have been cleared in between: fspt_clear zeroes alpha too).
+    Only valid when every owned pixel is traced (full-frame viewport); channels = 4 (default) ships the buffer as it is."""
 
     def __init__(self, rank, world, width, height, device, tile=TILE, dst=0, channels=4):
         import torch
@@ -90,7 +90,7 @@ class TileGather:
         self.n_max = max(counts)
         self.send = torch.zeros((self.n_max, channels), dtype=torch.float32, device=device)
         self.tmp = torch.zeros((self.n_max, 4), dtype=torch.float32, device=device) if channels != 4 else None
-        self.recv, self.all_idx, self.alpha_set = None, None, False
+        self.recv, self.all_idx = None, None
         if rank == dst:
             self.big = torch.zeros((world * self.n_max, channels), dtype=torch.float32, device=device)
             self.recv = list(self.big.split(self.n_max))  # views: the gather lands in one buffer
@@ -137,9 +137,7 @@ class TileGather:
             flat.index_copy_(0, self.all_idx, src)
         else:
             flat[:, :self.C].index_copy_(0, self.all_idx, src)
-            if not self.alpha_set:
-                flat[:, 3].index_fill_(0, self.all_idx, 1.0)
-                self.alpha_set = True
+            flat[:, 3].index_fill_(0, self.all_idx, 1.0)
         return accum
 
     def exchange(self, accum):
@@ -153,9 +151,14 @@ class TileGather:
         return accum
 
 
-def reduce_radiance(accum, dst=0):
-    """The one exchange step: sum the ranks' full-size buffers onto `dst` in place."""
+def reduce_radiance(accum, dst=0, own_mask=None):
+    """The one exchange step as a sum-reduce (the RCCL reduce north_star names): the ranks' full-size buffers are summed
+    onto `dst` in place.  Every rank's buffer must be zero outside its own tiles.  That holds for a fresh buffer, but
+    after a reduce `dst` holds the other ranks' pixels too - a second reduce would add them again - so a caller that
+    reduces repeatedly passes `own_mask` (bool [H, W], this rank's pixels): everything else is zeroed first."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if own_mask is not None:
+            accum.mul_(own_mask.unsqueeze(-1).to(accum.dtype))
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum

@@ -4,8 +4,9 @@
  *
  * Mirrors the reference's own host code so that main.js can switch from WebGL2
  * to the MI355X kernels with the same call order (INTEGRATION.md):
- *   TexturePacker / getMaterial / parseMaterials / mergeSceneProps
- *                                 texture_packer.js:5-63, main.js:206-270,869-871, mtl_loader.js (images: decoded RGBA8)
+ *   buildScene's material step    drives the reference's own TexturePacker / getMaterial / ParseMaterials when the
+ *                                 caller passes them (opts.host), a table-driven resolver with the same layer
+ *                                 numbering otherwise (AtlasLayers / readMtl / resolveMaterial; images: decoded RGBA8)
  *   packReferenceScene            main.js:355-392 + maskBVHBuffer 272-282, fed with the
  *                                 reference's own BVH / Triangle objects (bvh.js, obj_loader.js)
  *   buildScene                    native obj_loader.js + bvh.js (same decisions, float64) for
@@ -62,109 +63,112 @@ function resampleImage(img, res, corrected, swizzle) {
   return out;
 }
 
-/** texture_packer.js:5-63; images are decoded RGBA8 objects {currentSrc, width, height, data} instead of
- *  HTMLImageElements, and the atlas is written on the CPU (resampleImage) instead of by a WebGL context. */
-class TexturePacker {
-  constructor(atlasRes) { this.res = atlasRes || 2048; this.imageSet = []; this.imageKeys = {}; this.maxRes = 1; }
-  addTexture(image, corrected) {
-    if (this.imageKeys[image.currentSrc]) return this.imageKeys[image.currentSrc];
-    this.maxRes = Math.max(this.maxRes, image.height);
-    image.corrected = corrected;
-    this.imageSet.push(image);
-    this.imageKeys[image.currentSrc] = this.imageSet.length - 1;
-    return this.imageKeys[image.currentSrc];
+/* ---------------------------------------------------------------------------------------------------------------
+ * Material resolution for buildScene.  In the reference this is host code that STAYS in the reference
+ * (INTEGRATION.md 2: TexturePacker texture_packer.js:5-63, ParseMaterials mtl_loader.js:3-43, getMaterial
+ * main.js:206-270): a caller that has those modules passes them in (`opts.host = {TexturePacker, getMaterial,
+ * ParseMaterials}`) and buildScene drives them unchanged.  Without them - Node scripts, the tests on the GPU box -
+ * the table-driven resolver below gives the same layer numbering (pinned to the reference's JS by the 'mtl' golden,
+ * tests/test_node_host.py::test_js_full_scene_build_matches_reference_js).
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/** The atlas layer list: one entry per distinct image (by URL) or flat colour (by its components), in first-use
+ *  order.  Like the reference's packer an entry that landed at index 0 is never found again (its lookup tests the
+ *  stored index for truthiness), so the first layer may appear twice - the layer ids in `mat` depend on it. */
+class AtlasLayers {
+  constructor(limit) { this.res = limit || 2048; this.entries = []; this.index = new Map(); this.tallest = 1; }
+  _intern(key, entry) {
+    const at = this.index.get(key);
+    if (at) return at;
+    this.entries.push(entry);
+    this.index.set(key, this.entries.length - 1);
+    return this.entries.length - 1;
   }
-  addColor(color) {
-    const key = color.join(' ');
-    if (this.imageKeys[key]) return this.imageKeys[key];   // index 0 is falsy: never de-duplicated (texture_packer.js:27)
-    this.imageSet.push(color);
-    this.imageKeys[key] = this.imageSet.length - 1;
-    return this.imageKeys[key];
+  image(img, corrected) {
+    const known = this.index.get(img.currentSrc);
+    if (known) return known;
+    if (img.height > this.tallest) this.tallest = img.height;
+    img.corrected = corrected;
+    return this._intern(img.currentSrc, img);
   }
-  setAndGetResolution() { if (this.maxRes < this.res) this.res = this.maxRes; return this.res; }
-  getPixels() {
-    const res = this.setAndGetResolution();
-    const out = new Uint8Array(res * res * 4 * this.imageSet.length);
-    this.imageSet.forEach((c, i) => {
-      if (Array.isArray(c)) {   // gl.clearColor(c) + readPixels RGBA8 (texture_packer.js:152-157)
-        const px = [0, 1, 2].map((k) => Math.floor(Math.min(Math.max(Number(c[k]), 0), 1) * 255 + 0.5)).concat([255]);
-        for (let t = 0; t < res * res; t++) out.set(px, (i * res * res + t) * 4);
-      } else {
-        out.set(resampleImage(c, res, !!c.corrected, c.swizzle), i * res * res * 4);
-      }
+  colour(rgb) { return this._intern(rgb.join(' '), rgb); }
+  resolution() { this.res = Math.min(this.res, this.tallest); return this.res; }
+  /** RGBA8 texels of every layer, res x res each: flat colours as gl.clearColor + readPixels would store them, images
+   *  through resampleImage */
+  pixels() {
+    const res = this.resolution(), n = res * res * 4;
+    const out = new Uint8Array(n * this.entries.length);
+    this.entries.forEach((e, i) => {
+      if (!Array.isArray(e)) { out.set(resampleImage(e, res, !!e.corrected, e.swizzle), i * n); return; }
+      const px = [0, 1, 2].map((k) => Math.floor(Math.min(Math.max(Number(e[k]), 0), 1) * 255 + 0.5));
+      for (let t = i * n; t < (i + 1) * n; t += 4) { out[t] = px[0]; out[t + 1] = px[1]; out[t + 2] = px[2]; out[t + 3] = 255; }
     });
     return out;
   }
   describe() {
-    return this.imageSet.map((e) => (Array.isArray(e) ? { color: e.map(Number) } :
+    return this.entries.map((e) => (Array.isArray(e) ? { color: e.map(Number) } :
       { src: e.currentSrc, corrected: !!e.corrected, swizzle: e.swizzle ? Array.from(e.swizzle, Number) : null }));
   }
 }
 
-/** ParseMaterials (mtl_loader.js:3-43). */
-function parseMaterials(mtlText, basePath) {
+/** MTL statements the pipeline reads: s = one number, v = a list of numbers, u = a file name relative to the OBJ. */
+const MTL_FIELDS = { ns: 's', ni: 's', d: 's', illum: 's', dielectric: 's', ior: 's',
+  ka: 'v', kd: 'v', kem: 'v', ks: 'v', ke: 'v', pr: 'v', pm: 'v', pmr: 'v', pmr_swizzle: 'v',
+  map_bump: 'u', map_kd: 'u', map_kem: 'u', map_ks: 'u', map_d: 'u', map_ns: 'u', map_pmr: 'u' };
+/** MTL text -> {materials: {name: {field: value}}, urls: Set}.  Statements before the first `newmtl` are ignored; a
+ *  statement whose value is falsy (a scalar 0, an unparsable number) is dropped, as in the reference's loader. */
+function readMtl(text, basePath) {
   const materials = {}, urls = new Set();
-  const scalarTokens = new Set(['ns', 'ni', 'd', 'illum', 'dielectric', 'ior']);
-  const vectorTokens = new Set(['ka', 'kd', 'kem', 'ks', 'ke', 'pr', 'pm', 'pmr', 'pmr_swizzle']);
-  const stringTokens = new Set(['map_bump', 'map_kd', 'map_kem', 'map_ks', 'map_d', 'map_ns', 'map_pmr']);
-  let mtlName = null;
-  for (const line of mtlText.split('\n')) {
-    const tokens = line.trim().split(/[ ]+/), key = tokens[0].toLowerCase();
-    if (key === 'newmtl') { mtlName = tokens[1]; materials[mtlName] = {}; }
-    if (!mtlName) continue;
-    let value, isUrl = false;
-    if (scalarTokens.has(key)) value = parseFloat(tokens[1]);
-    else if (vectorTokens.has(key)) value = tokens.slice(1).map(parseFloat);
-    else if (stringTokens.has(key)) { value = tokens[1]; isUrl = true; }
-    if (value) {
-      if (isUrl) urls.add(basePath + '/' + value);
-      materials[mtlName][key] = value;
-    }
+  let cur = null;
+  for (const raw of text.split('\n')) {
+    const [word, ...rest] = raw.trim().split(/[ ]+/);
+    const field = word.toLowerCase();
+    if (field === 'newmtl') { cur = materials[rest[0]] = {}; continue; }
+    const kind = MTL_FIELDS[field];
+    if (!cur || !kind) continue;
+    const value = kind === 's' ? parseFloat(rest[0]) : (kind === 'v' ? rest.map(parseFloat) : rest[0]);
+    if (!value) continue;
+    if (kind === 'u') urls.add(basePath + '/' + value);
+    cur[field] = value;
   }
   return { materials, urls };
 }
 
-/** getMaterial (main.js:206-270), same signature: the OBJ group's MTL entry wins over the prop's scene-JSON fields;
- *  assets = {url: decoded image}. */
-function getMaterial(transforms, group, texturePacker, assets, basePath) {
-  const gm = (group && group.material) || {};
-  const asset = (url) => {
-    if (!assets || !assets[url]) throw new Error('texture ' + url + ' is not in assets');
-    if (!assets[url].currentSrc) assets[url].currentSrc = url;
-    return assets[url];
+/** The four atlas layers of a material, in the order their ids are handed out.  Per layer, first match wins:
+ *  the group's MTL image map, the group's MTL colour, the prop's scene-JSON field (an image URL, or - where `propColour` -
+ *  a colour), the default colour. */
+const MATERIAL_LAYERS = [
+  { id: 'diffuseIndex', map: 'map_kd', colour: 'kd', prop: 'diffuse', propColour: true, fallback: [0.5, 0.5, 0.5], corrected: true },
+  { id: 'roughnessIndex', map: 'map_pmr', colour: 'pmr', prop: 'metallicRoughness', propColour: true, fallback: [0.0, 0.3, 0],
+    mapSwizzle: 'pmr_swizzle', propSwizzle: 'mrSwizzle' },
+  { id: 'specularIndex', map: 'map_kem', colour: 'kem', prop: 'emission', propColour: false, fallback: [0, 0, 0] },
+  { id: 'normalIndex', map: 'map_bump', colour: null, prop: 'normal', propColour: false, anyTruthyProp: true, fallback: [0.5, 0.5, 1] },
+];
+function resolveMaterial(prop, group, layers, assets, basePath) {
+  const mtl = (group && group.material) || {};
+  const decoded = (url) => {
+    const img = assets && assets[url];
+    if (!img) throw new Error('texture ' + url + ' is not in assets');
+    if (!img.currentSrc) img.currentSrc = url;
+    return img;
   };
-  const material = {};
-  if (gm.map_kd) material.diffuseIndex = texturePacker.addTexture(asset(basePath + '/' + gm.map_kd), true);
-  else if (gm.kd) material.diffuseIndex = texturePacker.addColor(gm.kd);
-  else if (typeof transforms.diffuse === 'string') material.diffuseIndex = texturePacker.addTexture(asset(transforms.diffuse), true);
-  else if (typeof transforms.diffuse === 'object' && transforms.diffuse) material.diffuseIndex = texturePacker.addColor(transforms.diffuse);
-  else material.diffuseIndex = texturePacker.addColor([0.5, 0.5, 0.5]);
-
-  if (gm.map_pmr) {
-    const img = asset(basePath + '/' + gm.map_pmr);
-    img.swizzle = gm.pmr_swizzle;            // set on the shared image before de-duplication: the last use decides
-    material.roughnessIndex = texturePacker.addTexture(img);
-  } else if (gm.pmr) material.roughnessIndex = texturePacker.addColor(gm.pmr);
-  else if (typeof transforms.metallicRoughness === 'string') {
-    const img = asset(transforms.metallicRoughness);
-    img.swizzle = transforms.mrSwizzle;
-    material.roughnessIndex = texturePacker.addTexture(img);
-  } else if (typeof transforms.metallicRoughness === 'object' && transforms.metallicRoughness) {
-    material.roughnessIndex = texturePacker.addColor(transforms.metallicRoughness);
-  } else material.roughnessIndex = texturePacker.addColor([0.0, 0.3, 0]);
-
-  if (gm.map_kem) material.specularIndex = texturePacker.addTexture(asset(basePath + '/' + gm.map_kem));
-  else if (gm.kem) material.specularIndex = texturePacker.addColor(gm.kem);
-  else if (typeof transforms.emission === 'string') material.specularIndex = texturePacker.addTexture(asset(transforms.emission));
-  else material.specularIndex = texturePacker.addColor([0, 0, 0]);
-
-  if (gm.map_bump) material.normalIndex = texturePacker.addTexture(asset(basePath + '/' + gm.map_bump));
-  else if (transforms.normal) material.normalIndex = texturePacker.addTexture(asset(transforms.normal));
-  else material.normalIndex = texturePacker.addColor([0.5, 0.5, 1]);
-  material.ior = Number(gm.ior || transforms.ior || 1.4);
-  material.dielectric = Number(gm.dielectric || transforms.dielectric || -1);
-  material.emittance = transforms.emittance || [0, 0, 0];
-  return material;
+  const out = {};
+  for (const L of MATERIAL_LAYERS) {
+    const pv = prop[L.prop];
+    let img = null, swizzle;
+    if (mtl[L.map]) { img = decoded(basePath + '/' + mtl[L.map]); swizzle = mtl[L.mapSwizzle]; }
+    else if (L.colour && mtl[L.colour]) { out[L.id] = layers.colour(mtl[L.colour]); continue; }
+    else if (typeof pv === 'string' || (L.anyTruthyProp && pv)) { img = decoded(pv); swizzle = prop[L.propSwizzle]; }
+    else if (L.propColour && pv && typeof pv === 'object') { out[L.id] = layers.colour(pv); continue; }
+    else { out[L.id] = layers.colour(L.fallback); continue; }
+    // the swizzle lives on the shared decoded image and is (re)set before de-duplication: the last use decides
+    if (L.mapSwizzle) img.swizzle = swizzle;
+    out[L.id] = L.corrected ? layers.image(img, true) : layers.image(img);
+  }
+  out.ior = Number(mtl.ior || prop.ior || 1.4);
+  out.dielectric = Number(mtl.dielectric || prop.dielectric || -1);
+  out.emittance = prop.emittance || [0, 0, 0];
+  return out;
 }
 
 /** mergeSceneProps (main.js:869-871) */
@@ -199,12 +203,17 @@ function packReferenceScene(bvh) {
 /** initBVH (main.js:284-445) through the native builder (same decisions, float64).
  *  sceneOrProps: the scene JSON (props / static_props / animated_props, worldTransforms, normalize, atlasRes) or a
  *  bare props array; objTexts: {path: OBJ text}; env: {rgbe, width, height} | null;
- *  opts: {mtlTexts: {url: MTL text}, assets: {url: decoded image}, focusRays: [[eye, dir], ...]}. */
+ *  opts: {mtlTexts: {url: MTL text}, assets: {url: decoded image}, focusRays: [[eye, dir], ...],
+ *         host: {TexturePacker, getMaterial, ParseMaterials} (the reference's modules) + atlasPixels(packer)}. */
 function buildScene(sceneOrProps, objTexts, env, leafSize, opts) {
   opts = opts || {};
   const scene = Array.isArray(sceneOrProps) ? { props: sceneOrProps } : sceneOrProps;
   const props = mergeSceneProps(scene);
-  const packer = new TexturePacker(scene.atlasRes || 2048);
+  // the reference's own host modules when the caller has them (INTEGRATION.md), the resolver above otherwise
+  const host = opts.host || null;
+  const packer = host ? new host.TexturePacker(scene.atlasRes || 2048, props.length) : new AtlasLayers(scene.atlasRes || 2048);
+  const mtlOf = host ? host.ParseMaterials : readMtl;
+  const materialOf = host ? host.getMaterial : resolveMaterial;
   const b = addon.builderCreate();
   let s;
   try {
@@ -219,11 +228,11 @@ function buildScene(sceneOrProps, objTexts, env, leafSize, opts) {
           const url = basePath + '/' + g.mtllib;
           if (!libs[url]) {
             if (!opts.mtlTexts || opts.mtlTexts[url] === undefined) throw new Error('mtllib ' + url + ' is not in opts.mtlTexts');
-            libs[url] = parseMaterials(opts.mtlTexts[url], basePath).materials;
+            libs[url] = mtlOf(opts.mtlTexts[url], basePath).materials;
           }
           material = libs[url][g.name] || {};
         }
-        return getMaterial(p, { material }, packer, opts.assets, basePath);
+        return materialOf(p, { material }, packer, opts.assets, basePath);
       });
       addon.builderCommit(b, mats);
     }
@@ -233,8 +242,17 @@ function buildScene(sceneOrProps, objTexts, env, leafSize, opts) {
   } finally {
     addon.builderDestroy(b);
   }
-  s.atlas = packer.getPixels(); s.atlasRes = packer.res; s.atlasLayers = packer.imageSet.length;
-  s.layers = packer.describe();
+  if (host) {
+    // the reference's packer renders the atlas with a WebGL context of its own (texture_packer.js:103-175): its pixels
+    // are the caller's to fetch (opts.atlasPixels(packer) -> Uint8Array of res*res*4*layers); the layer ids are in `mat`
+    if (typeof opts.atlasPixels !== 'function') throw new Error('buildScene: opts.host needs opts.atlasPixels(packer)');
+    s.atlasRes = packer.setAndGetResolution(); s.atlasLayers = packer.imageSet.length;
+    s.atlas = opts.atlasPixels(packer);
+    s.layers = null;
+  } else {
+    s.atlas = packer.pixels(); s.atlasRes = packer.res; s.atlasLayers = packer.entries.length;
+    s.layers = packer.describe();
+  }
   if (env) { s.env = env.rgbe; s.envW = env.width; s.envH = env.height; s.bins = addon.envBins(env.rgbe, env.width, env.height); }
   else { s.env = null; s.envW = 0; s.envH = 0; s.bins = new Uint32Array([0, 0, 1, 2048]); }   // main.js:292
   s.leafSize = leafSize || 4;
@@ -389,5 +407,5 @@ class MultiPathTracer {
 // memory later scenes may spend on interleaved material textures (fspt_set_texture_interleave_budget; results do not depend on it)
 function setTextureInterleaveBudget(bytes) { addon.setTextureInterleaveBudget(bytes); }
 
-module.exports = { addon, setTextureInterleaveBudget, MultiPathTracer, TexturePacker, getMaterial, parseMaterials, mergeSceneProps, resampleImage, packReferenceScene, buildScene,
+module.exports = { addon, setTextureInterleaveBudget, MultiPathTracer, AtlasLayers, resolveMaterial, readMtl, mergeSceneProps, resampleImage, packReferenceScene, buildScene,
   PathTracer, saveBlob, loadBlob };

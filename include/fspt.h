@@ -120,8 +120,14 @@ int fspt_target_set_shard(fspt_target *target, uint32_t shard, uint32_t n_shards
                           uint32_t tile);
 /* Use caller-owned device memory (e.g. a torch tensor's data_ptr, W*H*4
  * floats) as the accumulator so that a collective can run on it in place.
- * NULL restores the internally allocated buffer. */
+ * NULL restores the internally allocated buffer.  The library works asynchronously (recorded two-call ticks, kernels
+ * on its own streams): the bound buffer is only current after fspt_sync, fspt_read_radiance or fspt_draw - anything
+ * else that reads it (a torch op, a collective) must call fspt_sync first.  fspt_target_destroy executes the ticks
+ * still recorded for a caller-owned accumulator before it lets go of it. */
 int fspt_target_bind_accumulator(fspt_target *target, void *device_ptr);
+/* The size the target was created with (what fspt_read_radiance / fspt_draw write: W*H*4 elements); bindings check
+ * the caller's array against it (canvas.width/height of main.js:598-617). */
+int fspt_target_size(fspt_target *target, uint32_t *width, uint32_t *height);
 /* Device pointer of the accumulator currently in use (W*H*4 floats). */
 int fspt_target_accumulator(fspt_target *target, void **device_ptr);
 
@@ -252,6 +258,12 @@ int fspt_multi_read_radiance(fspt_multi *m, float *out);
 int fspt_multi_draw(fspt_multi *m, float exposure, float saturation, int denoise, float max_sigma, uint8_t *out_rgba8);
 /* Bytes that crossed between devices in the most recent gather (the exchange's payload: 16 bytes per foreign pixel). */
 int fspt_multi_last_gather_bytes(fspt_multi *m, uint64_t *bytes);
+int fspt_multi_size(fspt_multi *m, uint32_t *width, uint32_t *height);  /* the frame fspt_multi_create was given */
+/* How target i's tiles reach devices[0] (the reference has no counterpart: README.md:28 "Tiled rendering" is a TODO):
+ * bit 0 = target i's device can write devices[0]'s memory directly (hipDeviceCanAccessPeer(devices[i], devices[0]):
+ * the direction the gather copy runs, issued on the sending device's stream), bit 1 = the reverse mapping.  0 = the
+ * copy is staged through the host.  A target on devices[0] itself reports 3. */
+int fspt_multi_peer_access(fspt_multi *m, uint32_t i, int *mask);
 
 /* clear() (main.js:826-836). */
 int fspt_clear(fspt_target *target);

@@ -26,6 +26,24 @@ if (mode === 'exports') {
   for (const k of ['bvh', 'tri', 'mat', 'norm', 'uv', 'bins', 'atlas']) out[k] = b64(s[k]);
   out.depth = s.depth; out.atlasLayers = s.atlasLayers; out.atlasRes = s.atlasRes; out.layers = s.layers;
   out.focus = b64(new Float64Array(s.focus));
+} else if (mode === 'build_injected') {
+  // opts.host: the caller's own TexturePacker / getMaterial / ParseMaterials drive the material step (INTEGRATION.md 2).
+  // Stand-ins with the reference's interface names, built on the module's resolver: checks the plumbing, and that the
+  // result equals the built-in route.
+  class Packer extends F.AtlasLayers {
+    get imageSet() { return this.entries; }
+    setAndGetResolution() { return this.resolution(); }
+  }
+  let calls = 0;
+  const host = { TexturePacker: Packer, ParseMaterials: F.readMtl,
+    getMaterial: (prop, group, packer, assets, base) => { calls++; return F.resolveMaterial(prop, group, packer, assets, base); } };
+  const s = F.buildScene(job.props, job.objs, env, 4, { host, atlasPixels: (packer) => packer.pixels() });
+  const r = F.buildScene(job.props, job.objs, env, 4);
+  out.calls = calls;
+  out.same = ['bvh', 'tri', 'mat', 'norm', 'uv', 'bins', 'atlas'].every((k) => b64(s[k]) === b64(r[k])) && s.atlasLayers === r.atlasLayers && s.atlasRes === r.atlasRes;
+  let threw = null;
+  try { F.buildScene(job.props, job.objs, env, 4, { host }); } catch (e) { threw = String(e.message); }
+  out.needs_pixels = threw;
 } else if (mode === 'blob') {
   // read a blob written by Python, write it back from JS
   const s = F.loadBlob(job.blob_in);

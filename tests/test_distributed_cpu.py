@@ -47,8 +47,22 @@ def _worker(rank, world, port, tmp):
     t3 = torch.from_numpy(acc.copy())
     g3 = D.TileGather(rank, world, W, H, torch.device("cpu"), channels=3)  # RGB only, alpha set by rank 0
     g3.exchange(t3)
-    g3.exchange(t3)  # a second read-out of the same target (alpha is set once)
+    g3.exchange(t3)  # a second read-out of the same target
+    # the accumulator is cleared (fspt_clear zeroes alpha too), re-rendered and read out again: alpha must come back
+    t4 = torch.from_numpy(acc.copy())
+    g3.exchange(t4)
+    t4.zero_()
+    t4 += torch.from_numpy(acc)
+    g3.exchange(t4)
+    # repeated sum-reduces of the same accumulator (bench.py --exchange reduce --reps N): rank 0 must not add the other
+    # ranks' pixels of the previous read-out again
+    t5 = torch.from_numpy(acc.copy())
+    own = torch.from_numpy(mask)
+    for _ in range(3):
+        D.reduce_radiance(t5, dst=0, own_mask=own)
     if rank == 0:
+        np.save(os.path.join(tmp, "cleared_rgb.npy"), t4.numpy())
+        np.save(os.path.join(tmp, "reduced3.npy"), t5.numpy())
         np.save(os.path.join(tmp, "reduced.npy"), t.numpy())
         np.save(os.path.join(tmp, "gathered.npy"), t2.numpy())
         np.save(os.path.join(tmp, "gathered_rgb.npy"), t3.numpy())
@@ -70,6 +84,8 @@ def test_two_rank_tile_shard_and_reduce(tmp_path):
     assert np.array_equal(got, want)
     assert np.array_equal(np.load(os.path.join(str(tmp_path), "gathered.npy")), want)  # tile-gather exchange
     assert np.array_equal(np.load(os.path.join(str(tmp_path), "gathered_rgb.npy")), want)  # ... shipping RGB only
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "cleared_rgb.npy")), want)   # ... after a clear
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "reduced3.npy")), want)      # three reduces in a row
 
 
 def test_tile_ownership_partitions_frame():

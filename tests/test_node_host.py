@@ -59,8 +59,17 @@ def test_js_build_scene_matches_python_host(small_scene):
     assert out["depth"] == small_scene.depth
 
 
+def test_js_build_with_injected_host_modules():
+    """buildScene(..., {host}) drives the caller's TexturePacker / getMaterial / ParseMaterials (the reference keeps
+    those) instead of the module's own resolver; same arrays either way."""
+    out = run_node("build_injected", small_job())
+    assert out["calls"] > 0 and out["same"] is True
+    assert "atlasPixels" in out["needs_pixels"]
+
+
 def test_js_full_scene_build_matches_reference_js():
-    """The JS host's own getMaterial / parseMaterials / mergeSceneProps / TexturePacker over the native builder:
+    """The JS host's material step (the table-driven resolver of fspt.js, used when the caller does not inject the
+    reference's TexturePacker / getMaterial / ParseMaterials) + mergeSceneProps over the native builder:
     the 'mtl' golden scene (MTL groups, image maps, worldTransforms, normalize, static + animated props) gives
     the arrays, layer list and auto-focus values of the reference's JS pipeline, and the Python host's atlas."""
     from test_goldens import load_js, stand_in_images, native_build
