@@ -105,6 +105,30 @@ def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=15.0):
                       f"{n_shards}-th 32x32 tile of the same {W}x{H} depth-{bounces} frame: {s} samples in {t:.2f} s"}
 
 
+def parity_check(arrays, W, H, cam, lens, bounces, n_ticks, seed, got, budget_samples=3.0e7):
+    """Self-verification of the run that was just timed: the accumulator the GPU produced over ALL its ticks so far
+    (warm-up + every timed region: same seed, same tick numbers) against the CPU oracle on a uniform sample of the
+    frame's 32x32 tiles (tile shard 0 of S, S from a sample budget), compared with == on float32.  The oracle is the
+    checker here, never the thing measured (it runs after the timed regions)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as O
+    from fspt_amd import distributed as D
+    n_shards = max(1, int(-(-float(W) * H * n_ticks // budget_samples)))
+    want = np.zeros((H, W, 4), np.float32)
+    t0 = time.perf_counter()
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], lens, cam["env_theta"], bounces, 0, n_ticks, seed, want,
+             shard=0, n_shards=n_shards, tile=D.TILE)
+    mask = D.owner_mask(0, n_shards, W, H)
+    equal = bool(np.array_equal(got[mask], want[mask]))
+    out = {"pixels": int(mask.sum()), "ticks": int(n_ticks), "equal": equal, "oracle_s": round(time.perf_counter() - t0, 2),
+           "sample": f"every {n_shards}-th 32x32 tile of the {W}x{H} frame, all {n_ticks} ticks rendered so far"}
+    if not equal:
+        bad = (got[mask] != want[mask]).any(axis=-1)
+        out["mismatching_pixels"] = int(bad.sum())
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,7 +148,11 @@ def parse_args(argv=None):
     ap.add_argument("--tex-interleave-budget", type=int, default=None,
                     help="bytes of interleaved material textures the scene may use (A/B: 0 = single-layer images only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "wavefront2"])
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of the timed run's accumulator")
+    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "wavefront2", "stream", "stream2"])
+    ap.add_argument("--pool", type=int, default=0, help="stream scheduler: live paths per state set (0 = library default)")
+    ap.add_argument("--drain", type=int, default=-1, help="stream scheduler: drain iterations before the tail kernel (-1 = default)")
+    ap.add_argument("--overlap", type=int, default=-1, help="stream scheduler: 1 = primary on a second HIP stream, 0 = one stream (-1 = default)")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="multi-GPU read-out: gather each rank's own tiles to rank 0 (default) or sum-reduce the full frame")
     ap.add_argument("--batch", type=int, default=128, help="ticks per wavefront batch")
@@ -276,6 +304,8 @@ def main():
     pt.set_camera(**cam)
     pt.set_shard(rank, n_gpus, D.TILE)
     pt.set_pipeline(args.pipeline, args.batch)
+    if args.pool or args.drain >= 0 or args.overlap >= 0:
+        pt.set_pool(args.pool, args.drain, 0, args.overlap)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     pt.bind_accumulator(accum.data_ptr(), keep=accum)
     pt.seed(1)
@@ -295,25 +325,30 @@ def main():
         pt.render(args.warmup)
     barrier()
     # ---- timed: --reps regions of exactly K steps each, every one closed by the path's one exchange step ----
-    times, kernel_ms_all, stages_all = [], [], []
+    own = torch.from_numpy(D.owner_mask(rank, n_gpus, W, H)).to(accum.device) if (n_gpus > 1 and args.exchange == "reduce") else None
+    times, kernel_ms_all, stages_all, exch_ms = [], [], [], []
     for _ in range(args.reps):
         barrier()
         t_start = time.perf_counter()
         pt.render(args.steps)
         pt.sync()
+        t_render = time.perf_counter()
         if exch is not None:
             exch.exchange(accum)  # RCCL over xGMI: rank 0 ends up with the whole frame
-        else:
-            D.reduce_radiance(accum, dst=0)
+        elif n_gpus > 1:
+            # sum-reduce of the full frame; the other ranks' pixels rank 0 received in the previous region are zeroed
+            # first (own_mask), or they would be added again
+            D.reduce_radiance(accum, dst=0, own_mask=own)
         barrier()
         elapsed = time.perf_counter() - t_start
+        exch_ms.append((time.perf_counter() - t_render) * 1e3)
         if dist is not None:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         times.append(elapsed)
         kernel_ms_all.append(pt.last_kernel_ms())
-        stages_all.append(pt.last_stage_ms() if args.pipeline.startswith("wavefront") else None)
+        stages_all.append(pt.last_stage_ms() if args.pipeline != "megakernel" else None)
     order = sorted(range(args.reps), key=lambda i: times[i])
     med = order[(args.reps - 1) // 2]  # the median region (lower median for an even count): its own stage timings are reported
     elapsed = times[med]
@@ -324,9 +359,20 @@ def main():
     value = total_samples / elapsed / 1e6
 
     if rank == 0:
+        # the frame as the timed regions left it (rank 0 holds the whole frame after the exchange), checked against the
+        # oracle BEFORE the counting ticks of report() add to it
+        check = None
+        if not args.no_parity_check:
+            check = parity_check(arrays, W, H, cam, lens, args.bounces, args.warmup + args.reps * args.steps, 1,
+                                 accum.cpu().numpy())
         out = report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed, times, kernel_ms, launches,
                      stages, build_s)
+        out["parity_check"] = check
+        if n_gpus > 1:
+            out["exchange_ms"] = round(exch_ms[med], 3)  # read-out exchange + closing barrier of the median region (inside `value`)
         print(json.dumps(out), flush=True)
+        if check is not None and not check["equal"]:
+            raise SystemExit("bench.py: the timed run's accumulator differs from the oracle")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

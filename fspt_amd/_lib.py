@@ -105,9 +105,11 @@ SIGNATURES = {
     "fspt_enable_counters": (C.c_int, [_VP, C.c_int]),
     "fspt_get_counters": (C.c_int, [_VP, C.POINTER(Counters)]),
     "fspt_counters_reset": (C.c_int, [_VP]),
+    "fspt_get_trace_lds_steps": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "fspt_math_eval": (C.c_int, [C.c_int, C.c_int, _F, _F, C.c_uint32, _F]),
     "fspt_last_kernel_ms": (C.c_int, [_VP, _F, _U32]),
     "fspt_target_set_pipeline": (C.c_int, [_VP, C.c_int, C.c_uint32]),
+    "fspt_target_set_pool": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_uint32, C.c_int]),
     "fspt_last_stage_ms": (C.c_int, [_VP, _F, _U32]),
     "fspt_target_prepare": (C.c_int, [_VP]),
     "fspt_target_set_tail": (C.c_int, [_VP, C.c_int]),

@@ -72,6 +72,11 @@ struct fspt_target {
   // wavefront pipeline
   uint32_t vw = 0, vh = 0;    // viewport (gl.viewport of the two draws); default = the whole target
   int pipeline = 1;           // 0 = megakernel, 1 = wavefront (2 = wavefront with two overlapped lanes sets n_lanes)
+  int sched = 0;              // wavefront pipeline: 0 = batch scheduler (all ticks x all pixels per batch), 1 = stream (fixed pool)
+  uint32_t pool_paths = 0;    // stream: paths per state set and lane (0 = default)
+  int stream_drain = -1;      // stream: iterations after the last generating one before the tail kernel takes over (-1 = default)
+  uint32_t stream_iter_cap = 0; // stream, test hook: at most this many iterations per run (the finishing launch does the rest)
+  int stream_overlap = -1;      // stream: plan / primary / resolve on a second HIP stream beside the previous trace (1), everything on one stream (0), default (-1)
   uint32_t batch_ticks = 128; // ticks traced together by the wavefront pipeline (58 GB of path state at 1080p;
                               // measured 64 / 128 / 256 -> 3 619 / 3 794 / 3 750 Msamples/s, profiles/r01)
   // Two lanes = two independent batches in flight on two HIP streams: while one batch sits in a latency-bound
@@ -84,9 +89,22 @@ struct fspt_target {
     hipEvent_t counts_ready = nullptr;
     bool counts_pending = false;
     uint32_t counts_slots = 0;             // slots of the batch the copy describes
-    uint32_t slots = 0;        // allocated path slots
+    uint32_t slots = 0;        // allocated path slots (batch scheduler)
     hipStream_t stream = nullptr;
     hipEvent_t resolved = nullptr; // this lane's most recent resolve has finished
+    // stream scheduler (fspt_device.hpp: WfStreamCtl): a pool of st_cap paths per state set + a ring of st_fin finished colours
+    uint32_t st_cap = 0, st_fin = 0;
+    hipStream_t stream_b = nullptr;          // plan / primary / resolve run here, beside the previous iteration's trace
+    hipEvent_t ev_logic[fspt::WF_RING] = {}, ev_b[fspt::WF_RING] = {}, ev_run = nullptr, ev_b_last = nullptr;
+    fspt::WfStreamCtl *ctl = nullptr;
+    fspt::WfStreamCtl *ctl_host = nullptr;   // pinned copy of the last run's statistics (never waited for)
+    hipEvent_t ctl_ready = nullptr;
+    bool ctl_pending = false;
+    uint64_t ctl_key = 0, stat_key = 0;      // what the pending copy / the known statistics describe (units, ticks, pool, bounces)
+    uint32_t ctl_units = 0;                  // units of the run the pending copy describes
+    uint32_t stat_gen_iters = 0;             // iterations the last such run needed to hand out all its units
+    uint64_t bytes = 0;                      // path-state bytes this lane holds (either scheduler)
+    bool zeroed = false;                     // counts / heads / ctl are zero (cleared behind the previous batch, off the next one's critical path)
   } lanes[2];
   uint32_t n_lanes = 1; // 2 = pipeline code 2: measured +3 % at 64+ ticks, -17 % at 8 ticks (profiles/r01)
   // Deferred two-call ticks (fspt_camera + fspt_trace): recorded, executed in batches at the next flush point
@@ -569,17 +587,25 @@ int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **
   if (e == hipSuccess) e = hipMalloc((void **)&t->ray_pos, px * 16);
   if (e == hipSuccess) e = hipMalloc((void **)&t->ray_dir, px * 16);
   if (e == hipSuccess) e = hipMalloc((void **)&t->work_counters, WORK_RING * 4);
-  if (e == hipSuccess) e = hipMalloc((void **)&t->counters, 6 * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&t->counters, 8 * 8); // 6 work counters (fspt_counters) + [6] = traversal steps the trace kernel served from LDS
   if (e == hipSuccess) e = hipStreamCreate(&t->stream);
   if (e == hipSuccess) e = hipEventCreate(&t->ev0);
   if (e == hipSuccess) e = hipEventCreate(&t->ev1);
   if (e == hipSuccess) e = hipEventCreate(&t->ev_start);
   for (auto &ln : t->lanes) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.stream_b, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.resolved, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.ev_run, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.ev_b_last, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.ctl_ready, hipEventDisableTiming);
+    for (int k = 0; k < fspt::WF_RING; ++k) {
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.ev_logic[k], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.ev_b[k], hipEventDisableTiming);
+    }
   }
   if (e == hipSuccess) e = hipMemsetAsync(t->accum_own, 0, px * 16, t->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(t->counters, 0, 48, t->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(t->counters, 0, 64, t->stream);
   if (e != hipSuccess) {
     fspt_set_error("fspt_target_create: %s", hipGetErrorString(e));
     fspt_target_destroy(t);
@@ -606,6 +632,12 @@ int fspt_target_destroy(fspt_target *t) {
     if (ln.counts_host) hipHostFree(ln.counts_host);
     if (ln.counts_ready) hipEventDestroy(ln.counts_ready);
     if (ln.resolved) hipEventDestroy(ln.resolved);
+    if (ln.stream_b) hipStreamSynchronize(ln.stream_b);
+    hipFree(ln.ctl);
+    if (ln.ctl_host) hipHostFree(ln.ctl_host);
+    for (hipEvent_t ev : {ln.ev_run, ln.ev_b_last, ln.ctl_ready}) if (ev) hipEventDestroy(ev);
+    for (int k = 0; k < fspt::WF_RING; ++k) { if (ln.ev_logic[k]) hipEventDestroy(ln.ev_logic[k]); if (ln.ev_b[k]) hipEventDestroy(ln.ev_b[k]); }
+    if (ln.stream_b) hipStreamDestroy(ln.stream_b);
     if (ln.stream) hipStreamDestroy(ln.stream);
   }
   if (t->ev_start) hipEventDestroy(t->ev_start);
@@ -712,15 +744,19 @@ static size_t wf_slot_bytes() {
 
 static void wf_release(fspt_target::WfLane &ln) {
   if (ln.stream) hipStreamSynchronize(ln.stream);
+  if (ln.stream_b) hipStreamSynchronize(ln.stream_b);
   for (void *&m : ln.mem) { if (m) { hipFree(m); m = nullptr; } }
   ln.slots = 0;
+  ln.st_cap = ln.st_fin = 0;
+  ln.bytes = 0;
+  ln.zeroed = false;
 }
 
 // Path state of one lane for `slots` path slots.  `budget_slots` = what fspt_target_set_memory_limit leaves this lane;
 // exceeding it is reported exactly like the device running out of memory (FSPT_E_NOMEM: the caller shrinks the batch).
 static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots, uint64_t budget_slots) {
   (void)t;
-  if (ln.slots >= slots && ln.counts) return FSPT_OK;
+  if (ln.slots >= slots && ln.counts && !ln.st_cap) return FSPT_OK;
   wf_release(ln);
   for (int i = 0; i < WF_ARRAYS; ++i) {
     hipError_t e = slots > budget_slots ? hipErrorOutOfMemory : hipMalloc(&ln.mem[i], (size_t)slots * WF_ARRAY_BYTES[i]);
@@ -741,6 +777,7 @@ static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots, ui
   if (!ln.counts_ready) HIP_TRY(hipEventCreateWithFlags(&ln.counts_ready, hipEventDisableTiming));
   HIP_TRY(hipStreamSynchronize(ln.stream));
   ln.slots = slots;
+  ln.bytes = (uint64_t)slots * wf_slot_bytes();
   return FSPT_OK;
 }
 
@@ -894,11 +931,15 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     uint32_t nbt = n_ticks - done < batch ? n_ticks - done : batch;
     p.n_batch = nbt;
     p.first_tick = first_tick + done;
+    p.ctl = nullptr; p.ring_slots = nbt * work_total; p.pool = 0; p.n_pools = 1; p.finish = 0;
     for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
     // the previous batch's live-path counts, if their copy has landed: where the tail kernel takes over
     wf_collect_counts(t, ln);
-    HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
-    HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, st));
+    if (!ln.zeroed) {
+      HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
+      HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, st));
+    }
+    ln.zeroed = false;
     p.gen_rays = gen ? 1u : 0u;
     // Round 1 = the primary launch (ray generation + primary traversal + its shading); round r >= 2: logic consumes the
     // results of trace r-1 and shades bounce r-1.  After round nb+1 every path has finished unless a refraction kept `i`
@@ -906,13 +947,14 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     const uint32_t last = nb + 1;
     uint32_t tail = wf_tail_round(t, (uint64_t)nbt * work_total, last);
     if (t->scene->has_dielectric && tail > last) tail = last; // refraction: paths may outlive `last` rounds
+    auto set_round = [&](uint32_t r) { p.round = r; p.cnt_in = r - 1; p.cnt_out = r; p.set_in = (r - 1) & 1u; p.set_out = r & 1u; };
     for (uint32_t r = 1; r <= last && r <= tail; ++r) {
-      p.round = r;
+      set_round(r);
       if ((rc = launch(r == 1 ? fspt::WF_K_PRIMARY : fspt::WF_K_LOGIC))) return rc;
       if (r < last && r < tail) { if ((rc = launch(fspt::WF_K_TRACE))) return rc; }
     }
     if (tail <= last && (tail < last || t->scene->has_dielectric)) {
-      p.round = tail;
+      set_round(tail);
       if ((rc = launch(fspt::WF_K_TAIL))) return rc;
     }
     HIP_TRY(hipMemcpyAsync(ln.counts_host, ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), hipMemcpyDeviceToHost, st));
@@ -923,11 +965,271 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     if (prev) HIP_TRY(hipStreamWaitEvent(st, prev->resolved, 0));
     if ((rc = launch(fspt::WF_K_RESOLVE))) return rc;
     HIP_TRY(hipEventRecord(ln.resolved, st));
+    // the next batch's counters and pool heads are cleared now, behind this batch (the clears used to sit between a
+    // render call and its first kernel: ~0.1 ms of every timed region)
+    HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
+    HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, st));
+    ln.zeroed = true;
     prev = &ln;
     done += nbt;
     ++bi;
   }
   if (prev) HIP_TRY(hipStreamWaitEvent(t->stream, prev->resolved, 0)); // the resolves are chained: the last one ends it all
+  return FSPT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Stream scheduler (fspt_device.hpp: WfStreamCtl; fspt_target_set_pipeline code 3 / 4)
+// ---------------------------------------------------------------------------
+static const uint32_t ST_DEFAULT_POOL = 16u << 20; // paths per state set and lane (3.4 GB; profiles/r03/sweep_stream_pool.log)
+static const bool ST_DEFAULT_OVERLAP = true; // profiles/r03/ab_stream_overlap.log: 8 Mi pool, 20 / 128 steps: 3 733 / 4 095 Msamples/s against 3 702 / 3 975 on one stream
+static const size_t ST_CTL_BYTES = sizeof(fspt::WfStreamCtl);
+static const size_t ST_COUNTS_BYTES = sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2);
+
+// Path state of one lane for the stream scheduler: two state sets + ray results for `cap` paths, `fin_slots` finished colours.
+static int st_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t cap, uint32_t fin_slots, uint64_t budget_bytes) {
+  (void)t;
+  if (ln.st_cap >= cap && ln.st_fin >= fin_slots && ln.counts && ln.ctl) return FSPT_OK; // (a larger pool from an earlier call is kept)
+  wf_release(ln);
+  const uint64_t need = (uint64_t)cap * (wf_slot_bytes() - 12) + (uint64_t)fin_slots * 12;
+  for (int i = 0; i < WF_ARRAYS; ++i) {
+    const size_t bytes = i == 14 ? (size_t)fin_slots * 12 : (size_t)cap * WF_ARRAY_BYTES[i];
+    hipError_t e = need > budget_bytes ? hipErrorOutOfMemory : hipMalloc(&ln.mem[i], bytes);
+    if (e == hipErrorOutOfMemory) {
+      (void)hipGetLastError();
+      wf_release(ln);
+      fspt_set_error("path pool of %u paths + %u finished samples (%llu bytes) does not fit %s", cap, fin_slots, (unsigned long long)need,
+                     need > budget_bytes ? "the target's memory limit" : "the free device memory");
+      return FSPT_E_NOMEM;
+    }
+    HIP_TRY(e);
+    HIP_TRY(hipMemsetAsync(ln.mem[i], 0, bytes, ln.stream)); // touch every page once, now
+  }
+  if (!ln.counts) HIP_TRY(hipMalloc((void **)&ln.counts, ST_COUNTS_BYTES));
+  if (!ln.heads) HIP_TRY(hipMalloc((void **)&ln.heads, WF_HEADS_BYTES));
+  if (!ln.counts_host) HIP_TRY(hipHostMalloc((void **)&ln.counts_host, ST_COUNTS_BYTES, hipHostMallocDefault));
+  if (!ln.counts_ready) HIP_TRY(hipEventCreateWithFlags(&ln.counts_ready, hipEventDisableTiming));
+  if (!ln.ctl) HIP_TRY(hipMalloc((void **)&ln.ctl, ST_CTL_BYTES));
+  if (!ln.ctl_host) HIP_TRY(hipHostMalloc((void **)&ln.ctl_host, ST_CTL_BYTES, hipHostMallocDefault));
+  HIP_TRY(hipStreamSynchronize(ln.stream));
+  ln.st_cap = cap; ln.st_fin = fin_slots;
+  ln.bytes = need;
+  return FSPT_OK;
+}
+
+// Geometry of a stream run: n_batch ticks of a lane's share of the frame.
+struct StPlan {
+  uint32_t cap, unit_slots, take_max, horizon, ring_slots, units;
+};
+static int st_plan(const fspt_target *t, uint32_t units, uint32_t nbt, uint32_t nb, StPlan &pl) {
+  const bool overlap = t->stream_overlap < 0 ? ST_DEFAULT_OVERLAP : t->stream_overlap != 0;
+  pl.units = units;
+  pl.unit_slots = 64u * nbt;
+  uint64_t cap = t->pool_paths ? t->pool_paths : ST_DEFAULT_POOL;
+  // a pool larger than the run needs is memory for nothing: everything fits when cap = the run's samples
+  const uint64_t all = (uint64_t)units * pl.unit_slots;
+  if (cap > all) cap = all;
+  if (cap < 2ull * pl.unit_slots) cap = 2ull * pl.unit_slots;
+  if (t->mem_limit) {
+    // what the memory limit leaves per lane, at ~(204 + 12 * (horizon + 3) / 2) bytes per pool path
+    const uint64_t per_path = (wf_slot_bytes() - 12) + 6ull * ((t->scene->has_dielectric ? fspt::MAX_PATH_ITERS : (nb ? nb : 1u)) + 3u);
+    const uint64_t fit = t->mem_limit / t->n_lanes / per_path;
+    if (cap > fit) cap = fit;
+    if (cap < 2ull * pl.unit_slots) { fspt_set_error("the target's memory limit leaves no room for a pool of two units (%u paths)", 2u * pl.unit_slots); return FSPT_E_NOMEM; }
+  }
+  if (cap > 0x1FFFFFFFull) cap = 0x1FFFFFFFull; // k_wf_trace: 29 bits of state index
+  pl.cap = (uint32_t)cap;
+  // overlapped: plan(i) runs before logic(i) and has to leave room for every live path; one stream: it runs after
+  pl.take_max = (uint32_t)(cap / (overlap ? 2 : 1) / pl.unit_slots);
+  if (pl.take_max < 1) pl.take_max = 1;
+  // every path generated in iteration k has ended after logic(k + horizon): the bounce budget, or - when a material can
+  // refract, tracer.fs:488 - the cap on loop iterations
+  pl.horizon = t->scene->has_dielectric ? (uint32_t)fspt::MAX_PATH_ITERS : (nb ? nb : 0u);
+  const uint64_t ring_units = (uint64_t)(pl.horizon + 3u) * pl.take_max;
+  const uint64_t ring = (ring_units < units ? ring_units : units) * pl.unit_slots; // never more than the run itself
+  if (ring > 0xFFFFFFFFull) { fspt_set_error("frame too large for the stream scheduler (fin ring of %llu samples)", (unsigned long long)ring); return FSPT_E_INVALID; }
+  pl.ring_slots = (uint32_t)ring;
+  return FSPT_OK;
+}
+
+static void st_collect(fspt_target::WfLane &ln) {
+  if (!ln.ctl_pending || hipEventQuery(ln.ctl_ready) != hipSuccess) return;
+  ln.ctl_pending = false;
+  ln.stat_key = ln.ctl_key;
+  uint64_t gen = (uint64_t)ln.ctl_host->last_gen_it + 1u;
+  // the finishing launch had to generate units itself: the iterations were too few - scale the estimate up
+  const uint32_t fin = ln.ctl_host->fin_gen_units, units = ln.ctl_units;
+  if (fin && units > fin) gen = (gen * units + (units - fin) - 1) / (units - fin) + 1;
+  else if (fin) gen = gen * 2 + 1;
+  ln.stat_gen_iters = (uint32_t)(gen > 100000 ? 100000 : gen);
+}
+
+// n_ticks ticks through the stream scheduler.  Everything is enqueued without waiting for the device.
+static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
+                         const float *rb_cam, const float *rb_trace, bool rays_from_buffers) {
+  fspt::TraceP tp{};
+  fill_trace_params(t, tp);
+  const uint32_t work_total = tp.n_owned_tiles * tp.tile * tp.tile;
+  if (work_total == 0) return FSPT_OK;
+  const uint32_t units_total = work_total >> 6; // tile is a multiple of 8: whole 64-pixel patches
+  uint32_t n_pools = t->n_lanes;
+  if (n_pools > units_total) n_pools = 1;
+  const uint32_t nb = cam->num_bounces;
+  const int cus = t->scene->num_cus;
+  constexpr uint32_t R = fspt::WF_RING;
+  const bool overlap = t->stream_overlap < 0 ? ST_DEFAULT_OVERLAP : t->stream_overlap != 0;
+
+  fspt::WfP base{};
+  base.scene = t->scene->d;
+  base.W = t->W; base.H = t->H; base.vw = t->vw; base.vh = t->vh;
+  base.env_theta = cam->env_theta; base.num_bounces = nb;
+  std::memcpy(base.cam.P, cam->P, 12); std::memcpy(base.cam.I, cam->I, 12);
+  base.cam.fov_scale = cam->fov_scale; base.cam.lens[0] = cam->lens[0]; base.cam.lens[1] = cam->lens[1];
+  base.ray_pos = t->ray_pos; base.ray_dir = t->ray_dir;
+  base.accum = t->accum;
+  base.counters = t->count ? t->counters : nullptr;
+  base.shard = tp.shard; base.n_shards = tp.n_shards; base.tile = tp.tile; base.tiles_x = tp.tiles_x; base.tiles_y = tp.tiles_y;
+  base.n_owned_tiles = tp.n_owned_tiles;
+  base.gen_rays = rays_from_buffers ? 0u : 1u;
+  base.n_pools = n_pools;
+
+  // everything already queued on the target's stream (clear, ray upload, earlier renders) comes first
+  HIP_TRY(hipEventRecord(t->ev_start, t->stream));
+  for (uint32_t l = 0; l < n_pools; ++l) HIP_TRY(hipStreamWaitEvent(t->lanes[l].stream, t->ev_start, 0));
+
+  int rc = FSPT_OK;
+  auto launch = [&](int kind, const fspt::WfP &p, hipStream_t st) -> int {
+    int e = kind == fspt::WF_K_PLAN ? -1 : ev_begin(t, kind, st);
+    hipError_t err = fspt::launch_wf(kind, p, t->count, cus, st);
+    ev_end(t, e, st);
+    if (err != hipSuccess) { fspt_set_error("stream launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
+    return FSPT_OK;
+  };
+
+  uint32_t done = 0;
+  while (done < n_ticks) {
+    const uint32_t nbt = n_ticks - done < (uint32_t)fspt::WF_MAX_BATCH ? n_ticks - done : (uint32_t)fspt::WF_MAX_BATCH;
+    fspt::WfP P[2];
+    StPlan pl[2];
+    uint32_t iters[2] = {0, 0};
+    int res_done[2] = {-1, -1}; // the iteration whose cursor position marks what has been folded into the accumulator
+    for (uint32_t l = 0; l < n_pools; ++l) {
+      fspt_target::WfLane &ln = t->lanes[l];
+      const uint32_t units = (units_total - l + n_pools - 1) / n_pools;
+      if ((rc = st_plan(t, units, nbt, nb, pl[l]))) return rc;
+      const uint64_t budget = t->mem_limit ? t->mem_limit / n_pools : ~0ull;
+      if ((rc = st_ensure(t, ln, pl[l].cap, pl[l].ring_slots, budget))) return rc;
+      fspt::WfP &p = P[l];
+      p = base;
+      for (int k = 0; k < 2; ++k) {
+        fspt::WfSet &ws = p.set[k];
+        ws.A = (float4 *)ln.mem[6 * k + 0]; ws.B = (float4 *)ln.mem[6 * k + 1]; ws.C = (float4 *)ln.mem[6 * k + 2];
+        ws.E = (float4 *)ln.mem[6 * k + 3]; ws.D = (float4 *)ln.mem[6 * k + 4]; ws.P = (float4 *)ln.mem[6 * k + 5];
+      }
+      p.hit = (float2 *)ln.mem[12]; p.shadow_hit = (int *)ln.mem[13]; p.fin = (float *)ln.mem[14];
+      p.counts = ln.counts; p.heads = ln.heads; p.ctl = ln.ctl;
+      p.work_total = units * 64u; p.n_batch = nbt; p.first_tick = first_tick + done;
+      p.ring_slots = pl[l].ring_slots; p.cap = pl[l].cap; p.take_max = pl[l].take_max; p.pool = l;
+      p.serial = overlap ? 0u : 1u;
+      for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
+      // how many iterations hand out all units: what the last such run needed, else from the pool's equilibrium
+      // (about 0.45 of the pool is new samples per iteration at 30 % survival per step)
+      st_collect(ln);
+      const uint64_t key = ((uint64_t)units << 32) ^ ((uint64_t)nbt << 24) ^ ((uint64_t)nb << 16) ^ (uint64_t)pl[l].cap * 0x9E3779B97F4A7C15ull;
+      uint32_t take_eq = (uint32_t)((overlap ? 0.45 : 0.75) * pl[l].cap / pl[l].unit_slots);
+      if (take_eq > pl[l].take_max) take_eq = pl[l].take_max;
+      if (take_eq < 1) take_eq = 1;
+      uint32_t gen = (units + take_eq - 1) / take_eq + (units > take_eq ? 1u : 0u);
+      if (ln.stat_key == key && ln.stat_gen_iters) gen = ln.stat_gen_iters;
+      const uint32_t drain = t->stream_drain >= 0 ? (uint32_t)t->stream_drain : (gen > 1 ? 2u : 0u);
+      iters[l] = gen + drain;
+      if (t->stream_iter_cap && iters[l] > t->stream_iter_cap) iters[l] = t->stream_iter_cap;
+      if (iters[l] < 1) iters[l] = 1;
+      ln.ctl_key = key;
+      ln.ctl_units = units;
+      // a fresh run: cursor 0, no history, counters and pool heads zero
+      if (!ln.zeroed) {
+        HIP_TRY(hipMemsetAsync(ln.ctl, 0, ST_CTL_BYTES, ln.stream));
+        HIP_TRY(hipMemsetAsync(ln.counts, 0, ST_COUNTS_BYTES, ln.stream));
+        HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, ln.stream));
+      }
+      ln.zeroed = false;
+      HIP_TRY(hipEventRecord(ln.ev_run, ln.stream));
+      HIP_TRY(hipStreamWaitEvent(ln.stream_b, ln.ev_run, 0));
+    }
+    const uint32_t it_max = iters[0] > iters[1] ? iters[0] : iters[1];
+    for (uint32_t it = 0; it < it_max; ++it) {
+      for (uint32_t l = 0; l < n_pools; ++l) {
+        if (it >= iters[l]) continue;
+        fspt_target::WfLane &ln = t->lanes[l];
+        fspt::WfP &p = P[l];
+        hipStream_t A = ln.stream, B = overlap ? ln.stream_b : ln.stream;
+        p.round = it; p.cnt_in = (it + R - 1) % R; p.cnt_out = it % R; p.set_in = (it + 1) & 1u; p.set_out = it & 1u;
+        if (!overlap) {
+          // ---- one stream: logic(it) first, so that plan(it) sees what really survived and fills the pool to the brim
+          if (it >= 1) { if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc; }
+          if ((rc = launch(fspt::WF_K_PLAN, p, A))) return rc;
+          if ((rc = launch(fspt::WF_K_PRIMARY, p, A))) return rc;
+          const int to = (int)it - (int)pl[l].horizon; // after logic(it) every path generated up to iteration `to` has ended
+          if (to >= 0 && to > res_done[l]) {
+            p.res_from = res_done[l]; p.res_to = to;
+            if ((rc = launch(fspt::WF_K_RESOLVE, p, A))) return rc;
+            res_done[l] = to;
+          }
+          if ((rc = launch(fspt::WF_K_TRACE, p, A))) return rc;
+          continue;
+        }
+        // ---- B: plan + primary of iteration `it` (beside trace(it - 1)), then the resolve that logic(it - 1) made possible
+        if (it >= 2) HIP_TRY(hipStreamWaitEvent(B, ln.ev_logic[(it - 1) % R], 0)); // logic(it-1) read the set primary(it) writes
+        if ((rc = launch(fspt::WF_K_PLAN, p, B))) return rc;
+        if ((rc = launch(fspt::WF_K_PRIMARY, p, B))) return rc;
+        HIP_TRY(hipEventRecord(ln.ev_b[it % R], B));
+        const int to = (int)it - 1 - (int)pl[l].horizon; // after logic(it-1) every path generated up to iteration `to` has ended
+        if (to >= 0 && to > res_done[l]) {
+          p.res_from = res_done[l]; p.res_to = to;
+          if ((rc = launch(fspt::WF_K_RESOLVE, p, B))) return rc;
+          res_done[l] = to;
+        }
+        // ---- A: logic(it) on the results of trace(it - 1), then trace(it) once primary(it) has added its survivors
+        if (it >= 1) {
+          if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
+          HIP_TRY(hipEventRecord(ln.ev_logic[it % R], A));
+        }
+        HIP_TRY(hipStreamWaitEvent(A, ln.ev_b[it % R], 0));
+        if ((rc = launch(fspt::WF_K_TRACE, p, A))) return rc;
+      }
+    }
+    // ---- the end of the run: logic on the last trace's results, then the tail kernel runs whatever is alive to
+    // completion and generates whatever the cursor has not handed out; then the rest is folded into the accumulator
+    for (uint32_t l = 0; l < n_pools; ++l) {
+      fspt_target::WfLane &ln = t->lanes[l];
+      fspt::WfP &p = P[l];
+      hipStream_t A = ln.stream, B = overlap ? ln.stream_b : ln.stream;
+      const uint32_t it = iters[l];
+      p.round = it; p.cnt_in = (it + R - 1) % R; p.cnt_out = it % R; p.set_in = (it + 1) & 1u; p.set_out = it & 1u;
+      if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
+      p.finish = 1;
+      if ((rc = launch(fspt::WF_K_TAIL, p, A))) return rc;
+      HIP_TRY(hipEventRecord(ln.ev_b_last, B));
+      HIP_TRY(hipStreamWaitEvent(A, ln.ev_b_last, 0)); // the resolves so far ran on B
+      // everything the iterations handed out (up to the last plan's cursor): the units the finishing launch generated
+      // itself went straight into the accumulator
+      p.res_from = res_done[l]; p.res_to = (int)it - 1;
+      if ((rc = launch(fspt::WF_K_RESOLVE, p, A))) return rc;
+      HIP_TRY(hipMemcpyAsync(ln.ctl_host, ln.ctl, ST_CTL_BYTES, hipMemcpyDeviceToHost, A));
+      HIP_TRY(hipEventRecord(ln.ctl_ready, A));
+      ln.ctl_pending = true;
+      HIP_TRY(hipEventRecord(ln.resolved, A));
+      // cleared for the next run behind this one, not in front of the next one's first kernel
+      HIP_TRY(hipMemsetAsync(ln.ctl, 0, ST_CTL_BYTES, A));
+      HIP_TRY(hipMemsetAsync(ln.counts, 0, ST_COUNTS_BYTES, A));
+      HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, A));
+      ln.zeroed = true;
+      HIP_TRY(hipStreamWaitEvent(B, ln.resolved, 0)); // the next run's B work comes after this run
+    }
+    done += nbt;
+  }
+  for (uint32_t l = 0; l < n_pools; ++l) HIP_TRY(hipStreamWaitEvent(t->stream, t->lanes[l].resolved, 0));
   return FSPT_OK;
 }
 
@@ -942,7 +1244,8 @@ static int render_ticks(fspt_target *t, const fspt_camera_params *cam, uint32_t 
   t->ev_used = 0; t->ev_overflow = false;
   if (t->pipeline == 1) {
     HIP_TRY(hipEventRecord(t->ev0, t->stream));
-    int rc = render_wavefront(t, cam, first_tick, n_ticks, rbc, rbt, false);
+    int rc = t->sched == 1 ? render_stream(t, cam, first_tick, n_ticks, rbc, rbt, false)
+                           : render_wavefront(t, cam, first_tick, n_ticks, rbc, rbt, false);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(t->ev1, t->stream));
     t->timed = true; t->last_launches = n_ticks;
@@ -1028,7 +1331,8 @@ int fspt_trace(fspt_target *t, uint32_t tick, float rand_base, float env_theta, 
     cp.env_theta = env_theta; cp.num_bounces = num_bounces;
     t->ev_used = 0; t->ev_overflow = false;
     HIP_TRY(hipEventRecord(t->ev0, t->stream));
-    int rc = render_wavefront(t, &cp, tick, 1, nullptr, &rand_base, true);
+    int rc = t->sched == 1 ? render_stream(t, &cp, tick, 1, nullptr, &rand_base, true)
+                           : render_wavefront(t, &cp, tick, 1, nullptr, &rand_base, true);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(t->ev1, t->stream));
     t->timed = true; t->last_launches = 1;
@@ -1154,14 +1458,32 @@ int fspt_target_set_viewport(fspt_target *t, uint32_t w, uint32_t h) {
 int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks) {
   if (!t) { fspt_set_error("fspt_target_set_pipeline: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
-  if (pipeline < 0 || pipeline > 2) { fspt_set_error("pipeline must be 0 (megakernel), 1 (wavefront) or 2 (wavefront, two lanes)"); return FSPT_E_INVALID; }
+  if (pipeline < 0 || pipeline > 4) { fspt_set_error("pipeline must be 0 (megakernel), 1 (wavefront batches), 2 (wavefront batches, two lanes), 3 (wavefront stream) or 4 (wavefront stream, two pools)"); return FSPT_E_INVALID; }
+  const bool two = pipeline == 2 || pipeline == 4;
   if (batch_ticks > (uint32_t)fspt::WF_MAX_BATCH * (pipeline == 2 ? 2u : 1u)) {
     fspt_set_error("batch_ticks must be <= %d per lane", fspt::WF_MAX_BATCH);
     return FSPT_E_INVALID;
   }
-  t->pipeline = pipeline == 2 ? 1 : pipeline;
-  t->n_lanes = pipeline == 2 ? 2u : 1u;
+  const int sched = pipeline >= 3 ? 1 : 0;
+  if (pipeline != 0 && (sched != t->sched || (two ? 2u : 1u) != t->n_lanes)) {
+    // the two schedulers size the lanes' memory differently: give it back (the next render allocates what it needs)
+    HIP_TRY(hipSetDevice(t->scene->device));
+    for (auto &ln : t->lanes) wf_release(ln);
+  }
+  t->pipeline = pipeline == 0 ? 0 : 1;
+  if (pipeline != 0) { t->sched = sched; t->n_lanes = two ? 2u : 1u; }
   if (batch_ticks) t->batch_ticks = batch_ticks;
+  return FSPT_OK;
+}
+
+int fspt_target_set_pool(fspt_target *t, uint32_t paths, int drain_iterations, uint32_t max_iterations, int overlap) {
+  if (!t) { fspt_set_error("fspt_target_set_pool: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
+  if (drain_iterations < -1 || drain_iterations > FSPT_MAX_BOUNCES + 1) { fspt_set_error("fspt_target_set_pool: drain_iterations must be -1 (default) or 0..%d", FSPT_MAX_BOUNCES + 1); return FSPT_E_INVALID; }
+  t->pool_paths = paths;
+  t->stream_drain = drain_iterations;
+  t->stream_iter_cap = max_iterations;
+  t->stream_overlap = overlap < 0 ? -1 : (overlap ? 1 : 0);
   return FSPT_OK;
 }
 
@@ -1196,7 +1518,7 @@ int fspt_target_set_memory_limit(fspt_target *t, uint64_t bytes) {
 int fspt_target_path_state_bytes(fspt_target *t, uint64_t *bytes, uint32_t *batch_ticks) {
   if (!t || !bytes) { fspt_set_error("fspt_target_path_state_bytes: NULL argument"); return FSPT_E_INVALID; }
   uint64_t b = 0;
-  for (auto &ln : t->lanes) b += (uint64_t)ln.slots * wf_slot_bytes();
+  for (auto &ln : t->lanes) b += ln.bytes;
   *bytes = b;
   if (batch_ticks) *batch_ticks = t->batch_ticks;
   return FSPT_OK;
@@ -1211,6 +1533,19 @@ int fspt_target_prepare(fspt_target *t) {
   fill_trace_params(t, tp);
   const uint64_t work_total = (uint64_t)tp.n_owned_tiles * tp.tile * tp.tile;
   if (work_total == 0) return FSPT_OK;
+  if (t->sched == 1) {
+    // the pool of the configured steady state: runs of batch_ticks ticks (at most WF_MAX_BATCH per run)
+    const uint32_t units_total = (uint32_t)(work_total >> 6);
+    const uint32_t n_pools = t->n_lanes > units_total ? 1u : t->n_lanes;
+    const uint32_t nbt = t->batch_ticks < (uint32_t)fspt::WF_MAX_BATCH ? (t->batch_ticks ? t->batch_ticks : 1u) : (uint32_t)fspt::WF_MAX_BATCH;
+    for (uint32_t l = 0; l < n_pools; ++l) {
+      StPlan pl;
+      int rc = st_plan(t, (units_total - l + n_pools - 1) / n_pools, nbt, clamp_bounces(t->last_cam.num_bounces ? t->last_cam.num_bounces : 8u), pl);
+      if (rc == FSPT_OK) rc = st_ensure(t, t->lanes[l], pl.cap, pl.ring_slots, t->mem_limit ? t->mem_limit / n_pools : ~0ull);
+      if (rc) return rc;
+    }
+    return FSPT_OK;
+  }
   uint32_t n_lanes, per_lane;
   return wf_plan_and_ensure(t, work_total, 0, n_lanes, per_lane);
 }
@@ -1242,7 +1577,7 @@ int fspt_counters_reset(fspt_target *t) {
   if (!t) { fspt_set_error("fspt_counters_reset: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
   HIP_TRY(hipSetDevice(t->scene->device));
-  HIP_TRY(hipMemsetAsync(t->counters, 0, 48, t->stream));
+  HIP_TRY(hipMemsetAsync(t->counters, 0, 64, t->stream));
   return FSPT_OK;
 }
 
@@ -1255,6 +1590,17 @@ int fspt_get_counters(fspt_target *t, fspt_counters *out) {
   HIP_TRY(hipStreamSynchronize(t->stream));
   out->samples = v[0]; out->rays = v[1]; out->steps = v[2]; out->leaves = v[3]; out->shades = v[4];
   out->env_lookups = v[5];
+  return FSPT_OK;
+}
+
+int fspt_get_trace_lds_steps(fspt_target *t, uint64_t *steps) {
+  if (!t || !steps) { fspt_set_error("fspt_get_trace_lds_steps: NULL argument"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
+  HIP_TRY(hipSetDevice(t->scene->device));
+  unsigned long long v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, t->counters + 6, 8, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  *steps = v;
   return FSPT_OK;
 }
 

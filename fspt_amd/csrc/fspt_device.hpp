@@ -161,6 +161,41 @@ struct alignas(128) WfCounts { // one per round, zeroed before the batch
 
 struct WfSet { float4 *A, *B, *C, *E, *D, *P; };
 
+// ---------------------------------------------------------------------------
+// Streaming scheduler (fspt_target_set_pipeline code 3 / 4): a FIXED pool of path state that is kept full.
+//   The (work index, tick) samples of a run of n_batch ticks are numbered pixel-major exactly like a batch's slots
+//   (g = w * n_batch + j) and cut into UNITS of 64 work indices x n_batch ticks (one 8x8 pixel patch, all its ticks).
+//   Iteration i:   plan(i)    takes as many units from the device-side cursor as are GUARANTEED to fit the state set:
+//                             cap - (live paths of set i-1)  - every live path may survive, every new sample may too
+//                  primary(i) camera rays + their traversal + shading for those units; survivors -> set i&1
+//                  logic(i)   one S step for the live paths of set (i-1)&1; survivors -> set i&1 (same counter)
+//                  trace(i)   the rays of set i&1
+//                  resolve    folds the units whose every path has ended (generated >= num_bounces iterations ago;
+//                             MAX_PATH_ITERS when a material can refract) into the accumulator, ticks in order
+//   so every trace / logic launch is about the size of the pool whatever the call's tick count, paths of all ages
+//   mixed; path state is cap x 204 bytes + a ring of finished colours, not (pixels x ticks) x 216 bytes.  plan /
+//   primary / resolve run on a second stream beside the previous iteration's trace.  After the last iteration the tail
+//   kernel runs whatever is alive to completion AND generates whatever the cursor has not handed out (the host only
+//   estimates the iteration count; nothing depends on the estimate but speed).
+//   fin is a RING of ring_slots entries (a multiple of the unit size, > everything in flight); the slot id a path
+//   carries is its ring position (slot % n_batch is still its tick).
+// ---------------------------------------------------------------------------
+constexpr int WF_RING = 4;    // iterations whose counters / pool heads exist at the same time (even: set parity = index parity)
+constexpr int WF_HIST = 128;  // cursor history kept for the resolve (> MAX_PATH_ITERS + 2)
+struct alignas(128) WfStreamCtl {
+  uint32_t cursor;       // next unit nobody has generated yet (may overshoot the run's units, work_total / 64, at the very end)
+  uint32_t reserved;
+  uint32_t n_iters;      // statistics of the run, read back by the host without waiting (tunes its iteration estimate)
+  uint32_t last_gen_it;  // last iteration that took units
+  uint32_t max_live;
+  uint32_t fin_gen_units; // units the finishing tail launch had to generate itself
+  uint32_t pad[26];
+  unsigned long long sum_live;
+  unsigned long long pad2[15];
+  uint32_t plan_start[WF_RING], plan_units[WF_RING]; // iteration i's chunk of units
+  uint32_t hist[WF_HIST]; // cursor after plan(i), i % WF_HIST
+};
+
 struct WfP {
   uint32_t gen_rays; // primary launch: 1 = camera.fs in the kernel, 0 = read the ray buffers (two-call form)
   uint32_t lds_top; // top-of-tree nodes k_wf_trace keeps in LDS (<= scene.n_top; set by launch_wf)
@@ -171,7 +206,17 @@ struct WfP {
   int *shadow_hit;
   WfCounts *counts;
   uint32_t *heads; // pool heads, see above
-  uint32_t round;
+  uint32_t round;  // batch scheduler: the round (1 = primary); stream: the iteration
+  // which counter / state set a launch reads and writes (batch: round - 1 / round; stream: iteration mod WF_RING)
+  uint32_t cnt_in, cnt_out, set_in, set_out;
+  WfStreamCtl *ctl;     // NULL = batch scheduler
+  uint32_t ring_slots;  // entries of the fin ring (batch: n_batch * work_total = no wrap)
+  uint32_t cap;         // stream: paths a state set holds
+  uint32_t take_max;    // stream: units plan(i) takes at most
+  uint32_t pool, n_pools; // stream: this lane traces units u * n_pools + pool of the frame (1 pool: all)
+  int res_from, res_to; // resolve (stream): fold the units between hist[res_from] (< 0: unit 0) and hist[res_to] (-2: all)
+  uint32_t finish;      // tail (stream): also generate what the cursor has not handed out
+  uint32_t serial;      // plan (stream): it runs AFTER logic(i) (one HIP stream) and sees the real survivors in counts[cnt_out]
   uint32_t W, H;
   uint32_t vw, vh; // viewport, as in TraceP
   uint32_t work_total; // work indices per tick (owned tiles * tile^2)
@@ -189,7 +234,7 @@ struct WfP {
 };
 
 // kernel classes; also the slots of fspt_last_stage_ms
-enum { WF_K_PRIMARY = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3, WF_K_TAIL = 4, WF_K_KINDS = 5 };
+enum { WF_K_PRIMARY = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3, WF_K_TAIL = 4, WF_K_KINDS = 5, WF_K_PLAN = 5 /* not timed */ };
 // count: 0 = production kernels; 1 = counting variants doing the reference's work (NEE shadow rays traced to the closest
 // hit, tracer.fs:501); 2 = counting variants of the production work (shadow rays stop at the first hit)
 hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream_t stream);

@@ -753,6 +753,13 @@ FM_DEV bool work_to_pixel(const P &p, uint32_t idx, uint32_t &x, uint32_t &y) {
   return x < p.vw && y < p.vh;
 }
 
+// Sample number g of a run (pixel-major: n_batch ticks per work index) -> work index.  With several pools (stream
+// scheduler, fspt_device.hpp) a pool's units - 64 work indices each - are every n_pools-th unit of the frame.
+FM_DEV uint32_t wf_work_index(const WfP &p, uint32_t g) {
+  const uint32_t w = g / p.n_batch;
+  return p.n_pools > 1u ? ((w >> 6) * p.n_pools + p.pool) * 64u + (w & 63u) : w;
+}
+
 // ---------------------------------------------------------------------------
 // The path-trace kernel: tracer.fs main() (436-518) over the whole frame.
 // ---------------------------------------------------------------------------
@@ -1029,8 +1036,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   const float4 *__restrict__ nodes = S.nodes;
   const float *__restrict__ leaves = S.leaves;
   const uint32_t leaf_size = S.leaf_size;
-  const WfSet st = p.set[p.round & 1];
-  WfCounts *cn = p.counts + p.round;
+  const WfSet st = p.set[p.set_out];
+  WfCounts *cn = p.counts + p.cnt_out;
   const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
   const uint32_t total = cn->n_ext;
 
@@ -1074,7 +1081,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   if (wave_id < n_chunks) chunk_range(wave_id, pool_next, pool_end); // chunk `wave_id` is the wave's own
   bool exhausted = n_chunks <= n_waves; // nothing beyond the waves' own chunks
 
-  uint32_t c_rays = 0, c_steps = 0, c_leaves = 0;
+  uint32_t c_rays = 0, c_steps = 0, c_leaves = 0, c_lds = 0;
   bool idle = true;
   bool is_shadow = false;
   // state index of the lane's path; bit 31: the path's bounce budget is used up (a hit of its extension ray will not be
@@ -1094,7 +1101,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
       if (avail == 0u) {
         if (exhausted) break;
         uint32_t j = 0;
-        if (lane == 0) j = atomicAdd(&p.heads[((size_t)p.round * WF_HEADS + stripe) * WF_HEAD_STRIDE], 1u);
+        if (lane == 0) j = atomicAdd(&p.heads[((size_t)p.cnt_out * WF_HEADS + stripe) * WF_HEAD_STRIDE], 1u);
         j = __builtin_amdgcn_readfirstlane(j);
         const unsigned long long c = (unsigned long long)n_waves + (unsigned long long)j * WF_HEADS + stripe;
         if (c >= n_chunks) { exhausted = true; break; }
@@ -1147,6 +1154,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
       float4 n0, n1, n2;
       int2 n3;
       if (cur < n_top) {
+        if (COUNT) c_lds++;
         // explicit LDS address space: keeps these ds_read_b128 from being merged with the global path into flat loads
         typedef float lds_f4 __attribute__((ext_vector_type(4)));
         typedef int lds_i2 __attribute__((ext_vector_type(2)));
@@ -1222,12 +1230,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     }
   }
   if (COUNT) {
-    unsigned long long v[3] = {c_rays, c_steps, c_leaves};
+    unsigned long long v[4] = {c_rays, c_steps, c_leaves, c_lds};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
       unsigned long long x = v[i];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
-      if (lane == 0 && x) atomicAdd(p.counters + 1 + i, x);
+      if (lane == 0 && x) atomicAdd(p.counters + (i < 3 ? 1 + i : 6), x); // [6]: interior steps served from the LDS copy of the top of the tree
     }
   }
 }
@@ -1277,6 +1285,20 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   DScene S = p.scene;
+  const WfSet out = p.set[p.set_out];
+  WfCounts *cn = p.counts + p.cnt_out;
+  // the samples of this launch: the whole batch, or (stream) the units plan(i) took from the cursor.  g = first + i is
+  // the sample's number in the run (pixel-major: work index g / n_batch, tick g % n_batch), ring0 + i (mod ring_slots)
+  // its place in the fin ring = the slot id the path carries.
+  const uint32_t unit_slots = 64u * p.n_batch;
+  uint32_t first = 0, n_in = p.n_batch * p.work_total, ring0 = 0;
+  if (p.ctl) {
+    const uint32_t u0 = p.ctl->plan_start[p.round % WF_RING], nu = p.ctl->plan_units[p.round % WF_RING];
+    if (nu == 0u) return; // nothing to generate in this iteration (cursor exhausted, or no room in the pool)
+    first = u0 * unit_slots;
+    n_in = nu * unit_slots;
+    ring0 = (uint32_t)(((unsigned long long)u0 * unit_slots) % p.ring_slots);
+  }
   if (LDSTAB) {
     for (uint32_t i = threadIdx.x; i < S.n_tex_sets * 3u; i += WF_LOGIC_THREADS) s_sets[i] = p.scene.tex_sets[i];
     for (uint32_t i = threadIdx.x; i < S.n_bins; i += WF_LOGIC_THREADS) s_bins[i] = p.scene.bins[i];
@@ -1285,9 +1307,6 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
     S.bins = s_bins;
     __syncthreads();
   }
-  const WfSet out = p.set[1];
-  const uint32_t n_in = p.n_batch * p.work_total;
-  WfCounts *cn = p.counts + 1;
   Counters cnt = {0, 0, 0, 0, 0, 0};
   int *stack = lds_dyn + (size_t)wave * S.stack_n * WAVE + lane;
 
@@ -1301,14 +1320,15 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t i = base + (uint32_t)u * WF_LOGIC_THREADS + threadIdx.x;
+      const uint32_t g = first + i;
       uint32_t fx = 0, fy = 0;
-      bool valid = i < n_in && work_to_pixel(p, i / p.n_batch, fx, fy);
+      bool valid = i < n_in && work_to_pixel(p, wf_work_index(p, g), fx, fy);
       V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
       float tB = MAX_T;
       int hitB = -1;
       if (valid) {
         if (p.gen_rays) {
-          camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[i % p.n_batch], o, d);
+          camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[g % p.n_batch], o, d);
         } else {
           float4 po = p.ray_pos[fy * p.W + fx], di = p.ray_dir[fy * p.W + fx];
           o = v3(po.x, po.y, po.z);
@@ -1336,6 +1356,8 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
     for (int u = 0; u < U; ++u) {
       if (!valid_u[u]) continue;
       const uint32_t i = base + (uint32_t)u * WF_LOGIC_THREADS + threadIdx.x;
+      uint32_t slot = ring0 + i; // < 2 * ring_slots: a launch is shorter than the ring
+      if (slot >= p.ring_slots) slot -= p.ring_slots;
       Path ps;
       ps.ro = o_u[u]; ps.rd = d_u[u];
       ps.thr = v3(1.0f, 1.0f, 1.0f);
@@ -1345,11 +1367,11 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
       ps.wx = ps.wy = 0.0f;
       ps.bounce = 0; ps.iters = 0; ps.pix = 0;
       ps.hasShadow = false; ps.primary = true;
-      const uint32_t j = i % p.n_batch;
+      const uint32_t j = (first + i) % p.n_batch;
       const bool finished = advance_path<COUNT>(S, ps, -1, t_u[u], hit_u[u], LDSTAB ? s_rb[j] : p.rb_trace[j], p.env_theta,
                                                 p.num_bounces, cnt);
-      if (finished) st3(p.fin + 3 * (size_t)i, ps.color);
-      else store_path(out, s_base + s_cnt[u][wave] + lane_rank(m_surv[u]), ps, i);
+      if (finished) st3(p.fin + 3 * (size_t)slot, ps.color);
+      else store_path(out, s_base + s_cnt[u][wave] + lane_rank(m_surv[u]), ps, slot);
     }
     __syncthreads();
   }
@@ -1384,9 +1406,9 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
     S.bins = s_bins;
   }
   __syncthreads();
-  const WfSet in = p.set[(p.round - 1) & 1], out = p.set[p.round & 1];
-  const uint32_t n_in = p.counts[p.round - 1].n_ext;
-  WfCounts *cn = p.counts + p.round;
+  const WfSet in = p.set[p.set_in], out = p.set[p.set_out];
+  const uint32_t n_in = p.counts[p.cnt_in].n_ext;
+  WfCounts *cn = p.counts + p.cnt_out;
   Counters cnt = {0, 0, 0, 0, 0, 0};
 
   // paths per thread and iteration: as many as keep every block busy, at most U
@@ -1522,15 +1544,21 @@ FM_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src, WAVE), __shfl(v.y, s
 #ifndef WF_TAIL_WAVES
 #define WF_TAIL_WAVES 4
 #endif
-template <bool COUNT, bool ANYHIT>
+// GEN (stream scheduler, the last launch of a run): when the list is used up the wave also takes whole UNITS the cursor
+// has not handed out (the host only estimated how many iterations the run needs) and runs their samples itself.  A
+// pair then owns a PIXEL: it generates and traces the pixel's ticks one after the other and folds every finished
+// sample into the pixel's accumulator value in its registers, in tick order (tracer.fs:515-517 is order-dependent) -
+// nothing of such a unit goes through the fin ring, and the run's last resolve ends where this launch began
+// (WfStreamCtl::hist of the last plan).
+template <bool COUNT, bool ANYHIT, bool GEN>
 __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const WfP p) {
   extern __shared__ int lds_stack[];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   const DScene &S = p.scene;
   int *stack = lds_stack + (size_t)wave * S.stack_n * WAVE + lane;
-  const WfSet in = p.set[p.round & 1];
-  WfCounts *cn = p.counts + p.round;
+  const WfSet in = p.set[p.set_out];
+  WfCounts *cn = p.counts + p.cnt_out;
   const uint32_t total = cn->n_ext;
   Counters cnt = {0, 0, 0, 0, 0, 0};
   const bool is_main = (lane & 1) == 0;
@@ -1548,16 +1576,23 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
   const uint32_t n_chunks = (total + PAIRS - 1u) / PAIRS;
   uint32_t pool_next = min(wave_id * PAIRS, total), pool_end = min(wave_id * PAIRS + PAIRS, total);
   bool exhausted = n_chunks <= n_waves;
+  // GEN: the pair's own pixel (work index; -1 none), the tick its current path is, the pixel's accumulator value so far
+  int g_w = -1;
+  uint32_t g_j = 0, g_pix = 0;
+  bool g_path = false; // the pair's current path is one it generated (its result goes to g_acc, not to fin)
+  float4 g_acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  uint32_t gen_next = 0, gen_end = 0; // work indices [gen_next, gen_end) of the wave's current unit not yet given to a pair
+  bool gen_done = !GEN;
   while (true) {
     // ---- refill idle pairs with paths of the list ----
     while (true) {
-      unsigned long long need = __ballot(is_main && ps.pix < 0);
+      unsigned long long need = __ballot(is_main && ps.pix < 0 && g_w < 0);
       if (need == 0ull) break;
       uint32_t avail = pool_end - pool_next;
       if (avail == 0u) {
         if (exhausted) break;
         uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&p.heads[((size_t)p.round * WF_HEADS + stripe) * WF_HEAD_STRIDE], 1u);
+        if (lane == 0) b = atomicAdd(&p.heads[((size_t)p.cnt_out * WF_HEADS + stripe) * WF_HEAD_STRIDE], 1u);
         b = __builtin_amdgcn_readfirstlane(b);
         const unsigned long long c = (unsigned long long)n_waves + (unsigned long long)b * WF_HEADS + stripe;
         if (c >= n_chunks) { exhausted = true; break; }
@@ -1568,12 +1603,65 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
       uint32_t rank = lane_rank(need);
       uint32_t want = (uint32_t)__popcll(need);
       uint32_t take = want < avail ? want : avail;
-      if (is_main && ps.pix < 0 && rank < take) {
+      if (is_main && ps.pix < 0 && g_w < 0 && rank < take) {
         int unused;
         slot = load_path(in, pool_next + rank, ps, nullptr, unused);
         ps.pix = 0;
       }
       pool_next += take;
+    }
+    if (GEN && exhausted && pool_end == pool_next) {
+      // ---- the list is used up: idle pairs without a pixel take one from the wave's unit (units from the cursor) ----
+      while (!gen_done) {
+        unsigned long long need = __ballot(is_main && ps.pix < 0 && g_w < 0);
+        if (need == 0ull) break;
+        if (gen_next == gen_end) {
+          uint32_t u = 0;
+          if (lane == 0) u = atomicAdd(&p.ctl->cursor, 1u);
+          u = __builtin_amdgcn_readfirstlane(u);
+          if (u >= (p.work_total >> 6)) { gen_done = true; break; }
+          if (lane == 0) atomicAdd(&p.ctl->fin_gen_units, 1u);
+          gen_next = u * 64u;
+          gen_end = gen_next + 64u;
+        }
+        const uint32_t left = gen_end - gen_next;
+        const uint32_t rank = lane_rank(need), want = (uint32_t)__popcll(need);
+        const uint32_t take = want < left ? want : left;
+        if (is_main && ps.pix < 0 && g_w < 0 && rank < take) {
+          uint32_t fx = 0, fy = 0;
+          const uint32_t w = p.n_pools > 1u ? (((gen_next + rank) >> 6) * p.n_pools + p.pool) * 64u + ((gen_next + rank) & 63u) : gen_next + rank;
+          if (work_to_pixel(p, w, fx, fy)) { // (a pixel outside the viewport does not exist)
+            g_w = (int)w;
+            g_j = 0;
+            g_pix = fy * p.W + fx;
+            g_acc = p.accum[g_pix];
+            g_path = false;
+          }
+        }
+        gen_next += take;
+      }
+      // ---- pairs that own a pixel and have no path: the pixel's next tick ----
+      if (is_main && ps.pix < 0 && g_w >= 0) {
+        const uint32_t fx = g_pix % p.W, fy = g_pix / p.W;
+        if (p.gen_rays) {
+          camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[g_j], ps.ro, ps.rd);
+        } else {
+          const float4 po = p.ray_pos[g_pix], di = p.ray_dir[g_pix];
+          ps.ro = v3(po.x, po.y, po.z);
+          ps.rd = v3(di.x, di.y, di.z);
+        }
+        ps.thr = v3(1.0f, 1.0f, 1.0f);
+        ps.color = v3(0.0f, 0.0f, 0.0f);
+        ps.envDir = v3(0.0f, 0.0f, 1.0f);
+        ps.pend = v3(0.0f, 0.0f, 0.0f);
+        ps.wx = ps.wy = 0.0f;
+        ps.bounce = 0; ps.iters = 0;
+        ps.hasShadow = false; ps.primary = true;
+        ps.pix = 0;
+        slot = g_j; // (only its tick is used: slot % n_batch)
+        g_path = true;
+        if (COUNT) cnt.samples++;
+      }
     }
     if (__ballot(is_main && ps.pix >= 0) == 0ull) break;
     // ---- T: even lanes trace their path's extension ray, odd lanes the same path's shadow ray ----
@@ -1591,12 +1679,18 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
     // ---- S: consume them ----
     if (m_live) {
       if (advance_path<COUNT>(S, ps, hitA, tR, hitR, p.rb_trace[slot % p.n_batch], p.env_theta, p.num_bounces, cnt)) {
-        st3(p.fin + 3 * (size_t)slot, ps.color);
+        if (GEN && g_path) {
+          g_acc = accumulate_sample(g_acc, ps.color, p.first_tick + g_j);
+          g_path = false;
+          if (++g_j == p.n_batch) { p.accum[g_pix] = g_acc; g_w = -1; }
+        } else {
+          st3(p.fin + 3 * (size_t)slot, ps.color);
+        }
         ps.pix = -1;
       }
     }
   }
-  flush_counters<COUNT>(cnt, p.counters, 1, lane);
+  flush_counters<COUNT>(cnt, p.counters, GEN ? 0 : 1, lane);
 }
 
 // ---- resolve: tracer.fs:515-517 for the batch's ticks in order, per pixel --------------
@@ -1607,11 +1701,21 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
   __shared__ float4 s_t[WAVES_PER_BLOCK][WAVE * (WF_RESOLVE_TICKS + 1)];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
-  for (uint32_t wb = blockIdx.x * BLOCK_THREADS; wb < p.work_total; wb += gridDim.x * BLOCK_THREADS) { // block-uniform trip count
-    const uint32_t w0 = wb + (uint32_t)wave * WAVE;
-    const uint32_t w = w0 + lane;
+  // one wave per UNIT (64 consecutive work indices = one 8x8 pixel patch, all n_batch ticks).  Batch scheduler: every
+  // unit of the batch; stream: the units between two recorded positions of the cursor (fspt_device.hpp).
+  const uint32_t unit_slots = 64u * p.n_batch;
+  uint32_t u0 = 0, u1 = p.work_total >> 6;
+  if (p.ctl) {
+    u0 = p.res_from < 0 ? 0u : p.ctl->hist[p.res_from % WF_HIST];
+    u1 = p.res_to == -2 ? (p.work_total >> 6) : (p.res_to < 0 ? 0u : p.ctl->hist[p.res_to % WF_HIST]);
+  }
+  for (uint32_t ub = u0 + blockIdx.x * WAVES_PER_BLOCK; ub < u1; ub += gridDim.x * WAVES_PER_BLOCK) { // block-uniform trip count
+    const uint32_t unit = ub + (uint32_t)wave;
+    const bool unit_ok = unit < u1;
+    const uint32_t w = wf_work_index(p, unit * unit_slots + (uint32_t)lane * p.n_batch);
+    const size_t fin0 = (size_t)(((unsigned long long)unit * unit_slots) % p.ring_slots); // the unit's place in the fin ring
     uint32_t x = 0, y = 0;
-    const bool ok = w < p.work_total && work_to_pixel(p, w, x, y);
+    const bool ok = unit_ok && work_to_pixel(p, w, x, y);
     const uint32_t pix = y * p.W + x;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (ok) acc = p.accum[pix];
@@ -1620,9 +1724,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
 #pragma unroll
       for (int q = 0; q < WF_RESOLVE_TICKS; ++q) {
         const uint32_t pp = (uint32_t)q * (WAVE / WF_RESOLVE_TICKS) + ((uint32_t)lane / WF_RESOLVE_TICKS);
-        const uint32_t w2 = w0 + pp;
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (w2 < p.work_total && tt < p.n_batch) { const V3 c = ld3(p.fin + 3 * ((size_t)w2 * p.n_batch + tt)); v = make_float4(c.x, c.y, c.z, 0.0f); }
+        if (unit_ok && tt < p.n_batch) { const V3 c = ld3(p.fin + 3 * (fin0 + (size_t)pp * p.n_batch + tt)); v = make_float4(c.x, c.y, c.z, 0.0f); }
         s_t[wave][pp * (WF_RESOLVE_TICKS + 1) + ((uint32_t)lane & (WF_RESOLVE_TICKS - 1))] = v;
       }
       __syncthreads();
@@ -1639,6 +1742,35 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
     }
     if (ok) p.accum[pix] = acc;
   }
+}
+
+// ---- plan (stream scheduler): how many units iteration p.round generates -------------------------
+// One thread decides, before primary(i) / logic(i) start: every live path of the previous set may survive logic(i) and
+// every new sample may survive its first shading, so  units <= (cap - live(i-1)) / unit size  can never overflow set i.
+// Also zeroes the counter and the pool heads of iteration i + 1 (nobody uses them yet: fspt_api.cpp render_stream).
+__global__ __launch_bounds__(WAVE) void k_wf_plan(const WfP p) {
+  WfStreamCtl *c = p.ctl;
+  const uint32_t nxt = (p.cnt_out + 1u) % WF_RING;
+  if (threadIdx.x < WF_HEADS) p.heads[((size_t)nxt * WF_HEADS + threadIdx.x) * WF_HEAD_STRIDE] = 0u;
+  if (threadIdx.x != 0) return;
+  p.counts[nxt].n_ext = 0u;
+  const uint32_t unit_slots = 64u * p.n_batch;
+  // paths set i may have to hold besides the new ones: everything alive in set i-1 (logic(i) has yet to run), or -
+  // one-stream form, logic(i) is done - the survivors it has already written
+  const uint32_t live = p.serial ? p.counts[p.cnt_out].n_ext : (p.round == 0u ? 0u : p.counts[p.cnt_in].n_ext);
+  const uint32_t room = p.cap > live ? (p.cap - live) / unit_slots : 0u;
+  const uint32_t total_units = p.work_total >> 6;
+  const uint32_t cur = c->cursor, left = total_units > cur ? total_units - cur : 0u;
+  uint32_t take = p.take_max < room ? p.take_max : room;
+  if (take > left) take = left;
+  c->plan_start[p.round % WF_RING] = cur;
+  c->plan_units[p.round % WF_RING] = take;
+  c->cursor = cur + take;
+  c->hist[p.round % WF_HIST] = cur + take;
+  c->n_iters = p.round + 1u;
+  if (take) c->last_gen_it = p.round;
+  if (live > c->max_live) c->max_live = live;
+  c->sum_live += live;
 }
 
 // multi-device read-out (fspt_multi_read_radiance): pack a shard's own pixels into work-index order / scatter them back
@@ -1831,9 +1963,18 @@ size_t wf_max_stack_entries() {
 }
 
 hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream_t stream) {
-  const uint32_t total = p.n_batch * p.work_total;
+  // the most paths / samples the launch can have to process (sizes the grid; the kernels read the real counts)
+  uint32_t total = p.n_batch * p.work_total;
   if (total == 0) return hipSuccess;
+  if (p.ctl) {
+    const unsigned long long lim = kernel == WF_K_PRIMARY ? (unsigned long long)p.take_max * 64ull * p.n_batch : (unsigned long long)p.cap;
+    if (kernel != WF_K_RESOLVE && !(kernel == WF_K_TAIL && p.finish) && lim < total) total = (uint32_t)lim;
+  }
   hipError_t e = hipSuccess;
+  if (kernel == WF_K_PLAN) {
+    hipLaunchKernelGGL(k_wf_plan, dim3(1), dim3(WAVE), 0, stream, p);
+    return hipGetLastError();
+  }
   if (kernel == WF_K_TRACE) {
     // persistent: the grid only has to fill the machine; the pool heads balance the work
     uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
@@ -1864,8 +2005,13 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
     size_t lds = stack_bytes(p.scene);
 #define FSPT_LAUNCH_TAIL(C, A)                                                                             \
     do {                                                                                                     \
-      if ((e = allow_lds(k_wf_tail<C, A>, lds)) != hipSuccess) return e;                                     \
-      hipLaunchKernelGGL((k_wf_tail<C, A>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);                \
+      if (p.ctl && p.finish) {                                                                               \
+        if ((e = allow_lds(k_wf_tail<C, A, true>, lds)) != hipSuccess) return e;                             \
+        hipLaunchKernelGGL((k_wf_tail<C, A, true>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);        \
+      } else {                                                                                               \
+        if ((e = allow_lds(k_wf_tail<C, A, false>, lds)) != hipSuccess) return e;                            \
+        hipLaunchKernelGGL((k_wf_tail<C, A, false>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);       \
+      }                                                                                                      \
     } while (0)
     if (count == 1) FSPT_LAUNCH_TAIL(true, false);
     else if (count == 2) FSPT_LAUNCH_TAIL(true, true);

@@ -538,6 +538,17 @@ static napi_value SetPipeline(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_target_set_pipeline((fspt_target *)h, p, b));
   return undefined(env);
 }
+static napi_value SetPool(napi_env env, napi_callback_info info) {
+  /* setPool(target, paths, drainIterations, maxIterations, overlap): fspt_target_set_pool (stream scheduler) */
+  napi_value a[5]; void *h; uint32_t paths, cap; int32_t drain, overlap;
+  if (get_args(env, info, 5, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &paths));
+  NAPI_OK(napi_get_value_int32(env, a[2], &drain));
+  NAPI_OK(napi_get_value_uint32(env, a[3], &cap));
+  NAPI_OK(napi_get_value_int32(env, a[4], &overlap));
+  FSPT_OK_OR_THROW(fspt_target_set_pool((fspt_target *)h, paths, drain, cap, overlap));
+  return undefined(env);
+}
 static napi_value SetMemoryLimit(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; double bytes;
   if (get_args(env, info, 2, a) || unwrap(env, a[0], &h) || get_f64(env, a[1], &bytes)) return NULL;
@@ -840,7 +851,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   struct { const char *name; napi_callback fn; } fns[] = {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"traceTest", TraceTest}, {"render", Render}, {"clear", Clear},
-      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline},
+      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline}, {"setPool", SetPool},
       {"setMemoryLimit", SetMemoryLimit}, {"setTextureInterleaveBudget", SetTextureInterleaveBudget}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail}, {"setDeferred", SetDeferred},
       {"renderAsync", RenderAsync}, {"multiCreate", MultiCreate}, {"multiDestroy", MultiDestroy}, {"multiTarget", MultiTarget},
       {"multiCamera", MultiCamera}, {"multiTrace", MultiTrace}, {"multiRender", MultiRender}, {"multiRenderAsync", MultiRenderAsync},

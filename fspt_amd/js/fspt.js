@@ -296,6 +296,8 @@ function loadBlob(path) {
     atlasLayers: m[1], env: secs.env || null, envW: m[2], envH: m[3], bins: secs.bins, leafSize: m[4], depth: m[5] };
 }
 
+const PIPELINE_CODES = { megakernel: 0, wavefront: 1, wavefront2: 2, stream: 3, stream2: 4 };
+
 class PathTracer {
   /** scene: {bvh,tri,mat,norm,uv,atlas,atlasRes,atlasLayers,env,envW,envH,bins,leafSize} */
   constructor(scene, width, height, device) {
@@ -346,7 +348,10 @@ class PathTracer {
   /** gl.viewport(0, 0, w, h) of drawCamera / drawTracer (main.js:744,761); the reference: resolution * resScale. */
   setViewport(w, h) { addon.setViewport(this._target, w || 0, h || 0); }
   setShard(shard, nShards, tile) { addon.setShard(this._target, shard, nShards, tile || 32); }
-  setPipeline(name, batch) { addon.setPipeline(this._target, name === 'megakernel' ? 0 : (name === 'wavefront2' ? 2 : 1), batch || 0); }
+  /** 'wavefront' (batches of ticks), 'stream' (fixed pool of live paths), 'stream2', 'megakernel', 'wavefront2' (include/fspt.h) */
+  setPipeline(name, batch) { addon.setPipeline(this._target, PIPELINE_CODES[name] === undefined ? 1 : PIPELINE_CODES[name], batch || 0); }
+  /** stream scheduler: live paths per state set (0 = default), drain iterations (-1 = default), iteration cap (0 = none) */
+  setPool(paths, drain, maxIterations, overlap) { addon.setPool(this._target, paths || 0, drain === undefined ? -1 : drain, maxIterations || 0, overlap === undefined ? -1 : overlap); }
   /** -1 adaptive (default), 0 never, r >= 1: the tail kernel takes the live paths over after wavefront round r */
   setTail(round) { addon.setTail(this._target, round === undefined ? -1 : round); }
   /** drawCamera + drawTracer ticks are recorded and run as batches at the next read-out (default, include/fspt.h);
@@ -398,7 +403,7 @@ class MultiPathTracer {
       !!denoise, maxSigma === undefined ? 3 : maxSigma, out);
   }
   setPipeline(name, batch) {
-    const code = name === 'megakernel' ? 0 : (name === 'wavefront2' ? 2 : 1);
+    const code = PIPELINE_CODES[name] === undefined ? 1 : PIPELINE_CODES[name];
     for (let i = 0; i < this.devices.length; i++) addon.setPipeline(addon.multiTarget(this._multi, i), code, batch || 0);
   }
   close() { if (this._multi) { addon.multiDestroy(this._multi); this._multi = null; } }

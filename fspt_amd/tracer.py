@@ -112,10 +112,16 @@ class PathTracer:
         L.check(L.lib().fspt_target_bind_accumulator(self._t, C.c_void_p(device_ptr)))
 
     def set_pipeline(self, pipeline, batch_ticks=0):
-        """'wavefront' (default), 'megakernel' or 'wavefront2' (two overlapped half-batches);
-        results are bit-identical."""
-        code = {"megakernel": 0, "wavefront": 1, "wavefront2": 2}.get(pipeline, pipeline)
+        """'wavefront' (batches), 'stream' (fixed pool of live paths), 'stream2' (two pools), 'megakernel' or
+        'wavefront2' (two overlapped half-batches); results are bit-identical."""
+        code = {"megakernel": 0, "wavefront": 1, "wavefront2": 2, "stream": 3, "stream2": 4}.get(pipeline, pipeline)
         L.check(L.lib().fspt_target_set_pipeline(self._t, int(code), int(batch_ticks)))
+
+    def set_pool(self, paths=0, drain=-1, max_iterations=0, overlap=-1):
+        """Stream scheduler: live paths per state set (0 = default), drain iterations (-1 = default), iteration cap
+        (0 = none; test hook), second HIP stream for plan / primary / resolve (-1 = default).  include/fspt.h:
+        fspt_target_set_pool."""
+        L.check(L.lib().fspt_target_set_pool(self._t, int(paths), int(drain), int(max_iterations), int(overlap)))
 
     def prepare(self):
         """Allocate the pipeline's path-state buffers now (not lazily inside the first render)."""

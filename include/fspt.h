@@ -196,13 +196,28 @@ float fspt_rand_base_next(uint64_t *state);
  * through draw.fs's `scale` (fspt_draw_scaled).  0, 0 restores the whole target. */
 int fspt_target_set_viewport(fspt_target *target, uint32_t w, uint32_t h);
 
-/* Execution strategy of fspt_trace / fspt_render (results are bit-identical):
- *   pipeline 1 (default) "wavefront": primary -> [trace <-> logic] x rounds -> resolve, queue-driven
+/* Execution strategy of fspt_trace / fspt_render (results are bit-identical).  The reference has one: a fragment
+ * shader invocation per pixel and draw call (main.js:758-807); its whole path state is two accumulators and two ray
+ * textures (main.js:598-617).
+ *   pipeline 1 "wavefront, batches": primary -> [trace <-> logic] x rounds -> resolve, queue-driven
  *              kernels over batch_ticks ticks at a time (0 keeps the current batch size; default and max 128);
- *   pipeline 0 "megakernel": one persistent kernel per tick (path regeneration);
- *   pipeline 2 "wavefront, two lanes": pipeline 1 with the batch split in two halves that run
+ *              path state = every (pixel, tick) of a batch;
+ *   pipeline 3 "wavefront, stream": the same kernels over a FIXED pool of live paths that is kept full (path
+ *              regeneration between launches): every launch is pool-sized whatever the call's tick count, path state
+ *              is the pool (fspt_target_set_pool) and a ring of finished samples; a run covers up to 128 ticks;
+ *   pipeline 4 "wavefront, stream, two pools": pipeline 3 on two halves of the frame's 8x8 patches, interleaved on
+ *              separate HIP streams;
+ *   pipeline 0 "megakernel": one persistent kernel per tick (path regeneration in place);
+ *   pipeline 2 "wavefront, batches, two lanes": pipeline 1 with the batch split in two halves that run
  *              concurrently on two HIP streams (separate path state, resolves chained in tick order). */
 int fspt_target_set_pipeline(fspt_target *target, int pipeline, uint32_t batch_ticks);
+/* Stream scheduler (pipeline 3 / 4): `paths` = live paths each state set of a pool holds (0 = default, 16 Mi; 204 bytes
+ * per path; never more than the call's samples); `drain_iterations` = trace/logic iterations after the last one that
+ * generated samples before the tail kernel runs the rest to completion (-1 = default); `max_iterations` caps the
+ * iterations of a run (0 = no cap; a test hook: the finishing launch then generates what the cursor has not handed
+ * out); `overlap` = 1: plan / primary / resolve of an iteration on a second HIP stream, beside the previous
+ * iteration's trace, 0: one stream, -1: default.  None of them changes a result. */
+int fspt_target_set_pool(fspt_target *target, uint32_t paths, int drain_iterations, uint32_t max_iterations, int overlap);
 /* Wavefront path state lives in device memory: 216 bytes per (pixel, tick) of a batch.  It is sized for the largest
  * n_ticks any call on this target has asked for so far (at most batch_ticks; fspt_trace = 1 tick = 0.46 GB at
  * 1920x1080, a 128-tick fspt_render = 58 GB) and grows when a longer call arrives.  fspt_target_set_memory_limit caps
@@ -307,6 +322,10 @@ typedef struct fspt_counters {
 } fspt_counters;
 int fspt_enable_counters(fspt_target *target, int enable);
 int fspt_get_counters(fspt_target *target, fspt_counters *out);
+/* Measurement only (bench.py's request-rate roofline of the trace kernel): of the traversal steps counted since
+ * fspt_counters_reset, how many k_wf_trace served from its LDS copy of the top of the tree instead of the vector-memory
+ * pipeline.  No counterpart in the reference. */
+int fspt_get_trace_lds_steps(fspt_target *target, uint64_t *steps);
 int fspt_counters_reset(fspt_target *target);
 
 /* Device-side evaluation of the deterministic math primitives (DESIGN.md

@@ -13,7 +13,7 @@ from fspt_amd import PathTracer, Scene, _lib as L
 pytestmark = pytest.mark.gpu
 
 
-PIPELINES = ["wavefront", "megakernel"]
+PIPELINES = ["wavefront", "megakernel", "stream"]
 
 
 def make_pt(arrays, W, H, cam, bounces=4, pipeline="wavefront", batch=0, tail=0):
@@ -127,7 +127,8 @@ def test_trace_two_call_bitwise(small_scene, camera, bounces, pipeline):
 
 
 @pytest.mark.parametrize("pipeline,batch", [("wavefront", 0), ("wavefront", 2), ("wavefront", 64), ("megakernel", 0),
-                                            ("wavefront2", 0), ("wavefront2", 2), ("wavefront2", 3)])
+                                            ("wavefront2", 0), ("wavefront2", 2), ("wavefront2", 3), ("stream", 0),
+                                            ("stream2", 0)])
 def test_render_fused_bitwise(medium_scene, camera, pipeline, batch):
     """fspt_render (ray generation fused into the path kernels) == oracle tick loop, for both
     execution strategies and for batches smaller / larger than the tick count."""
@@ -255,7 +256,7 @@ def test_trace_before_rays_is_state_error(small_scene):
     assert e.value.code == -6
 
 
-@pytest.mark.parametrize("pipeline", PIPELINES + ["wavefront2"])
+@pytest.mark.parametrize("pipeline", PIPELINES + ["wavefront2", "stream2"])
 def test_refractive_scene_bitwise(pipeline):
     """Dielectric material (tracer.fs:481-488: refraction does `i--`, so paths outlive NUM_BOUNCES
     rounds) + mesh normals + metallic: the reference-JS-built 'variant' golden scene."""
@@ -673,6 +674,143 @@ def test_full_size_baseline_config_properties():
     sh.clear(); sh.seed(seed); sh.render(ticks)
     assert sh.counters() == oc.as_dict()
     sh.close()
+
+
+@pytest.mark.parametrize("variant", ["c2", "c5", "textured"])
+def test_bench_configuration_full_size_library_defaults(variant):
+    """What bench.py times, as bench.py runs it: 1920x1080, depth 8, the LIBRARY DEFAULTS - default
+    scheduler, adaptive tail hand-over, default batch - and more ticks than one batch holds (130), so the adaptive rules
+    work from the live-path statistics of a real first batch.  Every 64th 32x32 tile (oracle tile shard 0 of 64)
+    equals the CPU oracle bit for bit.  c2 = BASELINE configs[1], c5 = configs[4] (aperture 0.1 + 0.5 deg sun, 94
+    bins), textured = bench.py --textured (2048^2 image maps, interleaved material textures)."""
+    from fspt_amd import scene as S
+    from fspt_amd import distributed as D
+    if variant == "textured":
+        arrays = S.bunny_scene_textured(n=76)
+    elif variant == "c5":
+        arrays = S.bunny_scene(n=76, sun_deg=0.5, sun_gain=2000.0)
+    else:
+        arrays = S.bunny_scene(n=76)
+    cam = dict(S.BUNNY_CAMERA)
+    if variant == "c5":
+        cam["aperture"] = 0.1
+    cam["lens"] = S.lens_features(cam["focal_depth"], cam["aperture"])
+    W, H, seed = 1920, 1080, 1
+    pt = PathTracer(arrays, W, H, num_bounces=8)   # no set_pipeline / set_tail: the defaults
+    pt.set_camera(cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["focal_depth"], cam["aperture"])
+    pt.seed(seed)
+    pt.render(5)     # bench.py's driver form: a short warm-up call ...
+    pt.render(125)   # ... then the rest, crossing a batch boundary (130 ticks in all)
+    got = pt.readRadiance()
+    pt.close()
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 8, 0, 130, seed, want,
+             shard=0, n_shards=64, tile=32)
+    mask = D.owner_mask(0, 64, W, H)
+    assert mask.sum() > 30000
+    assert np.array_equal(got[mask], want[mask])
+    assert np.isfinite(got).all() and (got[..., 3] == 1).all()
+
+
+@pytest.mark.parametrize("pipeline", ["stream", "stream2"])
+@pytest.mark.parametrize("overlap", [0, 1])
+@pytest.mark.parametrize("pool,drain,max_it", [(0, -1, 0), (1024, -1, 0), (1024, 0, 0), (4096, 5, 0), (0, -1, 1), (2048, -1, 3),
+                                               (1 << 20, 9, 0)])
+def test_stream_scheduler_bitwise(medium_scene, camera, pipeline, pool, drain, max_it, overlap):
+    """The stream scheduler (fixed pool of live paths, path regeneration between launches, include/fspt.h pipeline 3/4)
+    against the oracle, whole frame, work counters included:
+      * pools from two units (hundreds of iterations, the fin ring wraps many times) to larger than the call;
+      * the tail kernel taking over right after the last generating iteration, or only after every round;
+      * an iteration cap of 1 and 3: the finishing launch generates most of the run itself;
+      * plan / primary / resolve on a second HIP stream beside the previous trace (overlap 1) or everything on one
+        stream with the plan after the logic step (0)."""
+    W, H, ticks = 128, 80, 7
+    pt = make_pt(medium_scene, W, H, camera, 8, pipeline)
+    pt.set_pool(pool, drain, max_it, overlap)
+    pt.enable_counters(True)
+    pt.clear()
+    pt.seed(77)
+    pt.render(ticks)
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"],
+             8, 0, ticks, 77, want, counters=oc)
+    assert np.array_equal(pt.readRadiance(), want)
+    assert pt.counters() == oc.as_dict()
+    # a second call continues the stream (its iteration estimate now comes from the first run's statistics)
+    pt.enable_counters(False)
+    pt.render(ticks)
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"],
+             8, ticks, ticks, _advance_seed(77, ticks), want)
+    assert np.array_equal(pt.readRadiance(), want)
+    pt.close()
+
+
+def _advance_seed(seed, ticks):
+    """State of the host PRNG after `ticks` ticks (two draws per tick): what a later oracle call continues from."""
+    import ctypes as C
+    st = C.c_uint64(seed)
+    for _ in range(2 * ticks):
+        L.lib().fspt_rand_base_next(C.byref(st))
+    return st.value
+
+
+@pytest.mark.parametrize("pipeline", ["stream", "stream2"])
+def test_stream_runs_longer_than_one_tick_group(small_scene, camera, pipeline):
+    """A call of more than 128 ticks is several stream runs (128 + 2 here), each ended by its own drain; shards and a
+    ragged frame on top."""
+    W, H, ticks = 70, 45, 130
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"],
+             4, 0, ticks, 9, want, shard=1, n_shards=2, tile=16)
+    pt = make_pt(small_scene, W, H, camera, 4, pipeline)
+    pt.set_shard(1, 2, 16)
+    pt.set_pool(50000)
+    pt.seed(9)
+    pt.render(ticks)
+    assert np.array_equal(pt.readRadiance(), want)
+    pt.close()
+
+
+@pytest.mark.parametrize("pool", [0, 600])
+def test_stream_refraction_keeps_units_open(pool):
+    """A material that refracts (tracer.fs:481-488, `i--`): paths outlive NUM_BOUNCES iterations, so the resolve of a
+    unit waits for the iteration cap instead of the bounce budget; with a two-unit pool the fin ring is at its longest."""
+    from test_goldens import scene_from_golden
+    arrays = scene_from_golden("variant")
+    W, H = 96, 64
+    cam = dict(P=[0.3, 1.2, 3.4], I=[-0.05, -0.3, -0.95], fov_scale=0.5, env_theta=1.66, focal_depth=2.0, aperture=0.02)
+    cam["lens"] = [0.5, 0.02]
+    pt = make_pt(arrays, W, H, cam, 4, "stream")
+    pt.set_pool(pool)
+    pt.seed(3)
+    pt.render(4)
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 4, 0, 4, 3, want)
+    assert np.array_equal(pt.readRadiance(), want)
+    pt.close()
+
+
+def test_stream_path_state_is_bounded():
+    """VERDICT r2 'missing 2': the batch scheduler holds 216 bytes for every (pixel, tick) of a batch - 57 GB for 128 ticks
+    of a 1920x1080 frame; the stream scheduler holds a pool and a ring of finished samples, whatever the tick count."""
+    from fspt_amd import scene as S
+    arrays = S.bunny_scene(n=76)
+    cam = dict(S.BUNNY_CAMERA)
+    pt = PathTracer(arrays, 1920, 1080, num_bounces=8)
+    pt.set_pipeline("stream", 128)
+    pt.set_camera(cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["focal_depth"], cam["aperture"])
+    pt.seed(1)
+    pt.render(128)
+    pt.sync()
+    nbytes, _ = pt.path_state_bytes()
+    assert 0 < nbytes <= 3 << 30, nbytes
+    pt.set_pool(2 << 20)
+    pt.render(128)
+    pt.sync()
+    nbytes2, _ = pt.path_state_bytes()
+    assert nbytes2 <= nbytes  # (a smaller pool keeps the larger allocation)
+    pt.close()
 
 
 def test_bvh_deeper_than_the_reference_stack_is_rejected():

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round-3 profile session (run on the GPU box through gpurun):
+#   tools/prof_r03.sh <tag> [bench args...]     -> gpurun_out/<tag>_{kt,fetch,write,sq*}/ + logs
+# kernel trace + stats of the default bench command, then PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, as the
+# guide prescribes; SQ / TA / TD sets) over one timed batch.  rocprofv3 gets the program itself after `--`.
+set -u
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+T=$1; shift
+O=$R/gpurun_out
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -- python3 $R/bench.py --no-cpu-baseline ${KT_ARGS:---steps 20 --warmup 5} "$@" > $O/${T}_kt.log 2>&1
+find $O/${T}_kt -name "*kernel_trace.csv" -size +8M -delete
+# traffic passes: the timed configuration itself (TRAFFIC_ARGS, default: what the driver runs), one region, no warm-up
+TA=${TRAFFIC_ARGS:---steps 20}
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/${T}_$c -- python3 $R/bench.py --warmup 0 --reps 1 --no-cpu-baseline --no-parity-check $TA "$@" > $O/${T}_$c.log 2>&1
+done
+# request sizes behind FETCH_SIZE (profiles/r03/fetch_calib.json: every read request is a 128-byte line)
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/${T}_rdreq -- python3 $R/bench.py --warmup 0 --reps 1 --no-cpu-baseline --no-parity-check $TA "$@" > $O/${T}_rdreq.log 2>&1
+i=0
+for set in \
+ "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU" \
+ "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_WAVES" \
+ "TA_TA_BUSY_sum TD_TD_BUSY_sum GRBM_GUI_ACTIVE" \
+ "TCP_PERF_SEL_TOTAL_HIT_LRU_READ TCP_PERF_SEL_TOTAL_MISS_LRU_READ TCP_PERF_SEL_TOTAL_MISS_EVICT_READ" \
+ "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d $O/${T}_sq$i -- python3 $R/bench.py --steps 32 --batch 32 --warmup 0 --reps 1 --no-cpu-baseline --no-parity-check "$@" > $O/${T}_sq$i.log 2>&1
+done
+echo prof done
