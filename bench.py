@@ -36,22 +36,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2  # 1 228.8 G wave64 VALU instructions per second: CDNA4's SIMDs are 32 lanes wide, a
                                       # wave64 instruction issues over 2 cycles (MI355X_MICROARCH.md 'Wave scheduling')
-L1_GATHER_PEAK_GBS = 19000.0  # measured: coalesced dwordx4 loads from L1/L2, all CUs (profiles/r01/l1_pipe.json);
-                              # divergent per-lane 64-byte records reach 13 800
+L1_PEAK_FALLBACK = 8.6e11     # 16-byte lane-requests/s of divergent 64-byte record gathers, all CUs (profiles/r03/l1_peak.json);
+                              # bench.py measures it on the box it runs on (tools/microbench/l1_peak) and only falls
+                              # back to this when the microbenchmark binary is missing
 
 # kernel classes of the wavefront pipeline -> kernel symbol (as rocprofv3 prints it) and the resource that bounds it
 KERNELS = {
     "primary": ("fspt::k_wf_primary<false, true>", "hbm"),
-    "trace": ("fspt::k_wf_trace<false, true>", "l1_gather"),
+    "trace": ("fspt::k_wf_trace<false, true>", "l1"),
     "logic": ("fspt::k_wf_logic<false, true>", "hbm"),
     "resolve": ("fspt::k_wf_resolve", "hbm"),
-    "tail": ("fspt::k_wf_tail<false, true>", "l1_gather"),
+    "tail": ("fspt::k_wf_tail<false, true, false>", "l1"),
 }
-# The kernel the roofline block is about - fixed, not re-decided per run: the HBM-bound kernel class with the largest
-# share of GPU time in the committed rocprofv3 kernel statistics of the default workload (profiles/r02/
-# final_kernel_stats.csv: logic 32.7 %, primary 28.4 %; the trace class, 33.4 %, is bound by the CU's L1 gather
-# pipeline, not by HBM - its figures are in roofline.kernels.trace).
-ROOFLINE_CLASS = "logic"
+# The top-level roofline block is about the kernel class with the largest share of THIS run's GPU time (it
+# used to be pinned to the third-largest one).  On the default workload that is k_wf_trace, whose binding resource is not
+# HBM - the 25 MB scene is cache-resident - but the rate at which a CU's vector-memory pipeline takes per-lane requests:
+# it is priced in lane-requests/s against the rate a pure gather microbenchmark reaches on the same box.  The HBM view of
+# the whole pipeline (counter bytes / s against 8 TB/s) is kept beside it as roofline.hbm_counter.
 
 CONFIGS = {  # BASELINE.json configs[1..4]
     "c2": {},
@@ -152,6 +153,7 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "wavefront2", "stream", "stream2"])
     ap.add_argument("--pool", type=int, default=0, help="stream scheduler: live paths per state set (0 = library default)")
     ap.add_argument("--drain", type=int, default=-1, help="stream scheduler: drain iterations before the tail kernel (-1 = default)")
+    ap.add_argument("--trace-budget", type=int, default=-1, help="steps before a starved trace wave suspends its rays (0 = never, -1 = default)")
     ap.add_argument("--overlap", type=int, default=-1, help="stream scheduler: 1 = primary on a second HIP stream, 0 = one stream (-1 = default)")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="multi-GPU read-out: gather each rank's own tiles to rank 0 (default) or sum-reduce the full frame")
@@ -304,6 +306,8 @@ def main():
     pt.set_camera(**cam)
     pt.set_shard(rank, n_gpus, D.TILE)
     pt.set_pipeline(args.pipeline, args.batch)
+    if args.trace_budget >= 0:
+        pt.set_trace_budget(args.trace_budget)
     if args.pool or args.drain >= 0 or args.overlap >= 0:
         pt.set_pool(args.pool, args.drain, 0, args.overlap)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -384,6 +388,7 @@ def count_work(pt, mode, bounces=None):
     """One extra tick with the counting kernel variants (outside every timed region).  mode 1 = the reference's work
     (shadow rays traced to the closest hit like tracer.fs:501: equals the oracle's counters), mode 2 = the work the
     timed kernels really do (NEE shadow rays stop at the first hit)."""
+    import ctypes as C
     import fspt_amd
     L = fspt_amd._lib
     keep = pt.num_bounces
@@ -393,9 +398,29 @@ def count_work(pt, mode, bounces=None):
     L.check(L.lib().fspt_counters_reset(pt._t))
     pt.render(1)
     c = pt.counters()
+    lds = C.c_uint64()
+    L.check(L.lib().fspt_get_trace_lds_steps(pt._t, C.byref(lds)))
+    c["trace_lds_steps"] = int(lds.value)  # interior steps k_wf_trace served from its LDS copy of the top of the tree
     pt.enable_counters(0)
     pt.num_bounces = keep
     return c
+
+
+def l1_request_peak():
+    """16-byte lane-requests/s of a pure per-lane gather of 64-byte records (4 x dwordx4 per lane, the traversal's node
+    fetch) from an L2-resident table at k_wf_trace's occupancy, measured NOW on this box (tools/microbench/l1_peak.hip,
+    built by __graft_entry__.build()).  Returns (peak, source)."""
+    exe = os.path.join(ROOT, "tools", "microbench", "l1_peak")
+    if os.path.exists(exe):
+        try:
+            out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+            for l in out.splitlines():
+                if l.startswith("{"):
+                    j = json.loads(l)
+                    return float(j["gather_lane_requests_per_s"]), dict(j, source="tools/microbench/l1_peak, this run")
+        except Exception as e:  # noqa: BLE001 - a failed microbenchmark must not lose the bench line
+            return L1_PEAK_FALLBACK, {"source": f"fallback constant (l1_peak failed: {e})"}
+    return L1_PEAK_FALLBACK, {"source": "fallback constant (tools/microbench/l1_peak not built)"}
 
 
 def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed, times, kernel_ms, launches, stages, build_s):
@@ -428,23 +453,37 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
             pj = json.load(open(prof_path))
             if pj.get("source_sha") == sha and wl in pj.get("workloads", {}):
                 prof = pj["workloads"][wl]
+        # k_wf_trace in the unit of its binding resource: per-lane requests to the vector-memory pipeline.  An interior
+        # step fetches a 64-byte node as 4 requests (3 x 16 B + 1 x 8 B) unless the node is one of the top-of-tree nodes
+        # in LDS; a leaf visit is 9 x 16 B; a path item fetches its state with 3 x 16 B and stores 1 - 2 results.
+        tr_int = (act["steps"] - act["leaves"]) - (ref0["steps"] - ref0["leaves"])
+        tr_leaf = act["leaves"] - ref0["leaves"]
+        tr_paths = ref["shades"]  # one path item per shaded hit (its extension ray [+ shadow ray])
+        tr_req = 4.0 * max(0, tr_int - act["trace_lds_steps"]) + 9.0 * tr_leaf + 4.0 * tr_paths
+        l1_peak, l1_src = l1_request_peak()
         kernels = {}
         for k, (ms, n) in stages.items():
             name, bound = KERNELS[k]
-            peak = HBM_PEAK_GBS if bound == "hbm" else L1_GATHER_PEAK_GBS
             gbps = alg[k] * steps / (ms / 1e3) / 1e9 if ms > 0 else 0.0
             kj = {"kernel": name, "launches": n, "ms_per_step": round(ms / steps, 4), "avg_launch_ms": round(ms / max(1, n), 4),
-                  "alg_bytes_per_step": round(alg[k]), "alg_GBps": round(gbps, 1), "bound": bound, "peak_GBps": peak,
+                  "alg_bytes_per_step": round(alg[k]), "alg_GBps": round(gbps, 1), "bound": bound,
                   "traffic_bytes_per_launch": None, "traffic_GBps": None}
             if prof and name.replace("fspt::", "") in prof["kernels"]:
                 tps = prof["kernels"][name.replace("fspt::", "")]["hbm_bytes_per_sample"]
                 tb = tps * spt * steps
                 kj["traffic_bytes_per_launch"] = round(tb / max(1, n))
                 kj["traffic_GBps"] = round(tb / (ms / 1e3) / 1e9, 1) if ms > 0 else None
-            # fraction of the bounding resource's peak: HBM kernels are priced on what they really move when the counters
-            # are available (cache-resident scene data never has to come from HBM), else on the algorithmic bytes
-            num = kj["traffic_GBps"] if (bound == "hbm" and kj["traffic_GBps"] is not None) else gbps
-            kj["frac"] = round(num / peak, 4)
+            if k == "trace":
+                rps = tr_req * steps / (ms / 1e3) if ms > 0 else 0.0
+                kj.update({"lane_requests_per_step": round(tr_req), "achieved_Greq_per_s": round(rps / 1e9, 1),
+                           "peak_Greq_per_s": round(l1_peak / 1e9, 1), "frac": round(rps / l1_peak, 4),
+                           "lds_served_interior_steps": round(act["trace_lds_steps"] / max(1, tr_int), 3)})
+            elif bound == "hbm":
+                # HBM kernels are priced on what they really move between L2 and the fabric when the counters are available
+                # (cache-resident scene data never has to come from HBM), else on the algorithmic bytes
+                # (no fraction without counters: algorithmic bytes of cache-resident scene data are not HBM bytes)
+                kj.update({"peak_GBps": HBM_PEAK_GBS,
+                           "frac": round(kj["traffic_GBps"] / HBM_PEAK_GBS, 4) if kj["traffic_GBps"] is not None else None})
             kernels[k] = kj
         # The pipeline's instruction work against the chip's VALU issue rate.  Wave-instructions per sample of every
         # kernel class (SQ_INSTS_VALU, same stamped profile) x samples/s against 256 CUs x 4 SIMD-32s x 2.4 GHz / 2 cycles
@@ -456,20 +495,44 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
             valu = {"wave_instr_per_sample": round(wips, 1), "achieved_Ginstr_per_s": round(ach, 1),
                     "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": round(ach / VALU_PEAK_GINSTR, 4),
                     "per_kernel": {k.split("<")[0]: round(v["valu_wave_instr_per_sample"], 1) for k, v in prof["kernels"].items()}}
-        dom = kernels[ROOFLINE_CLASS]
-        d_ms, d_n = stages[ROOFLINE_CLASS]
-        roofline = {"bound": dom["bound"], "achieved": dom["alg_GBps"], "peak": dom["peak_GBps"], "unit": "GB/s",
-                    "frac": round(dom["alg_GBps"] / dom["peak_GBps"], 5),
-                    "traffic": dom["traffic_bytes_per_launch"], "kernel": dom["kernel"], "avg_launch_ms": dom["avg_launch_ms"],
-                    "launches": d_n, "bytes_per_launch": round(alg[ROOFLINE_CLASS] * steps / max(1, d_n)),
-                    "achieved_is": "algorithmic bytes of this kernel (280 H + 16 E, reference layout) / its HIP-event time",
-                    "traffic_frac": dom["frac"] if dom["traffic_GBps"] is not None else None,
-                    "traffic_source": (f"profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; source {sha})"
-                                       if dom["traffic_bytes_per_launch"] is not None else None),
-                    "bytes_per_sample": round(bps, 1), "per_sample": per_sample,
-                    "per_sample_timed_variant": {k: round(act[k] / max(1, spt), 4) for k in ("rays", "steps", "leaves")},
-                    "kernels": kernels, "valu": valu,
-                    "pipeline_alg_GBps": round(sum(alg.values()) * steps / (kernel_ms / 1e3) / 1e9, 1)}
+        # the whole pipeline's counter traffic against the HBM peak (bytes between L2 and the fabric, Infinity-Cache hits
+        # included: an upper bound on DRAM bytes)
+        hbm_counter = None
+        if prof:
+            tps = sum(v["hbm_bytes_per_sample"] for v in prof["kernels"].values())
+            gb = tps * spt * steps / elapsed / 1e9
+            hbm_counter = {"bytes_per_sample": round(tps, 1), "GBps": round(gb, 1), "peak_GBps": HBM_PEAK_GBS, "frac": round(gb / HBM_PEAK_GBS, 4),
+                           "is": "(2*FETCH_SIZE + WRITE_SIZE)*1024 of every kernel of the pipeline / the timed region; every read "
+                                 "request is a 128-byte line (profiles/r03/fetch_calib.json)",
+                           "source": f"profiles/hbm_traffic.json (source {sha})"}
+        dom_class = max(stages, key=lambda k: stages[k][0])  # the class with the largest share of this run's GPU time
+        dom = kernels[dom_class]
+        d_ms, d_n = stages[dom_class]
+        total_ms = sum(v[0] for v in stages.values())
+        if dom["bound"] == "l1" and dom_class == "trace":
+            roofline = {"bound": "l1", "achieved": dom["achieved_Greq_per_s"], "peak": dom["peak_Greq_per_s"], "unit": "Grequests/s",
+                        "frac": dom["frac"], "traffic": dom["traffic_bytes_per_launch"],
+                        "achieved_is": "per-lane vector-memory requests of this kernel (4 per interior step not served from LDS, "
+                                       "9 per leaf visit, 4 per path item; counted by the kernel's counting variant on this "
+                                       "frame) / its HIP-event time",
+                        "peak_is": "lane-requests/s of a pure 64-byte-record gather (4 x dwordx4 per lane) from an L2-resident "
+                                   "table at this kernel's occupancy", "peak_source": l1_src,
+                        "requests_per_launch": round(tr_req * steps / max(1, d_n))}
+        else:
+            roofline = {"bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(dom["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": dom["traffic_bytes_per_launch"],
+                        "achieved_is": "algorithmic bytes of this kernel (reference layout, SURVEY 8d) / its HIP-event time",
+                        "traffic_frac": dom.get("frac") if dom["traffic_GBps"] is not None else None,
+                        "bytes_per_launch": round(alg[dom_class] * steps / max(1, d_n))}
+        roofline.update({"kernel": dom["kernel"], "kernel_class": dom_class, "share_of_gpu_time": round(d_ms / max(total_ms, 1e-9), 3),
+                         "avg_launch_ms": dom["avg_launch_ms"], "launches": d_n,
+                         "traffic_source": (f"profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; source {sha})"
+                                            if dom["traffic_bytes_per_launch"] is not None else None),
+                         "hbm_counter": hbm_counter,
+                         "bytes_per_sample": round(bps, 1), "per_sample": per_sample,
+                         "per_sample_timed_variant": {k: round(act[k] / max(1, spt), 4) for k in ("rays", "steps", "leaves")},
+                         "kernels": kernels, "valu": valu,
+                         "pipeline_alg_GBps": round(sum(alg.values()) * steps / (kernel_ms / 1e3) / 1e9, 1)})
     else:
         avg_launch_ms = kernel_ms / max(1, launches)
         achieved = bps * spt / (avg_launch_ms / 1e3) / 1e9

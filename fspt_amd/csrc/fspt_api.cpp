@@ -53,6 +53,10 @@ struct fspt_scene {
 };
 
 static const int WF_ARRAYS = 15;
+#ifndef FSPT_SUSP_BUDGET
+#define FSPT_SUSP_BUDGET 48
+#endif
+static const uint32_t ST_DEFAULT_SUSP_BUDGET = FSPT_SUSP_BUDGET;
 struct fspt_target {
   fspt_scene *scene = nullptr;
   uint32_t W = 0, H = 0;
@@ -76,6 +80,7 @@ struct fspt_target {
   uint32_t pool_paths = 0;    // stream: paths per state set and lane (0 = default)
   int stream_drain = -1;      // stream: iterations after the last generating one before the tail kernel takes over (-1 = default)
   uint32_t stream_iter_cap = 0; // stream, test hook: at most this many iterations per run (the finishing launch does the rest)
+  uint32_t susp_budget = ST_DEFAULT_SUSP_BUDGET; // traversal steps a starved trace wave walks on before it parks its rays (0 = never)
   int stream_overlap = -1;      // stream: plan / primary / resolve on a second HIP stream beside the previous trace (1), everything on one stream (0), default (-1)
   uint32_t batch_ticks = 128; // ticks traced together by the wavefront pipeline (58 GB of path state at 1080p;
                               // measured 64 / 128 / 256 -> 3 619 / 3 794 / 3 750 Msamples/s, profiles/r01)
@@ -104,6 +109,8 @@ struct fspt_target {
     uint32_t ctl_units = 0;                  // units of the run the pending copy describes
     uint32_t stat_gen_iters = 0;             // iterations the last such run needed to hand out all its units
     uint64_t bytes = 0;                      // path-state bytes this lane holds (either scheduler)
+    int *susp[2] = {nullptr, nullptr};       // suspended-traversal records of the trace launches (fspt_device.hpp), ping-pong
+    uint32_t susp_stride = 0;
     bool zeroed = false;                     // counts / heads / ctl are zero (cleared behind the previous batch, off the next one's critical path)
   } lanes[2];
   uint32_t n_lanes = 1; // 2 = pipeline code 2: measured +3 % at 64+ ticks, -17 % at 8 ticks (profiles/r01)
@@ -634,6 +641,7 @@ int fspt_target_destroy(fspt_target *t) {
     if (ln.resolved) hipEventDestroy(ln.resolved);
     if (ln.stream_b) hipStreamSynchronize(ln.stream_b);
     hipFree(ln.ctl);
+    for (int *b : ln.susp) hipFree(b);
     if (ln.ctl_host) hipHostFree(ln.ctl_host);
     for (hipEvent_t ev : {ln.ev_run, ln.ev_b_last, ln.ctl_ready}) if (ev) hipEventDestroy(ev);
     for (int k = 0; k < fspt::WF_RING; ++k) { if (ln.ev_logic[k]) hipEventDestroy(ln.ev_logic[k]); if (ln.ev_b[k]) hipEventDestroy(ln.ev_b[k]); }
@@ -731,6 +739,17 @@ static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
   p.tiles_y = (t->H + t->tile - 1) / t->tile;
   uint32_t n_tiles = p.tiles_x * p.tiles_y;
   p.n_owned_tiles = (n_tiles > t->shard) ? (n_tiles - t->shard + t->n_shards - 1) / t->n_shards : 0;
+}
+
+// Records of suspended traversals: one per lane of a full trace grid (a lane parks at most one ray per launch), two buffers.
+static int susp_ensure(fspt_target *t, fspt_target::WfLane &ln) {
+  const uint32_t stride = ((uint32_t)fspt::WF_SUSP_HEADER + t->scene->d.stack_n + 3u) & ~3u;
+  if (ln.susp[0] && ln.susp_stride == stride) return FSPT_OK;
+  for (int *&b : ln.susp) { if (b) { HIP_TRY(hipFree(b)); b = nullptr; } }
+  const size_t recs = (size_t)t->scene->num_cus * 8u * 256u;
+  for (int *&b : ln.susp) HIP_TRY(hipMalloc((void **)&b, recs * stride * sizeof(int)));
+  ln.susp_stride = stride;
+  return FSPT_OK;
 }
 
 // bytes per path slot of every path-state array (fspt_device.hpp: WfP)
@@ -932,6 +951,10 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     p.n_batch = nbt;
     p.first_tick = first_tick + done;
     p.ctl = nullptr; p.ring_slots = nbt * work_total; p.pool = 0; p.n_pools = 1; p.finish = 0;
+    // suspended traversals: off while counting (the tail kernel re-traces a carried path's rays, which would count twice)
+    const bool susp_on = t->susp_budget != 0 && t->count == 0;
+    if (susp_on && (rc = susp_ensure(t, ln))) return rc;
+    p.susp[0] = ln.susp[0]; p.susp[1] = ln.susp[1]; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
     for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
     // the previous batch's live-path counts, if their copy has landed: where the tail kernel takes over
     wf_collect_counts(t, ln);
@@ -946,14 +969,21 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     // from advancing (tracer.fs:488).  After round `tail` the tail kernel runs whatever is still alive to completion.
     const uint32_t last = nb + 1;
     uint32_t tail = wf_tail_round(t, (uint64_t)nbt * work_total, last);
-    if (t->scene->has_dielectric && tail > last) tail = last; // refraction: paths may outlive `last` rounds
+    if ((t->scene->has_dielectric || susp_on) && tail > last) tail = last; // refraction / a suspended traversal: paths may outlive `last` rounds
     auto set_round = [&](uint32_t r) { p.round = r; p.cnt_in = r - 1; p.cnt_out = r; p.set_in = (r - 1) & 1u; p.set_out = r & 1u; };
     for (uint32_t r = 1; r <= last && r <= tail; ++r) {
       set_round(r);
       if ((rc = launch(r == 1 ? fspt::WF_K_PRIMARY : fspt::WF_K_LOGIC))) return rc;
-      if (r < last && r < tail) { if ((rc = launch(fspt::WF_K_TRACE))) return rc; }
+      if (r < last && r < tail) {
+        // the last trace launch of a batch lets its long rays finish: what it suspended the tail kernel would have to
+        // trace again from the start
+        const uint32_t keep = p.susp_budget;
+        if (r + 1 == (last < tail ? last : tail)) p.susp_budget = 0;
+        if ((rc = launch(fspt::WF_K_TRACE))) return rc;
+        p.susp_budget = keep;
+      }
     }
-    if (tail <= last && (tail < last || t->scene->has_dielectric)) {
+    if (tail <= last && (tail < last || t->scene->has_dielectric || susp_on)) {
       set_round(tail);
       if ((rc = launch(fspt::WF_K_TAIL))) return rc;
     }
@@ -1045,6 +1075,8 @@ static int st_plan(const fspt_target *t, uint32_t units, uint32_t nbt, uint32_t 
   // every path generated in iteration k has ended after logic(k + horizon): the bounce budget, or - when a material can
   // refract, tracer.fs:488 - the cap on loop iterations
   pl.horizon = t->scene->has_dielectric ? (uint32_t)fspt::MAX_PATH_ITERS : (nb ? nb : 0u);
+  // a suspended traversal makes its path lag a round, at most WF_LAG_MAX times (fspt_device.hpp)
+  if (t->susp_budget != 0 && t->count == 0) pl.horizon += fspt::WF_LAG_MAX;
   const uint64_t ring_units = (uint64_t)(pl.horizon + 3u) * pl.take_max;
   const uint64_t ring = (ring_units < units ? ring_units : units) * pl.unit_slots; // never more than the run itself
   if (ring > 0xFFFFFFFFull) { fspt_set_error("frame too large for the stream scheduler (fin ring of %llu samples)", (unsigned long long)ring); return FSPT_E_INVALID; }
@@ -1078,6 +1110,7 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
   const int cus = t->scene->num_cus;
   constexpr uint32_t R = fspt::WF_RING;
   const bool overlap = t->stream_overlap < 0 ? ST_DEFAULT_OVERLAP : t->stream_overlap != 0;
+  const bool susp_on = t->susp_budget != 0 && t->count == 0;
 
   fspt::WfP base{};
   base.scene = t->scene->d;
@@ -1130,6 +1163,8 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
       p.counts = ln.counts; p.heads = ln.heads; p.ctl = ln.ctl;
       p.work_total = units * 64u; p.n_batch = nbt; p.first_tick = first_tick + done;
       p.ring_slots = pl[l].ring_slots; p.cap = pl[l].cap; p.take_max = pl[l].take_max; p.pool = l;
+      if (susp_on && (rc = susp_ensure(t, ln))) return rc;
+      p.susp[0] = ln.susp[0]; p.susp[1] = ln.susp[1]; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
       p.serial = overlap ? 0u : 1u;
       for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
       // how many iterations hand out all units: what the last such run needed, else from the pool's equilibrium
@@ -1176,7 +1211,10 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
             if ((rc = launch(fspt::WF_K_RESOLVE, p, A))) return rc;
             res_done[l] = to;
           }
-          if ((rc = launch(fspt::WF_K_TRACE, p, A))) return rc;
+          { const uint32_t keep = p.susp_budget;
+            if (it + 1 == iters[l]) p.susp_budget = 0;
+            if ((rc = launch(fspt::WF_K_TRACE, p, A))) return rc;
+            p.susp_budget = keep; }
           continue;
         }
         // ---- B: plan + primary of iteration `it` (beside trace(it - 1)), then the resolve that logic(it - 1) made possible
@@ -1196,7 +1234,12 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
           HIP_TRY(hipEventRecord(ln.ev_logic[it % R], A));
         }
         HIP_TRY(hipStreamWaitEvent(A, ln.ev_b[it % R], 0));
-        if ((rc = launch(fspt::WF_K_TRACE, p, A))) return rc;
+        { // (the run's last trace launch lets its long rays finish: the tail kernel would trace them again from the start)
+          const uint32_t keep = p.susp_budget;
+          if (it + 1 == iters[l]) p.susp_budget = 0;
+          if ((rc = launch(fspt::WF_K_TRACE, p, A))) return rc;
+          p.susp_budget = keep;
+        }
       }
     }
     // ---- the end of the run: logic on the last trace's results, then the tail kernel runs whatever is alive to
@@ -1484,6 +1527,13 @@ int fspt_target_set_pool(fspt_target *t, uint32_t paths, int drain_iterations, u
   t->stream_drain = drain_iterations;
   t->stream_iter_cap = max_iterations;
   t->stream_overlap = overlap < 0 ? -1 : (overlap ? 1 : 0);
+  return FSPT_OK;
+}
+
+int fspt_target_set_trace_budget(fspt_target *t, uint32_t steps) {
+  if (!t) { fspt_set_error("fspt_target_set_trace_budget: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
+  t->susp_budget = steps;
   return FSPT_OK;
 }
 

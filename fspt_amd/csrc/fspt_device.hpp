@@ -140,7 +140,18 @@ struct IntersectP {
 // ---------------------------------------------------------------------------
 constexpr int WF_MAX_BATCH = 128;
 constexpr int WF_HIT_TERMINAL = -2; // hit[k].index of an extension ray that hit something but whose path has no bounce left
+constexpr int WF_HIT_PENDING = -3;  // hit[k].index of a path whose traversal was SUSPENDED by the trace launch (hit[k].t = its record)
 constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17, WF_FLAG_COLZERO = 1u << 18;
+// Suspended traversals (k_wf_trace): what a trace launch costs beyond its work is its LONGEST ray - a dependent chain of
+// up to a few hundred node fetches that a handful of lanes walk while the rest of the chip idles (~0.2 ms per launch,
+// profiles/r03).  A wave that can get no more work and has been walking for WfP::susp_budget steps writes the state of
+// its unfinished rays (node, t, hit, the LDS stack) to a record and ends; the logic launch carries such a path over to
+// the next state set unchanged (flag WF_FLAG_SUSP: the next trace launch must not start its rays afresh), and the next
+// trace launch resumes the records FIRST, beside its bulk of new rays.  Same traversal, same result; a path lags one
+// round per suspension (at most WF_LAG_MAX: the count lives in bits 20-22 of the flags).
+constexpr uint32_t WF_FLAG_SUSP = 1u << 19;
+constexpr uint32_t WF_LAG_SHIFT = 20, WF_LAG_MASK = 7u, WF_LAG_MAX = 4u;
+constexpr int WF_SUSP_HEADER = 8; // ints before the stack entries of a record: state index, node, t, hit, sp | ray << 8, shadow result, -, -
 #ifndef FSPT_WF_HEADS
 #define FSPT_WF_HEADS 16
 #endif
@@ -152,7 +163,8 @@ constexpr int WF_HEADS = FSPT_WF_HEADS; // work-pool heads of the trace kernel (
 constexpr int WF_HEAD_STRIDE = FSPT_WF_HEAD_STRIDE;
 struct alignas(128) WfCounts { // one per round, zeroed before the batch
   uint32_t n_ext;          // live paths written by this round's primary / logic launch
-  uint32_t pad[31];
+  uint32_t n_susp;         // traversals this round's trace launch suspended (records for the next one)
+  uint32_t pad[30];
 };
 // Trace / tail kernel work-pool heads: WF_HEADS per round, each in a memory line (and channel) of its own
 // (WfP::heads[(round * WF_HEADS + stripe) * WF_HEAD_STRIDE]): device-scope atomics execute at the memory side and
@@ -217,6 +229,9 @@ struct WfP {
   int res_from, res_to; // resolve (stream): fold the units between hist[res_from] (< 0: unit 0) and hist[res_to] (-2: all)
   uint32_t finish;      // tail (stream): also generate what the cursor has not handed out
   uint32_t serial;      // plan (stream): it runs AFTER logic(i) (one HIP stream) and sees the real survivors in counts[cnt_out]
+  int *susp[2];         // suspended-traversal records: trace(i) writes susp[cnt_out & 1], resumes susp[cnt_in & 1]
+  uint32_t susp_stride; // ints per record (WF_SUSP_HEADER + stack entries, a multiple of 4)
+  uint32_t susp_budget; // traversal steps a wave walks on after its last refill before it suspends (0: never)
   uint32_t W, H;
   uint32_t vw, vh; // viewport, as in TraceP
   uint32_t work_total; // work indices per tick (owned tiles * tile^2)

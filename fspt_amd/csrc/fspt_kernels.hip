@@ -515,6 +515,7 @@ struct Path {
   int pix;        // y*W + x, -1: lane idle
   bool hasShadow;
   bool primary;   // pending ray is the camera ray
+  uint32_t lag;   // rounds the path has lagged behind its generation because a traversal of it was suspended (<= WF_LAG_MAX)
 };
 
 // tracer.fs:447-499: shade the hit (t, tri) of ray (ro, rd); sets up the next
@@ -779,6 +780,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
   ps.bounce = 0;
   ps.iters = 0;
   ps.wx = ps.wy = 0.0f;
+  ps.lag = 0u;
   ps.ro = ps.rd = ps.thr = ps.color = ps.envDir = ps.pend = v3(0.0f, 0.0f, 0.0f);
 
   // traversal results of the previous T phase
@@ -960,7 +962,7 @@ FM_DEV uint32_t lane_rank(unsigned long long m) {
 // ---- path state <-> registers ---------------------------------------------------------------
 FM_DEV uint32_t pack_flags(const Path &ps, bool col_zero) {
   return ((uint32_t)ps.bounce & 255u) | (((uint32_t)ps.iters & 255u) << 8) | (ps.primary ? WF_FLAG_PRIMARY : 0u) |
-         (ps.hasShadow ? WF_FLAG_SHADOW : 0u) | (col_zero ? WF_FLAG_COLZERO : 0u);
+         (ps.hasShadow ? WF_FLAG_SHADOW : 0u) | (col_zero ? WF_FLAG_COLZERO : 0u) | ((ps.lag & WF_LAG_MASK) << WF_LAG_SHIFT);
 }
 // state of a surviving path -> index k of `o`; the colour array is only written while the colour is non-zero
 // (it is +0 until the first light arrives), D / P only when the path has a NEE shadow ray
@@ -990,6 +992,7 @@ FM_DEV uint32_t load_path(const WfSet &in, uint32_t k, Path &ps, const int *shad
   ps.iters = (int)((flags >> 8) & 255u);
   ps.primary = (flags & WF_FLAG_PRIMARY) != 0u;
   ps.hasShadow = (flags & WF_FLAG_SHADOW) != 0u;
+  ps.lag = (flags >> WF_LAG_SHIFT) & WF_LAG_MASK;
   ps.pix = 0;
   ps.wx = 0.0f;
   ps.envDir = v3(0.0f, 0.0f, 0.0f);
@@ -1003,6 +1006,22 @@ FM_DEV uint32_t load_path(const WfSet &in, uint32_t k, Path &ps, const int *shad
     if (shadow_hit) hitA = ldi(shadow_hit + k);
   }
   return __float_as_uint(ro.w);
+}
+
+// a path whose traversal was suspended: its state, bit for bit, from index i of `in` to index k of `o`, flagged and
+// with one more round of lag in the flags word
+FM_DEV void carry_path(const WfSet &in, const WfSet &o, uint32_t i, uint32_t k) {
+  const float4 a = ld4(in.A + i), c = ld4(in.C + i);
+  float4 b = ld4(in.B + i);
+  uint32_t fl = __float_as_uint(b.w);
+  const uint32_t lag = (fl >> WF_LAG_SHIFT) & WF_LAG_MASK;
+  fl = (fl & ~(WF_LAG_MASK << WF_LAG_SHIFT)) | ((lag < WF_LAG_MASK ? lag + 1u : lag) << WF_LAG_SHIFT) | WF_FLAG_SUSP;
+  st4(o.A + k, a);
+  st4(o.C + k, c);
+  if (!(fl & WF_FLAG_COLZERO)) st4(o.E + k, ld4(in.E + i));
+  if (fl & WF_FLAG_SHADOW) { st4(o.D + k, ld4(in.D + i)); st4(o.P + k, ld4(in.P + i)); }
+  b.w = __uint_as_float(fl);
+  st4(o.B + k, b);
 }
 
 // ---- trace: intersectScene for the rays of one round; persistent waves, per-lane refill -------
@@ -1032,19 +1051,27 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   const DScene &S = p.scene;
-  int *stack = lds_stack + (size_t)wave * S.stack_n * WAVE + lane;
+  // one more LDS entry per lane than the tree needs: the lane's finished shadow result while its extension ray is traced
+  // (a suspended traversal's record carries it along)
+  const uint32_t sn = S.stack_n + 1u;
+  int *stack = lds_stack + (size_t)wave * sn * WAVE + lane;
   const float4 *__restrict__ nodes = S.nodes;
   const float *__restrict__ leaves = S.leaves;
   const uint32_t leaf_size = S.leaf_size;
   const WfSet st = p.set[p.set_out];
   WfCounts *cn = p.counts + p.cnt_out;
   const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
-  const uint32_t total = cn->n_ext;
+  // suspended traversals (fspt_device.hpp): the records the previous trace launch wrote are this launch's FIRST items
+  const bool susp_on = !COUNT && p.susp_budget != 0u;
+  const uint32_t n_res = susp_on ? p.counts[p.cnt_in].n_susp : 0u;
+  const int *__restrict__ rec_in = p.susp[p.cnt_in & 1u];
+  int *rec_out = p.susp[p.cnt_out & 1u];
+  const uint32_t total = cn->n_ext + n_res;
 
   // top of the tree in LDS (behind the waves' stacks): every ray walks these nodes, and a fetch from LDS does not
   // occupy the vector-memory pipeline that bounds this kernel
   const int n_top = (int)p.lds_top;
-  float4 *top = reinterpret_cast<float4 *>(lds_stack + (size_t)WAVES_PER_BLOCK * S.stack_n * WAVE);
+  float4 *top = reinterpret_cast<float4 *>(lds_stack + (size_t)WAVES_PER_BLOCK * sn * WAVE);
   if (n_top > 0) {
     for (int i = threadIdx.x; i < n_top * NODE_F4; i += BLOCK_THREADS) top[i] = nodes[i];
     __syncthreads();
@@ -1055,7 +1082,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   // item is two rays one after the other.  Split, the two rays of the late paths run side by side on two lanes (any two:
   // their results go to hit[] and shadow_hit[] independently), and the launch ends after ONE long ray, not two.  Small
   // launches consist of ray items only.  (Costs a second state fetch per split path; WF_TRACE_RAY_ITEMS x the resident lanes.)
-  const uint32_t split_paths = min(total, (uint32_t)WF_TRACE_RAY_ITEMS * n_waves * (uint32_t)WAVE);
+  // (with suspended traversals the end of a launch is short anyway, and a record describes a whole path item)
+  const uint32_t split_paths = susp_on ? 0u : min(total, (uint32_t)WF_TRACE_RAY_ITEMS * n_waves * (uint32_t)WAVE);
   const uint32_t path_items = total - split_paths; // paths [0, path_items): one item per path
   // pool chunk: large while paths are plentiful (few atomics), one wave-load when they are scarce
   // (late rounds), so that every resident wave gets work
@@ -1082,6 +1110,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   bool exhausted = n_chunks <= n_waves; // nothing beyond the waves' own chunks
 
   uint32_t c_rays = 0, c_steps = 0, c_leaves = 0, c_lds = 0;
+  uint32_t starve = 0; // traversal steps since the wave found its pool empty (wave-uniform)
   bool idle = true;
   bool is_shadow = false;
   // state index of the lane's path; bit 31: the path's bounce budget is used up (a hit of its extension ray will not be
@@ -1118,25 +1147,65 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
           k = path_items + (j >> 1);
           mode = 1u + (j & 1u);
         }
+        // the first n_res items are suspended traversals: the record names the path's state index
+        const bool resume = k < n_res;
+        const int *rec = rec_in + (size_t)k * p.susp_stride;
+        if (resume) k = (uint32_t)rec[0]; else k -= n_res;
         const float4 ro = ld4(st.A + k), rd = ld4(st.B + k);
         const float4 sd = ld4(st.D + k); // fetched alongside (only meaningful when the path has a shadow ray)
         o = v3(ro.x, ro.y, ro.z);
         d_ext = v3(rd.x, rd.y, rd.z);
-        const bool has_shadow = (__float_as_uint(rd.w) & WF_FLAG_SHADOW) != 0u;
+        const uint32_t fl = __float_as_uint(rd.w);
+        const bool has_shadow = (fl & WF_FLAG_SHADOW) != 0u;
         if (mode == 2u && !has_shadow) mode = 3u;
+        // a path the logic launch carried over with a suspended traversal is this launch's resume item, not a new one
+        if (!resume && (fl & WF_FLAG_SUSP)) mode = 3u;
         is_shadow = has_shadow && mode != 1u;
-        d = is_shadow ? v3(sd.x, sd.y, sd.z) : d_ext;
-        inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         t = MAX_T;
         hit = -1;
         cur = mode == 3u ? REF_SENTINEL : S.root_ref;
         sp = 0;
-        const bool live = (__float_as_uint(rd.w) & 255u) < p.num_bounces && ((__float_as_uint(rd.w) >> 8) & 255u) < (uint32_t)MAX_PATH_ITERS;
-        path = k | (mode << 29) | (live ? 0u : 0x80000000u);
+        if (resume) { // node, t, hit | sp, ray, finished shadow result | stack
+          const int3 r0 = make_int3(rec[1], rec[2], rec[3]);
+          const int2 r1 = *reinterpret_cast<const int2 *>(rec + 4);
+          cur = r0.x; t = __int_as_float(r0.y); hit = r0.z;
+          sp = r1.x & 255;
+          is_shadow = ((r1.x >> 8) & 1) != 0;
+          for (int i = 0; i < sp; ++i) stack[i * WAVE] = rec[WF_SUSP_HEADER + i];
+          if (!is_shadow) { stack[S.stack_n * WAVE] = r1.y; if (has_shadow) sti(p.shadow_hit + k, r1.y); } // its shadow ray had finished before
+        }
+        d = is_shadow ? v3(sd.x, sd.y, sd.z) : d_ext;
+        inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const bool live = (fl & 255u) < p.num_bounces && ((fl >> 8) & 255u) < (uint32_t)MAX_PATH_ITERS;
+        // bit 29 of a path item (mode 0): the traversal may be suspended (the path has not lagged WF_LAG_MAX rounds yet)
+        const bool may_susp = susp_on && ((fl >> WF_LAG_SHIFT) & WF_LAG_MASK) < WF_LAG_MAX;
+        path = k | (mode << 29) | (may_susp ? (1u << 29) : 0u) | (live ? 0u : 0x80000000u);
         idle = false;
         if (COUNT && mode != 3u) c_rays++;
       }
       pool_next += take;
+    }
+    // ---- a wave that can get no more work walks on for susp_budget steps, then parks its unfinished traversals ----
+    const bool starved = susp_on && exhausted && pool_next == pool_end; // (wave-uniform)
+    if (starved && starve >= p.susp_budget) {
+      const bool park = !idle && cur != REF_SENTINEL && ((path >> 29) & 3u) == 1u; // a path item that may still lag
+      const unsigned long long m = __ballot(park);
+      if (m != 0ull) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&cn->n_susp, (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (park) {
+          const uint32_t k = path & 0x1fffffffu, rid = base + lane_rank(m);
+          int *rec = rec_out + (size_t)rid * p.susp_stride;
+          *reinterpret_cast<int4 *>(rec) = make_int4((int)k, cur, __float_as_int(t), hit);
+          *reinterpret_cast<int2 *>(rec + 4) = make_int2(sp | (is_shadow ? 256 : 0), stack[S.stack_n * WAVE]);
+          for (int i = 0; i < sp; ++i) rec[WF_SUSP_HEADER + i] = stack[i * WAVE];
+          st2(p.hit + k, make_float2(__uint_as_float(rid), __int_as_float(WF_HIT_PENDING)));
+          idle = true;
+          cur = REF_SENTINEL;
+        }
+      }
+      starve = 0u; // the lanes that had to stay (lagged paths) get another budget before the next look
     }
     if (__ballot(!idle) == 0ull) break;
 
@@ -1146,6 +1215,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     while (true) {
       unsigned long long in = __ballot(cur >= 0);
       if (in == 0ull) break;
+      if (starved && ++starve >= p.susp_budget) break;
 #if WF_INTERIOR_MIN > 1
       if ((uint32_t)__popcll(in) < WF_INTERIOR_MIN && __popcll(__ballot(!idle)) > __popcll(in)) break;
 #endif
@@ -1210,6 +1280,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
         idle = true; // empty item
       } else if (is_shadow) {
         sti(p.shadow_hit + k, hit);
+        stack[S.stack_n * WAVE] = hit; // kept for a record, should the extension ray be suspended
         if (mode == 2u) {
           idle = true; // the extension ray is another lane's item
         } else {
@@ -1365,7 +1436,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
       ps.envDir = v3(0.0f, 0.0f, 0.0f);
       ps.pend = v3(0.0f, 0.0f, 0.0f);
       ps.wx = ps.wy = 0.0f;
-      ps.bounce = 0; ps.iters = 0; ps.pix = 0;
+      ps.bounce = 0; ps.iters = 0; ps.pix = 0; ps.lag = 0u;
       ps.hasShadow = false; ps.primary = true;
       const uint32_t j = (first + i) % p.n_batch;
       const bool finished = advance_path<COUNT>(S, ps, -1, t_u[u], hit_u[u], LDSTAB ? s_rb[j] : p.rb_trace[j], p.env_theta,
@@ -1421,16 +1492,18 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
     for (uint32_t u = 0; u < u_eff; ++u) {
       const uint32_t loc = u * WF_LOGIC_THREADS + threadIdx.x;
       const uint32_t i = base + loc;
-      bool shade = false;
+      bool shade = false, carry = false;
       if (i < n_in) {
-        shade = __float_as_int(ld2(p.hit + i).y) >= 0; // -1: miss; WF_HIT_TERMINAL: hit with the bounce budget used up
-        if (!shade) own_fin |= 1u << u;
+        const int idx = __float_as_int(ld2(p.hit + i).y);
+        shade = idx >= 0; // -1: miss; WF_HIT_TERMINAL: hit with the bounce budget used up
+        carry = idx == WF_HIT_PENDING; // its traversal was suspended: the path moves on unchanged (fspt_device.hpp)
+        if (!shade && !carry) own_fin |= 1u << u;
       }
-      const unsigned long long m = __ballot(shade);
+      const unsigned long long m = __ballot(shade || carry);
       uint32_t wb = 0;
       if (lane == 0 && m) wb = atomicAdd(&s_n, (uint32_t)__popcll(m));
       wb = __builtin_amdgcn_readfirstlane(wb);
-      if (shade) s_list[wb + lane_rank(m)] = (uint16_t)loc;
+      if (shade || carry) s_list[wb + lane_rank(m)] = (uint16_t)(loc | (carry ? 0x8000u : 0u)); // loc < U * 512 = 4096
     }
     __syncthreads();
     uint32_t my_gbase = 0;
@@ -1458,7 +1531,17 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
         const uint32_t tsh = (jt - u_eff) * WF_LOGIC_THREADS + threadIdx.x;
         if ((jt - u_eff) * WF_LOGIC_THREADS >= n_shade) break; // block-uniform
         active = tsh < n_shade;
-        if (active) { i = base + s_list[tsh]; k_out = gbase + tsh; }
+        if (active) {
+          const uint32_t e = s_list[tsh];
+          i = base + (e & 0x7fffu); k_out = gbase + tsh;
+          if (e & 0x8000u) {
+            // carried over: same state at its new index, marked (the next trace launch resumes its record instead of
+            // starting its rays afresh) and one round of lag counted; the record learns the new index
+            carry_path(in, out, i, k_out);
+            p.susp[p.cnt_in & 1u][(size_t)__float_as_uint(ld2(p.hit + i).x) * p.susp_stride] = (int)k_out;
+            active = false;
+          }
+        }
       }
       if (active) {
         Path ps;
@@ -1566,6 +1649,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
   Path ps;
   ps.pix = -1;
   ps.hasShadow = false;
+  ps.lag = 0u;
   ps.ro = ps.rd = ps.envDir = v3(0.0f, 0.0f, 1.0f);
   uint32_t slot = 0;
   // pool as in k_wf_trace: chunks of 32 paths; every wave's first chunk is its own, the rest is dealt out by the
@@ -1754,6 +1838,7 @@ __global__ __launch_bounds__(WAVE) void k_wf_plan(const WfP p) {
   if (threadIdx.x < WF_HEADS) p.heads[((size_t)nxt * WF_HEADS + threadIdx.x) * WF_HEAD_STRIDE] = 0u;
   if (threadIdx.x != 0) return;
   p.counts[nxt].n_ext = 0u;
+  p.counts[nxt].n_susp = 0u;
   const uint32_t unit_slots = 64u * p.n_batch;
   // paths set i may have to hold besides the new ones: everything alive in set i-1 (logic(i) has yet to run), or -
   // one-stream form, logic(i) is done - the survivors it has already written
@@ -1978,7 +2063,7 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
   if (kernel == WF_K_TRACE) {
     // persistent: the grid only has to fill the machine; the pool heads balance the work
     uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
-    size_t lds = stack_bytes(p.scene);
+    size_t lds = stack_bytes(p.scene) + (size_t)WAVES_PER_BLOCK * WAVE * sizeof(int); // + one entry per lane (k_wf_trace: sh_keep)
     // LDS left over per block at the occupancy the stacks (and the registers: 7 blocks) allow -> top-of-tree cache
     WfP q = p;
     {

@@ -549,6 +549,13 @@ static napi_value SetPool(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_target_set_pool((fspt_target *)h, paths, drain, cap, overlap));
   return undefined(env);
 }
+static napi_value SetTraceBudget(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h; uint32_t steps;
+  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &steps));
+  FSPT_OK_OR_THROW(fspt_target_set_trace_budget((fspt_target *)h, steps));
+  return undefined(env);
+}
 static napi_value SetMemoryLimit(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; double bytes;
   if (get_args(env, info, 2, a) || unwrap(env, a[0], &h) || get_f64(env, a[1], &bytes)) return NULL;
@@ -851,7 +858,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   struct { const char *name; napi_callback fn; } fns[] = {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"traceTest", TraceTest}, {"render", Render}, {"clear", Clear},
-      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline}, {"setPool", SetPool},
+      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline}, {"setPool", SetPool}, {"setTraceBudget", SetTraceBudget},
       {"setMemoryLimit", SetMemoryLimit}, {"setTextureInterleaveBudget", SetTextureInterleaveBudget}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail}, {"setDeferred", SetDeferred},
       {"renderAsync", RenderAsync}, {"multiCreate", MultiCreate}, {"multiDestroy", MultiDestroy}, {"multiTarget", MultiTarget},
       {"multiCamera", MultiCamera}, {"multiTrace", MultiTrace}, {"multiRender", MultiRender}, {"multiRenderAsync", MultiRenderAsync},

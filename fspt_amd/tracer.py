@@ -123,6 +123,10 @@ class PathTracer:
         fspt_target_set_pool."""
         L.check(L.lib().fspt_target_set_pool(self._t, int(paths), int(drain), int(max_iterations), int(overlap)))
 
+    def set_trace_budget(self, steps):
+        """Traversal steps a starved trace wave walks on before it suspends its rays (0 = never; include/fspt.h)."""
+        L.check(L.lib().fspt_target_set_trace_budget(self._t, int(steps)))
+
     def prepare(self):
         """Allocate the pipeline's path-state buffers now (not lazily inside the first render)."""
         L.check(L.lib().fspt_target_prepare(self._t))
@@ -288,7 +292,7 @@ class MultiPathTracer:
             yield t
 
     def set_pipeline(self, pipeline, batch_ticks=0):
-        code = {"megakernel": 0, "wavefront": 1, "wavefront2": 2}.get(pipeline, pipeline)
+        code = {"megakernel": 0, "wavefront": 1, "wavefront2": 2, "stream": 3, "stream2": 4}.get(pipeline, pipeline)
         for t in self._targets():
             L.check(L.lib().fspt_target_set_pipeline(t, int(code), int(batch_ticks)))
 
@@ -338,6 +342,13 @@ class MultiPathTracer:
         L.check(L.lib().fspt_multi_draw(self._m, float(exposure), float(saturation), 1 if denoise else 0, float(max_sigma),
                                         L.u8ptr(out)))
         return out
+
+    def peer_access(self, i):
+        """How target i's tiles reach devices[0]: bit 0 = its device can write devices[0]'s memory directly (the
+        direction the gather copy runs), bit 1 = the reverse; 0 = staged through the host."""
+        m = C.c_int()
+        L.check(L.lib().fspt_multi_peer_access(self._m, int(i), C.byref(m)))
+        return m.value
 
     def last_gather_bytes(self):
         b = C.c_uint64()

@@ -218,6 +218,13 @@ int fspt_target_set_pipeline(fspt_target *target, int pipeline, uint32_t batch_t
  * out); `overlap` = 1: plan / primary / resolve of an iteration on a second HIP stream, beside the previous
  * iteration's trace, 0: one stream, -1: default.  None of them changes a result. */
 int fspt_target_set_pool(fspt_target *target, uint32_t paths, int drain_iterations, uint32_t max_iterations, int overlap);
+/* Wavefront pipelines: a trace launch ends on its longest ray - up to a few hundred dependent node fetches walked by a
+ * handful of lanes.  A wave that can get no more rays walks on for `steps` traversal steps, then writes the state of its
+ * unfinished traversals (node, t, hit, stack) to memory and ends; the next trace launch resumes them first, beside its
+ * new rays (the path lags a round, at most four times).  Same traversal, same result.  0 = never suspend; the default
+ * is 48.  Not used by the counting kernel variants.  (The reference has no counterpart: one fragment-shader invocation
+ * walks its whole path, tracer.fs:436-518.) */
+int fspt_target_set_trace_budget(fspt_target *target, uint32_t steps);
 /* Wavefront path state lives in device memory: 216 bytes per (pixel, tick) of a batch.  It is sized for the largest
  * n_ticks any call on this target has asked for so far (at most batch_ticks; fspt_trace = 1 tick = 0.46 GB at
  * 1920x1080, a 128-tick fspt_render = 58 GB) and grows when a longer call arrives.  fspt_target_set_memory_limit caps

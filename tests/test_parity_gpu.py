@@ -304,6 +304,7 @@ def test_num_bounces_beyond_the_iteration_cap(small_scene, camera, pipeline, bou
 
 def test_stage_timing(small_scene, camera):
     pt = make_pt(small_scene, 64, 48, camera, 4, "wavefront", 2)
+    pt.set_trace_budget(0)  # (with suspended traversals every batch ends with a tail launch for the paths that lag)
     pt.render(4)
     st = pt.last_stage_ms()
     # per batch: one primary launch (camera ray + its traversal + its shading), then rounds 1..4 of trace and
@@ -813,6 +814,49 @@ def test_stream_path_state_is_bounded():
     pt.close()
 
 
+@pytest.mark.parametrize("pipeline,tail", [("wavefront", 0), ("wavefront", -1), ("wavefront", 2), ("stream", 0), ("stream2", 0)])
+@pytest.mark.parametrize("budget", [1, 3, 17, 0])
+def test_suspended_traversals_bitwise(medium_scene, camera, pipeline, tail, budget):
+    """A trace wave that can get no more rays suspends its unfinished traversals after `budget` steps (node, t, hit and
+    the LDS stack go to a record), the logic launch carries the path over unchanged, the next trace launch resumes the
+    record (include/fspt.h: fspt_target_set_trace_budget).  With a budget of 1 almost every launch parks rays and
+    paths reach the lag limit; 0 switches it off.  Same frame as the oracle in every case."""
+    W, H, ticks = 128, 80, 6
+    pt = make_pt(medium_scene, W, H, camera, 8, pipeline, tail=tail)
+    pt.set_trace_budget(budget)
+    if pipeline.startswith("stream"):
+        pt.set_pool(3000)
+    pt.seed(31)
+    pt.render(ticks)
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"],
+             8, 0, ticks, 31, want)
+    assert np.array_equal(pt.readRadiance(), want)
+    pt.close()
+
+
+@pytest.mark.parametrize("pipeline", ["wavefront", "stream"])
+def test_suspended_traversals_deep_stack_and_refraction(small_scene, pipeline):
+    """Suspension records with the deepest stack the reference can walk (63 entries), and with a refracting material
+    (paths that outlive the bounce budget and are carried over on top of that)."""
+    from test_goldens import scene_from_golden
+    arrays = chain_scene(64, small_scene)
+    W, H = 72, 40
+    cam = dict(P=[64 + 2.5, 0.05, 0.1], I=[-1.0, -0.01, -0.02], fov_scale=0.5, env_theta=1.66, focal_depth=2.0,
+               aperture=0.02, lens=[0.5, 0.02])
+    for arr, c, nb in ((arrays, cam, 3),
+                       (scene_from_golden("variant"), dict(P=[0.3, 1.2, 3.4], I=[-0.05, -0.3, -0.95], fov_scale=0.5, env_theta=1.66,
+                                                          focal_depth=2.0, aperture=0.02, lens=[0.5, 0.02]), 4)):
+        want = np.zeros((H, W, 4), np.float32)
+        O.render(arr, W, H, c["P"], c["I"], c["fov_scale"], c["lens"], c["env_theta"], nb, 0, 3, 9, want)
+        pt = make_pt(arr, W, H, c, nb, pipeline)
+        pt.set_trace_budget(2)
+        pt.seed(9)
+        pt.render(3)
+        assert np.array_equal(pt.readRadiance(), want), pipeline
+        pt.close()
+
+
 def test_bvh_deeper_than_the_reference_stack_is_rejected():
     """tracer.fs:368 `int stack[64]`: a (degenerate, chain-shaped) tree deeper than 63 levels is refused."""
     import ctypes as C
@@ -991,6 +1035,36 @@ def test_multi_device_eight_way_full_hd(medium_scene, camera):
     n_tiles = 60 * 34
     assert mp.last_gather_bytes() == (n_tiles - len(range(0, n_tiles, 8))) * 32 * 32 * 16  # 7/8 of the tiles, whole tiles
     mp.close()
+
+
+@pytest.mark.parametrize("pipeline", ["wavefront", "stream"])
+def test_multi_render_returns_before_the_devices_are_done(medium_scene, camera, pipeline):
+    """fspt_multi_render is called from ONE host thread for all devices, so it must only enqueue: a
+    host-side wait inside it would serialise the devices.  The call has to come back long before the work is done
+    (fspt_multi_sync is what waits), on either scheduler; the frame still equals the single-target render."""
+    import time
+    from fspt_amd import MultiPathTracer
+    W, H, ticks = 640, 360, 128
+    mp = MultiPathTracer(medium_scene, W, H, devices=[0, 0, 0], num_bounces=8)
+    mp.set_pipeline(pipeline, 128)
+    mp.set_camera(camera["P"], camera["I"], camera["fov_scale"], camera["env_theta"], camera["focal_depth"], camera["aperture"])
+    assert all(mp.peer_access(i) == 3 for i in range(3))  # the same device: nothing to stage
+    mp.seed(5)
+    mp.render(ticks)  # warm-up: allocations happen here
+    mp.sync()
+    t0 = time.perf_counter()
+    mp.render(ticks)
+    t_enqueue = time.perf_counter() - t0
+    mp.sync()
+    t_total = time.perf_counter() - t0
+    assert t_enqueue < 0.5 * t_total, (t_enqueue, t_total)
+    got = mp.readRadiance()
+    mp.close()
+    pt = make_pt(medium_scene, W, H, camera, 8, "wavefront", 128, tail=-1)
+    pt.seed(5)
+    pt.render(2 * ticks)
+    assert np.array_equal(got, pt.readRadiance())
+    pt.close()
 
 
 def test_bound_torch_accumulator_and_tile_gather_on_gpu(small_scene, camera):
