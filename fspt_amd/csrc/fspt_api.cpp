@@ -54,7 +54,7 @@ struct fspt_scene {
 
 static const int WF_ARRAYS = 15;
 #ifndef FSPT_SUSP_BUDGET
-#define FSPT_SUSP_BUDGET 48
+#define FSPT_SUSP_BUDGET 24 // profiles/r03/ab_trace_suspend_budget.log: 0 / 16 / 24 / 32 / 48 -> 3 883 / 3 938 / 3 940 / 3 935 / 3 921 Msamples/s in 20-step regions (same box, twice)
 #endif
 static const uint32_t ST_DEFAULT_SUSP_BUDGET = FSPT_SUSP_BUDGET;
 struct fspt_target {
@@ -954,7 +954,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     // suspended traversals: off while counting (the tail kernel re-traces a carried path's rays, which would count twice)
     const bool susp_on = t->susp_budget != 0 && t->count == 0;
     if (susp_on && (rc = susp_ensure(t, ln))) return rc;
-    p.susp[0] = ln.susp[0]; p.susp[1] = ln.susp[1]; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
+    p.susp[0] = susp_on ? ln.susp[0] : nullptr; p.susp[1] = susp_on ? ln.susp[1] : nullptr; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
     for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
     // the previous batch's live-path counts, if their copy has landed: where the tail kernel takes over
     wf_collect_counts(t, ln);
@@ -1060,10 +1060,18 @@ static int st_plan(const fspt_target *t, uint32_t units, uint32_t nbt, uint32_t 
   const uint64_t all = (uint64_t)units * pl.unit_slots;
   if (cap > all) cap = all;
   if (cap < 2ull * pl.unit_slots) cap = 2ull * pl.unit_slots;
+  // every path generated in iteration k has ended after logic(k + horizon): the bounce budget, or - when a material can
+  // refract, tracer.fs:488 - the cap on loop iterations
+  pl.horizon = t->scene->has_dielectric ? (uint32_t)fspt::MAX_PATH_ITERS : (nb ? nb : 0u);
+  // a suspended traversal makes its path lag a round, at most WF_LAG_MAX times (fspt_device.hpp)
+  if (t->susp_budget != 0 && t->count == 0) pl.horizon += fspt::WF_LAG_MAX;
   if (t->mem_limit) {
-    // what the memory limit leaves per lane, at ~(204 + 12 * (horizon + 3) / 2) bytes per pool path
-    const uint64_t per_path = (wf_slot_bytes() - 12) + 6ull * ((t->scene->has_dielectric ? fspt::MAX_PATH_ITERS : (nb ? nb : 1u)) + 3u);
-    const uint64_t fit = t->mem_limit / t->n_lanes / per_path;
+    // what the memory limit leaves per lane: 204 bytes per pool path + its share of the ring, 12 * (horizon + 3) / 2
+    // (one stream: / 1) bytes, + one unit of rounding
+    const uint64_t per_path = (wf_slot_bytes() - 12) + (overlap ? 6ull : 12ull) * (pl.horizon + 3u);
+    const uint64_t lane_limit = t->mem_limit / t->n_lanes;
+    const uint64_t round_up = 12ull * (pl.horizon + 3u) * pl.unit_slots;
+    const uint64_t fit = lane_limit > round_up ? (lane_limit - round_up) / per_path : 0;
     if (cap > fit) cap = fit;
     if (cap < 2ull * pl.unit_slots) { fspt_set_error("the target's memory limit leaves no room for a pool of two units (%u paths)", 2u * pl.unit_slots); return FSPT_E_NOMEM; }
   }
@@ -1072,11 +1080,6 @@ static int st_plan(const fspt_target *t, uint32_t units, uint32_t nbt, uint32_t 
   // overlapped: plan(i) runs before logic(i) and has to leave room for every live path; one stream: it runs after
   pl.take_max = (uint32_t)(cap / (overlap ? 2 : 1) / pl.unit_slots);
   if (pl.take_max < 1) pl.take_max = 1;
-  // every path generated in iteration k has ended after logic(k + horizon): the bounce budget, or - when a material can
-  // refract, tracer.fs:488 - the cap on loop iterations
-  pl.horizon = t->scene->has_dielectric ? (uint32_t)fspt::MAX_PATH_ITERS : (nb ? nb : 0u);
-  // a suspended traversal makes its path lag a round, at most WF_LAG_MAX times (fspt_device.hpp)
-  if (t->susp_budget != 0 && t->count == 0) pl.horizon += fspt::WF_LAG_MAX;
   const uint64_t ring_units = (uint64_t)(pl.horizon + 3u) * pl.take_max;
   const uint64_t ring = (ring_units < units ? ring_units : units) * pl.unit_slots; // never more than the run itself
   if (ring > 0xFFFFFFFFull) { fspt_set_error("frame too large for the stream scheduler (fin ring of %llu samples)", (unsigned long long)ring); return FSPT_E_INVALID; }
@@ -1164,7 +1167,7 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
       p.work_total = units * 64u; p.n_batch = nbt; p.first_tick = first_tick + done;
       p.ring_slots = pl[l].ring_slots; p.cap = pl[l].cap; p.take_max = pl[l].take_max; p.pool = l;
       if (susp_on && (rc = susp_ensure(t, ln))) return rc;
-      p.susp[0] = ln.susp[0]; p.susp[1] = ln.susp[1]; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
+      p.susp[0] = susp_on ? ln.susp[0] : nullptr; p.susp[1] = susp_on ? ln.susp[1] : nullptr; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
       p.serial = overlap ? 0u : 1u;
       for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
       // how many iterations hand out all units: what the last such run needed, else from the pool's equilibrium
@@ -1568,7 +1571,7 @@ int fspt_target_set_memory_limit(fspt_target *t, uint64_t bytes) {
 int fspt_target_path_state_bytes(fspt_target *t, uint64_t *bytes, uint32_t *batch_ticks) {
   if (!t || !bytes) { fspt_set_error("fspt_target_path_state_bytes: NULL argument"); return FSPT_E_INVALID; }
   uint64_t b = 0;
-  for (auto &ln : t->lanes) b += ln.bytes;
+  for (auto &ln : t->lanes) b += ln.bytes; // (+ 2 x 59 MB of suspension records per lane on a 256-CU part, whatever the frame)
   *bytes = b;
   if (batch_ticks) *batch_ticks = t->batch_ticks;
   return FSPT_OK;

@@ -1062,8 +1062,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   WfCounts *cn = p.counts + p.cnt_out;
   const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
   // suspended traversals (fspt_device.hpp): the records the previous trace launch wrote are this launch's FIRST items
+  // (a launch with budget 0 - the last one of a batch - still RESUMES what the previous launch suspended)
   const bool susp_on = !COUNT && p.susp_budget != 0u;
-  const uint32_t n_res = susp_on ? p.counts[p.cnt_in].n_susp : 0u;
+  const uint32_t n_res = (!COUNT && p.susp[0] != nullptr) ? p.counts[p.cnt_in].n_susp : 0u;
   const int *__restrict__ rec_in = p.susp[p.cnt_in & 1u];
   int *rec_out = p.susp[p.cnt_out & 1u];
   const uint32_t total = cn->n_ext + n_res;
@@ -1083,7 +1084,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   // their results go to hit[] and shadow_hit[] independently), and the launch ends after ONE long ray, not two.  Small
   // launches consist of ray items only.  (Costs a second state fetch per split path; WF_TRACE_RAY_ITEMS x the resident lanes.)
   // (with suspended traversals the end of a launch is short anyway, and a record describes a whole path item)
-  const uint32_t split_paths = susp_on ? 0u : min(total, (uint32_t)WF_TRACE_RAY_ITEMS * n_waves * (uint32_t)WAVE);
+  const uint32_t split_paths = (susp_on || n_res != 0u) ? 0u : min(total, (uint32_t)WF_TRACE_RAY_ITEMS * n_waves * (uint32_t)WAVE);
   const uint32_t path_items = total - split_paths; // paths [0, path_items): one item per path
   // pool chunk: large while paths are plentiful (few atomics), one wave-load when they are scarce
   // (late rounds), so that every resident wave gets work
@@ -1215,7 +1216,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
     while (true) {
       unsigned long long in = __ballot(cur >= 0);
       if (in == 0ull) break;
-      if (starved && ++starve >= p.susp_budget) break;
 #if WF_INTERIOR_MIN > 1
       if ((uint32_t)__popcll(in) < WF_INTERIOR_MIN && __popcll(__ballot(!idle)) > __popcll(in)) break;
 #endif
@@ -1260,6 +1260,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
         cur = REF_SENTINEL;
       }
       }
+      // (checked AFTER the step: every pass of the outer loop moves its rays on, also the ones that may not be parked)
+      if (starved && ++starve >= p.susp_budget) break;
     }
     // ---- leaf ----
     if (!idle && cur < 0 && cur != REF_SENTINEL) {

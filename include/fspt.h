@@ -222,7 +222,7 @@ int fspt_target_set_pool(fspt_target *target, uint32_t paths, int drain_iteratio
  * handful of lanes.  A wave that can get no more rays walks on for `steps` traversal steps, then writes the state of its
  * unfinished traversals (node, t, hit, stack) to memory and ends; the next trace launch resumes them first, beside its
  * new rays (the path lags a round, at most four times).  Same traversal, same result.  0 = never suspend; the default
- * is 48.  Not used by the counting kernel variants.  (The reference has no counterpart: one fragment-shader invocation
+ * is 24.  Not used by the counting kernel variants.  (The reference has no counterpart: one fragment-shader invocation
  * walks its whole path, tracer.fs:436-518.) */
 int fspt_target_set_trace_budget(fspt_target *target, uint32_t steps);
 /* Wavefront path state lives in device memory: 216 bytes per (pixel, tick) of a batch.  It is sized for the largest

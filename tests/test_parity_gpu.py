@@ -792,6 +792,37 @@ def test_stream_refraction_keeps_units_open(pool):
     pt.close()
 
 
+def test_stream_pool_follows_the_memory_limit(medium_scene, camera):
+    """fspt_target_set_memory_limit caps the stream scheduler's pool + ring as it caps the batch scheduler's path state;
+    the frame does not change; a limit too small for two units is refused with FSPT_E_NOMEM."""
+    W, H, ticks = 320, 200, 40
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"],
+             8, 0, ticks, 3, want)
+    pt = make_pt(medium_scene, W, H, camera, 8, "stream")
+    pt.seed(3)
+    pt.render(ticks)
+    assert np.array_equal(pt.readRadiance(), want)
+    free_bytes, _ = pt.path_state_bytes()
+    pt.close()
+    pt = make_pt(medium_scene, W, H, camera, 8, "stream")
+    pt.set_memory_limit(16 << 20)
+    pt.seed(3)
+    pt.render(ticks)
+    assert np.array_equal(pt.readRadiance(), want)
+    nbytes, _ = pt.path_state_bytes()
+    assert 0 < nbytes <= 16 << 20 and nbytes < free_bytes
+    pt.close()
+    pt = make_pt(medium_scene, W, H, camera, 8, "stream")
+    pt.set_memory_limit(100 << 10)
+    pt.seed(3)
+    with pytest.raises(L.FsptError) as e:
+        pt.render(ticks)
+        pt.sync()
+    assert e.value.code == -4  # FSPT_E_NOMEM
+    pt.close()
+
+
 def test_stream_path_state_is_bounded():
     """VERDICT r2 'missing 2': the batch scheduler holds 216 bytes for every (pixel, tick) of a batch - 57 GB for 128 ticks
     of a 1920x1080 frame; the stream scheduler holds a pool and a ring of finished samples, whatever the tick count."""
@@ -805,7 +836,7 @@ def test_stream_path_state_is_bounded():
     pt.render(128)
     pt.sync()
     nbytes, _ = pt.path_state_bytes()
-    assert 0 < nbytes <= 3 << 30, nbytes
+    assert 0 < nbytes <= 6 << 30, nbytes  # 16 Mi-path pool 3.4 GB + ring of finished samples 1.5 GB + suspension records 0.1 GB
     pt.set_pool(2 << 20)
     pt.render(128)
     pt.sync()
