@@ -57,6 +57,10 @@ static const int WF_ARRAYS = 15;
 #define FSPT_SUSP_BUDGET 24 // profiles/r03/ab_trace_suspend_budget.log: 0 / 16 / 24 / 32 / 48 -> 3 883 / 3 938 / 3 940 / 3 935 / 3 921 Msamples/s in 20-step regions (same box, twice)
 #endif
 static const uint32_t ST_DEFAULT_SUSP_BUDGET = FSPT_SUSP_BUDGET;
+#ifndef FSPT_SPLIT_FINISH
+#define FSPT_SPLIT_FINISH 0
+#endif
+static const int ST_DEFAULT_SPLIT_FINISH = FSPT_SPLIT_FINISH;
 struct fspt_target {
   fspt_scene *scene = nullptr;
   uint32_t W = 0, H = 0;
@@ -81,6 +85,7 @@ struct fspt_target {
   int stream_drain = -1;      // stream: iterations after the last generating one before the tail kernel takes over (-1 = default)
   uint32_t stream_iter_cap = 0; // stream, test hook: at most this many iterations per run (the finishing launch does the rest)
   uint32_t susp_budget = ST_DEFAULT_SUSP_BUDGET; // traversal steps a starved trace wave walks on before it parks its rays (0 = never)
+  int split_finish = ST_DEFAULT_SPLIT_FINISH; // 0: k_wf_logic finishes the paths that end in a round itself; 1: k_wf_finish does, in front of it; 2: beside it on a second stream
   int stream_overlap = -1;      // stream: plan / primary / resolve on a second HIP stream beside the previous trace (1), everything on one stream (0), default (-1)
   uint32_t batch_ticks = 128; // ticks traced together by the wavefront pipeline (58 GB of path state at 1080p;
                               // measured 64 / 128 / 256 -> 3 619 / 3 794 / 3 750 Msamples/s, profiles/r01)
@@ -932,7 +937,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     fspt_target::WfLane &ln = t->lanes[bi % n_lanes];
     hipStream_t st = ln.stream;
     auto launch = [&](int kind) -> int {
-      int e = ev_begin(t, kind, st);
+      int e = kind == fspt::WF_K_FINISH ? ev_begin(t, fspt::WF_K_LOGIC, st) : (kind >= fspt::WF_K_KINDS ? -1 : ev_begin(t, kind, st));
       hipError_t err = fspt::launch_wf(kind, p, t->count, cus, st);
       ev_end(t, e, st);
       if (err != hipSuccess) { fspt_set_error("wavefront launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
@@ -953,6 +958,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     p.ctl = nullptr; p.ring_slots = nbt * work_total; p.pool = 0; p.n_pools = 1; p.finish = 0;
     // suspended traversals: off while counting (the tail kernel re-traces a carried path's rays, which would count twice)
     const bool susp_on = t->susp_budget != 0 && t->count == 0;
+    p.split_finish = t->split_finish ? 1u : 0u;
     if (susp_on && (rc = susp_ensure(t, ln))) return rc;
     p.susp[0] = susp_on ? ln.susp[0] : nullptr; p.susp[1] = susp_on ? ln.susp[1] : nullptr; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
     for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
@@ -973,7 +979,23 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     auto set_round = [&](uint32_t r) { p.round = r; p.cnt_in = r - 1; p.cnt_out = r; p.set_in = (r - 1) & 1u; p.set_out = r & 1u; };
     for (uint32_t r = 1; r <= last && r <= tail; ++r) {
       set_round(r);
+      if (r > 1 && susp_on) { if ((rc = launch(fspt::WF_K_CARRY))) return rc; } // the paths trace(r-1) suspended move on
+      if (r > 1 && t->split_finish) {
+        if (t->split_finish == 2) {
+          // beside the logic launch, on the lane's second stream: it reads the set logic(r) reads and writes fin only
+          HIP_TRY(hipEventRecord(ln.ev_b[0], st));
+          HIP_TRY(hipStreamWaitEvent(ln.stream_b, ln.ev_b[0], 0));
+          int e = ev_begin(t, fspt::WF_K_LOGIC, ln.stream_b);
+          hipError_t err = fspt::launch_wf(fspt::WF_K_FINISH, p, t->count, cus, ln.stream_b);
+          ev_end(t, e, ln.stream_b);
+          if (err != hipSuccess) { fspt_set_error("finish launch failed: %s", hipGetErrorString(err)); return FSPT_E_HIP; }
+          HIP_TRY(hipEventRecord(ln.ev_b[1], ln.stream_b));
+        } else if ((rc = launch(fspt::WF_K_FINISH))) return rc;
+      }
       if ((rc = launch(r == 1 ? fspt::WF_K_PRIMARY : fspt::WF_K_LOGIC))) return rc;
+      // the set finish(r) reads is overwritten by logic(r+1) / by the next batch's primary launch: both come after the trace
+      // launch or the resolve that follows here on `st`, which wait for it
+      if (r > 1 && t->split_finish == 2) HIP_TRY(hipStreamWaitEvent(st, ln.ev_b[1], 0));
       if (r < last && r < tail) {
         // the last trace launch of a batch lets its long rays finish: what it suspended the tail kernel would have to
         // trace again from the start
@@ -1135,7 +1157,7 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
 
   int rc = FSPT_OK;
   auto launch = [&](int kind, const fspt::WfP &p, hipStream_t st) -> int {
-    int e = kind == fspt::WF_K_PLAN ? -1 : ev_begin(t, kind, st);
+    int e = kind == fspt::WF_K_FINISH ? ev_begin(t, fspt::WF_K_LOGIC, st) : (kind >= fspt::WF_K_KINDS ? -1 : ev_begin(t, kind, st));
     hipError_t err = fspt::launch_wf(kind, p, t->count, cus, st);
     ev_end(t, e, st);
     if (err != hipSuccess) { fspt_set_error("stream launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
@@ -1169,6 +1191,7 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
       if (susp_on && (rc = susp_ensure(t, ln))) return rc;
       p.susp[0] = susp_on ? ln.susp[0] : nullptr; p.susp[1] = susp_on ? ln.susp[1] : nullptr; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
       p.serial = overlap ? 0u : 1u;
+      p.split_finish = t->split_finish ? 1u : 0u;
       for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
       // how many iterations hand out all units: what the last such run needed, else from the pool's equilibrium
       // (about 0.45 of the pool is new samples per iteration at 30 % survival per step)
@@ -1205,7 +1228,11 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
         p.round = it; p.cnt_in = (it + R - 1) % R; p.cnt_out = it % R; p.set_in = (it + 1) & 1u; p.set_out = it & 1u;
         if (!overlap) {
           // ---- one stream: logic(it) first, so that plan(it) sees what really survived and fills the pool to the brim
-          if (it >= 1) { if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc; }
+          if (it >= 1) {
+            if (susp_on && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
+            if (t->split_finish && (rc = launch(fspt::WF_K_FINISH, p, A))) return rc;
+            if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
+          }
           if ((rc = launch(fspt::WF_K_PLAN, p, A))) return rc;
           if ((rc = launch(fspt::WF_K_PRIMARY, p, A))) return rc;
           const int to = (int)it - (int)pl[l].horizon; // after logic(it) every path generated up to iteration `to` has ended
@@ -1233,6 +1260,8 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
         }
         // ---- A: logic(it) on the results of trace(it - 1), then trace(it) once primary(it) has added its survivors
         if (it >= 1) {
+          if (susp_on && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
+          if (t->split_finish && (rc = launch(fspt::WF_K_FINISH, p, A))) return rc;
           if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
           HIP_TRY(hipEventRecord(ln.ev_logic[it % R], A));
         }
@@ -1253,6 +1282,8 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
       hipStream_t A = ln.stream, B = overlap ? ln.stream_b : ln.stream;
       const uint32_t it = iters[l];
       p.round = it; p.cnt_in = (it + R - 1) % R; p.cnt_out = it % R; p.set_in = (it + 1) & 1u; p.set_out = it & 1u;
+      if (susp_on && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
+      if (t->split_finish && (rc = launch(fspt::WF_K_FINISH, p, A))) return rc;
       if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
       p.finish = 1;
       if ((rc = launch(fspt::WF_K_TAIL, p, A))) return rc;
@@ -1537,6 +1568,14 @@ int fspt_target_set_trace_budget(fspt_target *t, uint32_t steps) {
   if (!t) { fspt_set_error("fspt_target_set_trace_budget: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
   t->susp_budget = steps;
+  return FSPT_OK;
+}
+
+int fspt_target_set_finish_kernel(fspt_target *t, int mode) {
+  if (!t) { fspt_set_error("fspt_target_set_finish_kernel: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
+  if (mode < 0 || mode > 2) { fspt_set_error("fspt_target_set_finish_kernel: mode must be 0, 1 or 2"); return FSPT_E_INVALID; }
+  t->split_finish = mode;
   return FSPT_OK;
 }
 

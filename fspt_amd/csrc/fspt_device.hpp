@@ -145,8 +145,8 @@ constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17, WF_FLA
 // Suspended traversals (k_wf_trace): what a trace launch costs beyond its work is its LONGEST ray - a dependent chain of
 // up to a few hundred node fetches that a handful of lanes walk while the rest of the chip idles (~0.2 ms per launch,
 // profiles/r03).  A wave that can get no more work and has been walking for WfP::susp_budget steps writes the state of
-// its unfinished rays (node, t, hit, the LDS stack) to a record and ends; the logic launch carries such a path over to
-// the next state set unchanged (flag WF_FLAG_SUSP: the next trace launch must not start its rays afresh), and the next
+// its unfinished rays (node, t, hit, the LDS stack) to a record and ends; k_wf_carry (in front of the logic launch) moves
+// such a path on to the next state set unchanged (flag WF_FLAG_SUSP: the next trace launch must not start its rays afresh), and the next
 // trace launch resumes the records FIRST, beside its bulk of new rays.  Same traversal, same result; a path lags one
 // round per suspension (at most WF_LAG_MAX: the count lives in bits 20-22 of the flags).
 constexpr uint32_t WF_FLAG_SUSP = 1u << 19;
@@ -231,6 +231,7 @@ struct WfP {
   uint32_t serial;      // plan (stream): it runs AFTER logic(i) (one HIP stream) and sees the real survivors in counts[cnt_out]
   int *susp[2];         // suspended-traversal records: trace(i) writes susp[cnt_out & 1], resumes susp[cnt_in & 1]
   uint32_t susp_stride; // ints per record (WF_SUSP_HEADER + stack entries, a multiple of 4)
+  uint32_t split_finish; // the paths that end in a round are finished by k_wf_finish, k_wf_logic only shades
   uint32_t susp_budget; // traversal steps a wave walks on after its last refill before it suspends (0: never)
   uint32_t W, H;
   uint32_t vw, vh; // viewport, as in TraceP
@@ -249,7 +250,7 @@ struct WfP {
 };
 
 // kernel classes; also the slots of fspt_last_stage_ms
-enum { WF_K_PRIMARY = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3, WF_K_TAIL = 4, WF_K_KINDS = 5, WF_K_PLAN = 5 /* not timed */ };
+enum { WF_K_PRIMARY = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3, WF_K_TAIL = 4, WF_K_KINDS = 5, WF_K_PLAN = 5 /* not timed */, WF_K_CARRY = 6 /* not timed */, WF_K_FINISH = 7 /* timed with the logic class */ };
 // count: 0 = production kernels; 1 = counting variants doing the reference's work (NEE shadow rays traced to the closest
 // hit, tracer.fs:501); 2 = counting variants of the production work (shadow rays stop at the first hit)
 hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream_t stream);

@@ -698,9 +698,10 @@ FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randB
 // bounce (new rays in ps) or finish.  Returns true when the path is finished; ps.color
 // then holds the un-clamped sample colour.  Shared by the megakernel and the wavefront
 // pipeline so both run the same arithmetic in the same order.
+// ... its first half: everything but the shading of a live hit.  Returns true when the path is finished (k_wf_finish is
+// this half alone: the paths of a round that end need none of the shading code's 128 registers).
 template <bool COUNT>
-FM_DEV bool advance_path(const DScene &S, Path &ps, int hitA, float tB, int hitB, float randBase, float envTheta,
-                         uint32_t numBounces, Counters &cnt) {
+FM_DEV bool consume_rays(const DScene &S, Path &ps, int hitA, int hitB, float envTheta, uint32_t numBounces, Counters &cnt) {
   // NEE result (tracer.fs:500-505)
   if (ps.hasShadow && hitA == -1) {
     V3 es = env_sample<COUNT>(S, ps.envDir, envTheta, cnt);
@@ -718,6 +719,12 @@ FM_DEV bool advance_path(const DScene &S, Path &ps, int hitA, float tB, int hitB
     return true;
   }
   if (ps.bounce >= (int)numBounces || ps.iters >= MAX_PATH_ITERS) return true; // tracer.fs:446 bound, live hit
+  return false;
+}
+template <bool COUNT>
+FM_DEV bool advance_path(const DScene &S, Path &ps, int hitA, float tB, int hitB, float randBase, float envTheta,
+                         uint32_t numBounces, Counters &cnt) {
+  if (consume_rays<COUNT>(S, ps, hitA, hitB, envTheta, numBounces, cnt)) return true;
   shade_hit<COUNT>(S, ps, tB, hitB, randBase, envTheta, cnt);
   return false;
 }
@@ -1024,6 +1031,22 @@ FM_DEV void carry_path(const WfSet &in, const WfSet &o, uint32_t i, uint32_t k) 
   st4(o.B + k, b);
 }
 
+// ---- carry: the paths whose traversal the previous trace launch suspended move on to the next state set ---------------
+// One thread per record (a handful to a few thousand per launch): same state at a new index of the set this round's
+// logic launch writes (same counter), marked - the next trace launch resumes the record instead of starting the path's
+// rays afresh - one round of lag counted, and the record learns the new index.  A kernel of its own, launched in front of
+// k_wf_logic: inside the logic kernel the few lines cost the shading loop registers (9 spilled, profiles/r03).
+__global__ __launch_bounds__(BLOCK_THREADS) void k_wf_carry(const WfP p) {
+  const uint32_t n = p.counts[p.cnt_in].n_susp;
+  int *rec = p.susp[p.cnt_in & 1u];
+  for (uint32_t r = blockIdx.x * BLOCK_THREADS + threadIdx.x; r < n; r += gridDim.x * BLOCK_THREADS) {
+    int *q = rec + (size_t)r * p.susp_stride;
+    const uint32_t k_new = atomicAdd(&p.counts[p.cnt_out].n_ext, 1u);
+    carry_path(p.set[p.set_in], p.set[p.set_out], (uint32_t)q[0], k_new);
+    q[0] = (int)k_new;
+  }
+}
+
 // ---- trace: intersectScene for the rays of one round; persistent waves, per-lane refill -------
 // One item per live path k of the round: its NEE shadow ray (if it has one) and then its extension ray, traced by the
 // same lane one after the other (they share their origin: one state fetch, and no items that turn out to be empty).
@@ -1053,7 +1076,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   const DScene &S = p.scene;
   // one more LDS entry per lane than the tree needs: the lane's finished shadow result while its extension ray is traced
   // (a suspended traversal's record carries it along)
-  const uint32_t sn = S.stack_n + 1u;
+  const uint32_t sn = S.stack_n + 4u; // + 3: the extension ray's direction while the shadow ray is traced
   int *stack = lds_stack + (size_t)wave * sn * WAVE + lane;
   const float4 *__restrict__ nodes = S.nodes;
   const float *__restrict__ leaves = S.leaves;
@@ -1118,7 +1141,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   // shaded); bits 29-30: what the item covers - 0 both rays, 1 the extension ray, 2 the shadow ray, 3 nothing (the shadow
   // item of a path without one; the lane still goes through the finish step below)
   uint32_t path = 0;
-  V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0), d_ext = v3(0, 0, 1);
+  V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0);
   float t = MAX_T;
   int hit = -1, cur = REF_SENTINEL, sp = 0;
 
@@ -1155,7 +1178,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
         const float4 ro = ld4(st.A + k), rd = ld4(st.B + k);
         const float4 sd = ld4(st.D + k); // fetched alongside (only meaningful when the path has a shadow ray)
         o = v3(ro.x, ro.y, ro.z);
-        d_ext = v3(rd.x, rd.y, rd.z);
+        // the extension ray's direction waits in the lane's LDS column while the shadow ray is traced (3 registers that
+        // the leaf code needs: with them in registers it spilled 16 bytes per lane and leaf visit)
+        stack[(S.stack_n + 1u) * WAVE] = __float_as_int(rd.x); stack[(S.stack_n + 2u) * WAVE] = __float_as_int(rd.y); stack[(S.stack_n + 3u) * WAVE] = __float_as_int(rd.z);
         const uint32_t fl = __float_as_uint(rd.w);
         const bool has_shadow = (fl & WF_FLAG_SHADOW) != 0u;
         if (mode == 2u && !has_shadow) mode = 3u;
@@ -1175,7 +1200,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
           for (int i = 0; i < sp; ++i) stack[i * WAVE] = rec[WF_SUSP_HEADER + i];
           if (!is_shadow) { stack[S.stack_n * WAVE] = r1.y; if (has_shadow) sti(p.shadow_hit + k, r1.y); } // its shadow ray had finished before
         }
-        d = is_shadow ? v3(sd.x, sd.y, sd.z) : d_ext;
+        d = is_shadow ? v3(sd.x, sd.y, sd.z) : v3(rd.x, rd.y, rd.z);
         inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         const bool live = (fl & 255u) < p.num_bounces && ((fl >> 8) & 255u) < (uint32_t)MAX_PATH_ITERS;
         // bit 29 of a path item (mode 0): the traversal may be suspended (the path has not lagged WF_LAG_MAX rounds yet)
@@ -1287,7 +1312,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
           idle = true; // the extension ray is another lane's item
         } else {
           is_shadow = false;
-          d = d_ext;
+          d = v3(__int_as_float(stack[(S.stack_n + 1u) * WAVE]), __int_as_float(stack[(S.stack_n + 2u) * WAVE]), __int_as_float(stack[(S.stack_n + 3u) * WAVE]));
           inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
           t = MAX_T;
           hit = -1;
@@ -1494,18 +1519,20 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
     for (uint32_t u = 0; u < u_eff; ++u) {
       const uint32_t loc = u * WF_LOGIC_THREADS + threadIdx.x;
       const uint32_t i = base + loc;
-      bool shade = false, carry = false;
+      bool shade = false;
       if (i < n_in) {
         const int idx = __float_as_int(ld2(p.hit + i).y);
         shade = idx >= 0; // -1: miss; WF_HIT_TERMINAL: hit with the bounce budget used up
-        carry = idx == WF_HIT_PENDING; // its traversal was suspended: the path moves on unchanged (fspt_device.hpp)
-        if (!shade && !carry) own_fin |= 1u << u;
+        // (WF_HIT_PENDING: its traversal was suspended - k_wf_carry has moved the path on, nothing to do here)
+        // (p.split_finish: the paths that end here are k_wf_finish's)
+        if (!shade && idx != WF_HIT_PENDING && !p.split_finish) own_fin |= 1u << u;
       }
-      const unsigned long long m = __ballot(shade || carry);
+      const unsigned long long m = __ballot(shade);
       uint32_t wb = 0;
       if (lane == 0 && m) wb = atomicAdd(&s_n, (uint32_t)__popcll(m));
       wb = __builtin_amdgcn_readfirstlane(wb);
-      if (shade || carry) s_list[wb + lane_rank(m)] = (uint16_t)(loc | (carry ? 0x8000u : 0u)); // loc < U * 512 = 4096
+      if (shade) s_list[wb + lane_rank(m)] = (uint16_t)loc;
+
     }
     __syncthreads();
     uint32_t my_gbase = 0;
@@ -1533,17 +1560,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
         const uint32_t tsh = (jt - u_eff) * WF_LOGIC_THREADS + threadIdx.x;
         if ((jt - u_eff) * WF_LOGIC_THREADS >= n_shade) break; // block-uniform
         active = tsh < n_shade;
-        if (active) {
-          const uint32_t e = s_list[tsh];
-          i = base + (e & 0x7fffu); k_out = gbase + tsh;
-          if (e & 0x8000u) {
-            // carried over: same state at its new index, marked (the next trace launch resumes its record instead of
-            // starting its rays afresh) and one round of lag counted; the record learns the new index
-            carry_path(in, out, i, k_out);
-            p.susp[p.cnt_in & 1u][(size_t)__float_as_uint(ld2(p.hit + i).x) * p.susp_stride] = (int)k_out;
-            active = false;
-          }
-        }
+        if (active) { i = base + s_list[tsh]; k_out = gbase + tsh; }
       }
       if (active) {
         Path ps;
@@ -1558,6 +1575,34 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
       }
     }
     __syncthreads(); // s_list / s_total are rewritten by the next iteration
+  }
+  flush_counters<COUNT>(cnt, p.counters, 4, lane);
+}
+
+// ---- finish: the paths of a round that END in it (WfP::split_finish) -------------------------------------------------
+// Two paths in three of a round end there: the extension ray left the scene (environment lookup, tracer.fs:509-512) or
+// hit something with the bounce budget used up; before that the NEE result is added (tracer.fs:500-505).  That is two
+// random environment fetches and ~300 instructions - latency-bound work that k_wf_logic does at the 4 waves/SIMD its
+// shading code's 128 registers allow.  Here it runs by itself at 8 waves/SIMD, on a stream of its own beside the logic
+// launch (which then only shades): the two write different things (fin / the next state set).
+#ifndef WF_FINISH_WAVES
+#define WF_FINISH_WAVES 8
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK_THREADS, WF_FINISH_WAVES) void k_wf_finish(const WfP p) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const DScene &S = p.scene;
+  const WfSet in = p.set[p.set_in];
+  const uint32_t n_in = p.counts[p.cnt_in].n_ext;
+  Counters cnt = {0, 0, 0, 0, 0, 0};
+  for (uint32_t i = blockIdx.x * BLOCK_THREADS + threadIdx.x; i < n_in; i += gridDim.x * BLOCK_THREADS) {
+    const int idx = __float_as_int(ld2(p.hit + i).y);
+    if (idx >= 0 || idx == WF_HIT_PENDING) continue; // shaded by k_wf_logic / carried by k_wf_carry
+    Path ps;
+    int hitA;
+    const uint32_t slot = load_path(in, i, ps, p.shadow_hit, hitA);
+    consume_rays<COUNT>(S, ps, hitA, idx, p.env_theta, p.num_bounces, cnt);
+    st3(p.fin + 3 * (size_t)slot, ps.color);
   }
   flush_counters<COUNT>(cnt, p.counters, 4, lane);
 }
@@ -2062,10 +2107,20 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
     hipLaunchKernelGGL(k_wf_plan, dim3(1), dim3(WAVE), 0, stream, p);
     return hipGetLastError();
   }
+  if (kernel == WF_K_FINISH) {
+    const uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
+    if (count) hipLaunchKernelGGL(k_wf_finish<true>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(k_wf_finish<false>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
+    return hipGetLastError();
+  }
+  if (kernel == WF_K_CARRY) {
+    hipLaunchKernelGGL(k_wf_carry, dim3(64), dim3(BLOCK_THREADS), 0, stream, p);
+    return hipGetLastError();
+  }
   if (kernel == WF_K_TRACE) {
     // persistent: the grid only has to fill the machine; the pool heads balance the work
     uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
-    size_t lds = stack_bytes(p.scene) + (size_t)WAVES_PER_BLOCK * WAVE * sizeof(int); // + one entry per lane (k_wf_trace: sh_keep)
+    size_t lds = stack_bytes(p.scene) + (size_t)4 * WAVES_PER_BLOCK * WAVE * sizeof(int); // + four entries per lane (k_wf_trace: the kept shadow result, the extension ray's direction)
     // LDS left over per block at the occupancy the stacks (and the registers: 7 blocks) allow -> top-of-tree cache
     WfP q = p;
     {

@@ -352,6 +352,8 @@ class PathTracer {
   setPipeline(name, batch) { addon.setPipeline(this._target, PIPELINE_CODES[name] === undefined ? 1 : PIPELINE_CODES[name], batch || 0); }
   /** traversal steps a starved trace wave walks on before it suspends its rays (0 = never; include/fspt.h) */
   setTraceBudget(steps) { addon.setTraceBudget(this._target, steps); }
+  /** 0: the logic kernel finishes the paths that end in a round, 1: a kernel of its own in front of it, 2: beside it (include/fspt.h) */
+  setFinishKernel(mode) { addon.setFinishKernel(this._target, mode); }
   /** stream scheduler: live paths per state set (0 = default), drain iterations (-1 = default), iteration cap (0 = none) */
   setPool(paths, drain, maxIterations, overlap) { addon.setPool(this._target, paths || 0, drain === undefined ? -1 : drain, maxIterations || 0, overlap === undefined ? -1 : overlap); }
   /** -1 adaptive (default), 0 never, r >= 1: the tail kernel takes the live paths over after wavefront round r */

@@ -127,6 +127,10 @@ class PathTracer:
         """Traversal steps a starved trace wave walks on before it suspends its rays (0 = never; include/fspt.h)."""
         L.check(L.lib().fspt_target_set_trace_budget(self._t, int(steps)))
 
+    def set_finish_kernel(self, mode):
+        """0: the logic kernel finishes the paths that end in a round; 1: k_wf_finish in front of it; 2: beside it."""
+        L.check(L.lib().fspt_target_set_finish_kernel(self._t, int(mode)))
+
     def prepare(self):
         """Allocate the pipeline's path-state buffers now (not lazily inside the first render)."""
         L.check(L.lib().fspt_target_prepare(self._t))

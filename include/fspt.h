@@ -225,6 +225,12 @@ int fspt_target_set_pool(fspt_target *target, uint32_t paths, int drain_iteratio
  * is 24.  Not used by the counting kernel variants.  (The reference has no counterpart: one fragment-shader invocation
  * walks its whole path, tracer.fs:436-518.) */
 int fspt_target_set_trace_budget(fspt_target *target, uint32_t steps);
+/* Wavefront pipelines: who finishes the paths that END in a round (two in three: the extension ray left the scene -
+ * environment lookup, tracer.fs:509-512 - or the bounce budget is used up; the NEE result before that, :500-505).
+ * 0: the logic kernel, beside its shading; 1: a kernel of its own (8 waves/SIMD instead of the 4 the shading code's
+ * registers allow) in front of the logic launch; 2: the same on a second HIP stream beside the logic launch (batch
+ * scheduler).  Same arithmetic, same result. */
+int fspt_target_set_finish_kernel(fspt_target *target, int mode);
 /* Wavefront path state lives in device memory: 216 bytes per (pixel, tick) of a batch.  It is sized for the largest
  * n_ticks any call on this target has asked for so far (at most batch_ticks; fspt_trace = 1 tick = 0.46 GB at
  * 1920x1080, a 128-tick fspt_render = 58 GB) and grows when a longer call arrives.  fspt_target_set_memory_limit caps

@@ -44,7 +44,7 @@ def test_addon_exports():
                  "builderCreate", "builderParseObj", "builderCommit", "builderNormalize", "builderBuild",
                  "builderAutofocus", "builderDestroy", "envBins", "counters", "renderAsync", "multiCreate", "multiRender",
                  "multiRenderAsync", "multiReadRadiance", "multiDraw", "multiTarget", "multiDestroy", "setTail",
-                 "setMemoryLimit", "prepare", "setTextureInterleaveBudget", "setPool", "setTraceBudget"):
+                 "setMemoryLimit", "prepare", "setTextureInterleaveBudget", "setPool", "setTraceBudget", "setFinishKernel"):
         assert name in out["exports"]
 
 

@@ -888,6 +888,38 @@ def test_suspended_traversals_deep_stack_and_refraction(small_scene, pipeline):
         pt.close()
 
 
+@pytest.mark.parametrize("pipeline", ["wavefront", "stream"])
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("scene_name", ["medium", "variant"])
+def test_finish_kernel_bitwise(medium_scene, camera, pipeline, mode, scene_name):
+    """fspt_target_set_finish_kernel: the paths that end in a round (miss -> environment lookup, bounce budget used up,
+    NEE result) finished by k_wf_finish - in front of the logic launch (1) or beside it on a second stream (2) - instead
+    of by the logic kernel: radiance and work counters are the oracle's, with and without refraction."""
+    if scene_name == "variant":
+        from test_goldens import scene_from_golden
+        arrays = scene_from_golden("variant")
+        cam = dict(P=[0.3, 1.2, 3.4], I=[-0.05, -0.3, -0.95], fov_scale=0.5, env_theta=1.66, focal_depth=2.0, aperture=0.02)
+        cam["lens"] = [0.5, 0.02]
+    else:
+        arrays, cam = medium_scene, camera
+    W, H, ticks = 128, 80, 5
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 4, 0, ticks, 13, want, counters=oc)
+    for counting in (False, True):
+        pt = make_pt(arrays, W, H, cam, 4, pipeline, tail=-1)
+        pt.set_finish_kernel(mode)
+        if counting:
+            pt.enable_counters(True)
+        pt.clear()
+        pt.seed(13)
+        pt.render(ticks)
+        assert np.array_equal(pt.readRadiance(), want), (counting,)
+        if counting:
+            assert pt.counters() == oc.as_dict()
+        pt.close()
+
+
 def test_bvh_deeper_than_the_reference_stack_is_rejected():
     """tracer.fs:368 `int stack[64]`: a (degenerate, chain-shaped) tree deeper than 63 levels is refused."""
     import ctypes as C

@@ -39,16 +39,16 @@ def kname(n):
 
 
 for tag, wl in pairs:
-    name = os.path.basename(tag)  # the session may live in a sub-directory of gpurun_out
+    base = os.path.basename(tag)  # the session may live in a sub-directory of gpurun_out
     ks = newest(glob.glob(f"{G}/{tag}_kt/**/*kernel_stats.csv", recursive=True))
     if ks:
-        shutil.copy(ks[0], os.path.join(P, f"{name}_kernel_stats.csv"))
+        shutil.copy(ks[0], os.path.join(P, f"{base}_kernel_stats.csv"))
     log = f"{G}/{tag}_kt.log"
     samples = None
     if os.path.exists(log):
         for l in open(log):
             if l.startswith("{"):
-                open(os.path.join(P, f"{name}_bench.json.log"), "w").write(l)
+                open(os.path.join(P, f"{base}_bench.json.log"), "w").write(l)
                 j = json.loads(l)
                 w, h = re.search(r"(\d+)x(\d+)", j["metric"]).groups()
                 samples = int(w) * int(h) * j["steps"]  # samples of the one timed batch
@@ -96,7 +96,7 @@ for tag, wl in pairs:
             if k and "<true" not in k:
                 agg.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     if agg:
-        with open(os.path.join(P, f"{name}_pmc_summary.txt"), "w") as o:
+        with open(os.path.join(P, f"{base}_pmc_summary.txt"), "w") as o:
             for (k, c), v in agg.items():
                 o.write(f"{k:32s} {c:40s} launches={len(v):4d} sum={sum(v):.6g} mean={sum(v) / len(v):.6g}\n")
     # derived per-kernel figures: vector-memory pipeline busy fractions (instances calibrated on the saturated
@@ -134,7 +134,7 @@ for tag, wl in pairs:
     if derived:
         json.dump({"note": "from <tag>_pmc_summary.txt: bench.py --steps 32 --batch 32 (one 32-tick batch); busy = *_BUSY_sum / "
                            "GRBM_GUI_ACTIVE / 31.33 instances (profiles/r01/l1_pipe.json)", "kernels": derived},
-                  open(os.path.join(P, f"{name}_derived.json"), "w"), indent=1)
+                  open(os.path.join(P, f"{base}_derived.json"), "w"), indent=1)
         for k, d in derived.items():
             print(wl, k, d)
     for k, v in kern.items():
