@@ -11,7 +11,11 @@
 //    in one kernel.  k_wf_trace is a persistent while-while traversal with per-lane dynamic refill from the
 //    round's path list (one item per path: its shadow ray, then its extension ray), its deferred-child stack in
 //    LDS; k_wf_logic classifies the live paths, reserves the survivors' output range with one atomic per 4 096
-//    paths, finishes the others in place and shades the survivors with dense waves.
+//    paths, finishes the others in place and shades the survivors with dense waves.  Two schedulers drive these
+//    kernels (fspt_api.cpp): BATCHES - every (pixel, tick) of up to 128 ticks at once, rounds that drain to nothing - and
+//    a STREAM over a fixed pool of live paths that k_wf_plan keeps full (fspt_device.hpp: WfStreamCtl).  A trace wave
+//    that can get no more rays parks its unfinished traversals in records; k_wf_carry moves those paths on and the next
+//    trace launch resumes them first (fspt_device.hpp: suspended traversals).
 //  * megakernel (k_trace): one persistent kernel per tick; a lane whose path has
 //    terminated pulls the next pixel in place (path regeneration); the wave alternates
 //      S  consume traversal results (tracer.fs:501-512), finish / regenerate

@@ -12,7 +12,7 @@ os.makedirs(P, exist_ok=True)
 pairs = list(zip(sys.argv[1::2], sys.argv[2::2]))
 out = {"source_sha": bench.source_sha(),
        "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate runs) over `bench.py --warmup 0 --reps 1 --no-cpu-baseline"
-              " <the timed configuration>` (one timed region + the counting ticks, which run other kernel variants); bytes ="
+              " <the timed configuration>` (the warm-up and the timed regions of the driver's 20-step form + the counting ticks, which run other kernel variants); bytes ="
               " (2*FETCH_SIZE + WRITE_SIZE)*1024.  The factor 2 is calibrated for gathers too (profiles/r03/fetch_calib.json,"
               " tools/fetch_calib.sh): on gfx950 EVERY L2 read miss is one 128-byte request (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ,"
               " for 4-byte random reads and 16-byte streams alike) and FETCH_SIZE tallies it as 64 bytes; the kernels' own"
@@ -74,7 +74,7 @@ for tag, wl in pairs:
             if l.startswith("{"):
                 j = json.loads(l)
                 w, h = re.search(r"(\d+)x(\d+)", j["metric"]).groups()
-                samples = int(w) * int(h) * j["steps"]
+                samples = int(w) * int(h) * (j["steps"] * j.get("reps", 1) + j["warmup"])  # every tick the counters saw
     kern = {}
     for k, f in res["FETCH_SIZE"].items():
         w = res["WRITE_SIZE"].get(k, [])
@@ -87,7 +87,7 @@ for tag, wl in pairs:
         rq = rdreq.get(k)
         if rq:
             kern[k]["rdreq_by_size"] = {n: rq.get(n, 0.0) for n in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")}
-    out["workloads"][wl] = {"samples_per_region": samples, "kernels": kern}
+    out["workloads"][wl] = {"samples_counted": samples, "kernels": kern}
     # SQ / TA / TD summaries
     agg = collections.OrderedDict()
     for f in newest(glob.glob(f"{G}/{tag}_sq*/**/*counter_collection.csv", recursive=True)):

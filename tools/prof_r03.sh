@@ -11,13 +11,14 @@ O=$R/gpurun_out
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -- python3 $R/bench.py --no-cpu-baseline ${KT_ARGS:---steps 20 --warmup 5} "$@" > $O/${T}_kt.log 2>&1
 find $O/${T}_kt -name "*kernel_trace.csv" -size +8M -delete
-# traffic passes: the timed configuration itself (TRAFFIC_ARGS, default: what the driver runs), one region, no warm-up
-TA=${TRAFFIC_ARGS:---steps 20}
+# traffic passes: the timed configuration itself (TRAFFIC_ARGS, default: the driver's 20-step regions - one warm-up
+# region, whose first batch has no live-path statistics yet, and four timed ones; the counters sum all five)
+TA=${TRAFFIC_ARGS:---steps 20 --warmup 20 --reps 4}
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/${T}_$c -- python3 $R/bench.py --warmup 0 --reps 1 --no-cpu-baseline --no-parity-check $TA "$@" > $O/${T}_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/${T}_$c -- python3 $R/bench.py --no-cpu-baseline --no-parity-check $TA "$@" > $O/${T}_$c.log 2>&1
 done
 # request sizes behind FETCH_SIZE (profiles/r03/fetch_calib.json: every read request is a 128-byte line)
-timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/${T}_rdreq -- python3 $R/bench.py --warmup 0 --reps 1 --no-cpu-baseline --no-parity-check $TA "$@" > $O/${T}_rdreq.log 2>&1
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/${T}_rdreq -- python3 $R/bench.py --no-cpu-baseline --no-parity-check $TA "$@" > $O/${T}_rdreq.log 2>&1
 i=0
 for set in \
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU" \
