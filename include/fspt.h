@@ -235,7 +235,10 @@ int fspt_target_set_finish_kernel(fspt_target *target, int mode);
  * n_ticks any call on this target has asked for so far (at most batch_ticks; fspt_trace = 1 tick = 0.46 GB at
  * 1920x1080, a 128-tick fspt_render = 58 GB) and grows when a longer call arrives.  fspt_target_set_memory_limit caps
  * it (bytes; 0 = no cap): a batch that does not fit the cap - or the free device memory - is halved until it does,
- * which only costs speed (results do not depend on the batch size).  FSPT_E_NOMEM when even one tick does not fit. */
+ * which only costs speed (results do not depend on the batch size).  FSPT_E_NOMEM when even one tick does not fit.
+ * The stream scheduler (pipeline 3 / 4) holds a pool instead - 204 bytes per pool path + a ring of finished samples,
+ * 3.4 + 1.5 GB at the default 16 Mi paths whatever the frame and tick count - and the limit shrinks the pool
+ * (FSPT_E_NOMEM below two units of 64 pixels x the call's ticks). */
 int fspt_target_set_memory_limit(fspt_target *target, uint64_t bytes);
 /* Path-state bytes currently allocated by this target and the batch size in use (after any halving). */
 int fspt_target_path_state_bytes(fspt_target *target, uint64_t *bytes, uint32_t *batch_ticks);
