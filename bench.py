@@ -274,6 +274,12 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, local_rank, world)
 
+    # The request-rate peak the trace kernel is priced against is measured first, by a child process started BEFORE this
+    # process touches the GPU (no fork of a process that holds a HIP context).
+    global _L1_PEAK
+    if rank == 0 and _L1_PEAK is None:
+        _L1_PEAK = l1_request_peak()
+
     import numpy as np
     import torch
     import fspt_amd
@@ -412,6 +418,9 @@ def count_work(pt, mode, bounces=None):
     return c
 
 
+_L1_PEAK = None  # (peak, source) measured at the start of main()
+
+
 def l1_request_peak():
     """16-byte lane-requests/s of a pure per-lane gather of 64-byte records (4 x dwordx4 per lane, the traversal's node
     fetch) from an L2-resident table at k_wf_trace's occupancy, measured NOW on this box (tools/microbench/l1_peak.hip,
@@ -466,7 +475,7 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
         tr_leaf = act["leaves"] - ref0["leaves"]
         tr_paths = ref["shades"]  # one path item per shaded hit (its extension ray [+ shadow ray])
         tr_req = 4.0 * max(0, tr_int - act["trace_lds_steps"]) + 9.0 * tr_leaf + 4.0 * tr_paths
-        l1_peak, l1_src = l1_request_peak()
+        l1_peak, l1_src = _L1_PEAK if _L1_PEAK is not None else l1_request_peak()
         kernels = {}
         for k, (ms, n) in stages.items():
             name, bound = KERNELS[k]

@@ -1166,7 +1166,10 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
 
   uint32_t done = 0;
   while (done < n_ticks) {
-    const uint32_t nbt = n_ticks - done < (uint32_t)fspt::WF_MAX_BATCH ? n_ticks - done : (uint32_t)fspt::WF_MAX_BATCH;
+    uint32_t nbt = n_ticks - done < (uint32_t)fspt::WF_MAX_BATCH ? n_ticks - done : (uint32_t)fspt::WF_MAX_BATCH;
+    // the samples of a run are numbered in 32 bits (kernels: g = first + i): a frame beyond 2^32 / 128 pixels runs fewer ticks at a time
+    while (nbt > 1 && (uint64_t)work_total * nbt > 0xFFFFFFFFull) nbt /= 2;
+    if ((uint64_t)work_total * nbt > 0xFFFFFFFFull) { fspt_set_error("frame too large for the stream scheduler (more than 2^32 pixels per shard)"); return FSPT_E_INVALID; }
     fspt::WfP P[2];
     StPlan pl[2];
     uint32_t iters[2] = {0, 0};
