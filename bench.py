@@ -313,6 +313,9 @@ def main():
     pt = fspt_amd.PathTracer(arrays, W, H, device=local_rank, num_bounces=args.bounces)
     pt.set_camera(**cam)
     pt.set_shard(rank, n_gpus, D.TILE)
+    # a batch never holds more ticks than the longest call of this run: path state is allocated (and page-touched) for
+    # that, not for the 128-tick maximum (216 bytes per pixel and tick: 57 GB at 1920x1080 x 128, 9 GB x 20)
+    args.batch = max(1, min(args.batch, max(args.steps, args.warmup)))
     pt.set_pipeline(args.pipeline, args.batch)
     if args.trace_budget >= 0:
         pt.set_trace_budget(args.trace_budget)
@@ -569,7 +572,8 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
                    "env_bins": int(arrays.bins.size // 4), "atlas": f"{arrays.atlas_res}^2 x {arrays.atlas_layers}",
                    "sharding": f"32x32 tiles round-robin over {n_gpus}", "world_size_seen": world_seen,
                    "exchange": (args.exchange if n_gpus > 1 else "none"), "pipeline": args.pipeline,
-                   "batch_ticks": args.batch, "scene_build_s": round(build_s, 2), "source_sha": sha},
+                   "batch_ticks": args.batch, "path_state_bytes": pt.path_state_bytes()[0],
+                   "scene_build_s": round(build_s, 2), "source_sha": sha},
         "roofline": roofline,
     }
     if n_gpus == 1 and not args.no_cpu_baseline:

@@ -977,9 +977,10 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     uint32_t tail = wf_tail_round(t, (uint64_t)nbt * work_total, last);
     if ((t->scene->has_dielectric || susp_on) && tail > last) tail = last; // refraction / a suspended traversal: paths may outlive `last` rounds
     auto set_round = [&](uint32_t r) { p.round = r; p.cnt_in = r - 1; p.cnt_out = r; p.set_in = (r - 1) & 1u; p.set_out = r & 1u; };
+    bool prev_trace_suspends = false; // (no carry launch behind a trace launch that cannot have suspended anything)
     for (uint32_t r = 1; r <= last && r <= tail; ++r) {
       set_round(r);
-      if (r > 1 && susp_on) { if ((rc = launch(fspt::WF_K_CARRY))) return rc; } // the paths trace(r-1) suspended move on
+      if (r > 1 && susp_on && prev_trace_suspends) { if ((rc = launch(fspt::WF_K_CARRY))) return rc; } // the paths trace(r-1) suspended move on
       if (r > 1 && t->split_finish) {
         if (t->split_finish == 2) {
           // beside the logic launch, on the lane's second stream: it reads the set logic(r) reads and writes fin only
@@ -1002,6 +1003,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
         const uint32_t keep = p.susp_budget;
         if (r + 1 == (last < tail ? last : tail)) p.susp_budget = 0;
         if ((rc = launch(fspt::WF_K_TRACE))) return rc;
+        prev_trace_suspends = p.susp_budget != 0;
         p.susp_budget = keep;
       }
     }
@@ -1285,7 +1287,7 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
       hipStream_t A = ln.stream, B = overlap ? ln.stream_b : ln.stream;
       const uint32_t it = iters[l];
       p.round = it; p.cnt_in = (it + R - 1) % R; p.cnt_out = it % R; p.set_in = (it + 1) & 1u; p.set_out = it & 1u;
-      if (susp_on && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
+      // (no carry launch: the run's last trace launch does not suspend)
       if (t->split_finish && (rc = launch(fspt::WF_K_FINISH, p, A))) return rc;
       if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
       p.finish = 1;

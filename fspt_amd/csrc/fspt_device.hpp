@@ -150,7 +150,10 @@ constexpr uint32_t WF_FLAG_PRIMARY = 1u << 16, WF_FLAG_SHADOW = 1u << 17, WF_FLA
 // trace launch resumes the records FIRST, beside its bulk of new rays.  Same traversal, same result; a path lags one
 // round per suspension (at most WF_LAG_MAX: the count lives in bits 20-22 of the flags).
 constexpr uint32_t WF_FLAG_SUSP = 1u << 19;
-constexpr uint32_t WF_LAG_SHIFT = 20, WF_LAG_MASK = 7u, WF_LAG_MAX = 4u;
+#ifndef FSPT_WF_LAG_MAX
+#define FSPT_WF_LAG_MAX 4
+#endif
+constexpr uint32_t WF_LAG_SHIFT = 20, WF_LAG_MASK = 7u, WF_LAG_MAX = FSPT_WF_LAG_MAX;
 constexpr int WF_SUSP_HEADER = 8; // ints before the stack entries of a record: state index, node, t, hit, sp | ray << 8, shadow result, -, -
 #ifndef FSPT_WF_HEADS
 #define FSPT_WF_HEADS 16

@@ -1832,6 +1832,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
 // fin is slot-major (pixel-major): a wave reads 8 ticks of 64 pixels as full 128-byte segments, transposes them
 // through LDS and every lane folds its pixel's ticks in order (the running mean is order-dependent).
 #define WF_RESOLVE_TICKS 8
+#ifndef WF_RESOLVE_BLOCKS_PER_CU
+#define WF_RESOLVE_BLOCKS_PER_CU 16u
+#endif
 __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
   __shared__ float4 s_t[WAVES_PER_BLOCK][WAVE * (WF_RESOLVE_TICKS + 1)];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -2183,7 +2186,7 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
 #undef FSPT_LAUNCH_LOGIC
     }
   } else {
-    uint32_t grid = min((p.work_total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 16u);
+    uint32_t grid = min((p.work_total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * WF_RESOLVE_BLOCKS_PER_CU);
     hipLaunchKernelGGL(k_wf_resolve, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
   }
   return hipGetLastError();
