@@ -1353,6 +1353,20 @@ def test_fuzz_random_scenes_bitwise(seed):
         assert np.array_equal(got, want, equal_nan=True), f"{pipeline}: {(got != want).any(-1).sum()} of {W * H} pixels differ"
         assert pt.counters() == oc.as_dict(), pipeline
         pt.close()
+    # the production kernel variants (no counters): suspended traversals with a tiny budget - almost every launch parks
+    # rays - on both schedulers, the stream scheduler with a pool of a few units
+    for pipeline, pool in (("wavefront", 0), ("stream", 0), ("stream", 300 + 37 * seed)):
+        pt = PathTracer(sc, W, H, num_bounces=bounces)
+        pt.eye, pt.dir, pt.fovScale, pt.envTheta, pt.lensFeatures = cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["lens"]
+        pt.set_pipeline(pipeline, 2)
+        pt.set_trace_budget(1 + seed % 5)
+        if pool:
+            pt.set_pool(pool, seed % 4 - 1, 0, seed % 2)
+        pt.seed(rseed)
+        pt.render(3)
+        got = pt.readRadiance()
+        assert np.array_equal(got, want, equal_nan=True), f"{pipeline} pool {pool}: {(got != want).any(-1).sum()} of {W * H} pixels differ"
+        pt.close()
 
 
 def test_batch_is_halved_when_path_state_does_not_fit(small_scene, camera):
