@@ -94,9 +94,17 @@ static inline vec3 v_bary(vec3 w, vec3 a, vec3 b, vec3 c) {
 static inline float f_lerp(float x, float y, float a) { return om_fma(a, y - x, x); }
 
 /* ---- rnd (tracer.fs:181, camera.fs:19) --------------------------------- */
-static inline float rnd(float *seed) {
+static inline float rnd_seed(float *seed) {
   *seed = *seed + 0.211324865405187f;
   return om_fract(om_sin(*seed) * 43758.5453123f);
+}
+/* The tracer's `seed` global.  `rec` (probes only): the values the reference GLSL's own rnd()
+ * returned for the same calls, replayed in call order - takes the GLSL implementation's sin()
+ * out of a comparison of everything downstream of rnd(). */
+typedef struct { float seed; const float *rec; uint32_t used; } rng_t;
+static inline float rnd(rng_t *g) {
+  if (g->rec) return g->rec[g->used++];
+  return rnd_seed(&g->seed);
 }
 
 /* ---- data accessors (tracer.fs:105-179) -------------------------------- */
@@ -241,7 +249,7 @@ static vec3 env_sample(const oracle_scene *s, vec3 dir, float envTheta, oracle_c
   return env_color(s, cx, cy);
 }
 /* sampleEnv (tracer.fs:421-434) */
-static void sample_env(const oracle_scene *s, float envTheta, float *seed, vec3 *dir, float *pdf) {
+static void sample_env(const oracle_scene *s, float envTheta, rng_t *seed, vec3 *dir, float *pdf) {
   float nb = (float)s->n_bins;
   int idx = (int)(nb * rnd(seed));
   if (idx > (int)s->n_bins - 1) idx = (int)s->n_bins - 1;
@@ -311,7 +319,7 @@ static inline vec3 frame_combine(vec3 t, vec3 b, vec3 n, vec3 h) {
             om_fma(n.y, h.z, om_fma(b.y, h.y, t.y * h.x)),
             om_fma(n.z, h.z, om_fma(b.z, h.y, t.z * h.x)));
 }
-static vec3 sample_microfacet(vec3 normal, float rough, float *seed) {
+static vec3 sample_microfacet(vec3 normal, float rough, rng_t *seed) {
   float r1 = rnd(seed), r2 = rnd(seed);
   vec3 t, b; local_frame(normal, &t, &b);
   float a = om_max(0.001f, rough);
@@ -322,7 +330,7 @@ static vec3 sample_microfacet(vec3 normal, float rough, float *seed) {
   vec3 h = v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
   return frame_combine(t, b, normal, h);
 }
-static vec3 sample_lambert(vec3 normal, float *seed) {
+static vec3 sample_lambert(vec3 normal, rng_t *seed) {
   float r1 = rnd(seed), r2 = rnd(seed);
   vec3 t, b; local_frame(normal, &t, &b);
   float r = sqrtf(r1);
@@ -370,11 +378,150 @@ typedef struct {
   float macro_normal[3]; float bary_normal[3];
 } oracle_first_hit;
 
+/* ---- one iteration of the bounce loop, tracer.fs:447-499 ------------------
+ * From `Material mat = createMaterial(result.index)` to `vec2 weights = misWeights(...)`: everything
+ * between two intersectScene calls that does not touch `color` / `accumulatedReflectance`.  Shared by
+ * trace_pixel and by oracle_bounce_probe (the probe replays the GLSL's recorded rnd() values). */
+typedef struct {
+  vec3 origin;             /* hit point (tracer.fs:450) */
+  vec3 ro, rd;             /* the extension ray (ray.origin / ray.dir after the body) */
+  vec3 texDiffuse, texEmissive;
+  vec3 macroNormal, microNormal;
+  vec3 envDir; float envPdf, cosEnv;
+  vec3 bsdfThroughput, envThroughput;
+  float bsdfPdf; vec2 weights;
+  float dielectric;
+  float seed0;             /* tracer.fs:458 */
+  int inside, specular, refracted;
+} bounce_t;
+
+static inline void bounce_body(const oracle_scene *s, vec3 ro, vec3 rd, hit_t result, float randBase,
+                               float envTheta, rng_t *g, oracle_first_hit *fh, const float *tex, bounce_t *o) {
+  int ti = result.index;
+  const float *m = s->mat + (size_t)ti * 12;
+  float layDiffuse = m[0], laySpec = m[1], layNormal = m[2], layRough = m[3];
+  float ior = m[9], dielectric = m[10];
+  vec3 a, b, cc;
+  fetch_tri(s, ti, &a, &b, &cc);
+  const float *tuv = s->uv + (size_t)ti * 6;
+  vec3 origin = v_fma(rd, result.t, ro);
+  vec3 w = bary_weights(a, b, cc, origin);
+  vec2 tc;
+  tc.x = om_fma(w.z, tuv[4], om_fma(w.y, tuv[2], w.x * tuv[0]));
+  tc.y = om_fma(w.z, tuv[5], om_fma(w.y, tuv[3], w.x * tuv[1]));
+  float td[4], te[4], tm[4], tn[4];
+  atlas_fetch(s, tc, layDiffuse, td);
+  atlas_fetch(s, tc, laySpec, te);
+  atlas_fetch(s, tc, layRough, tm);
+  atlas_fetch(s, tc, layNormal, tn);
+  if (tex) { /* probes only: the four texture() results as the GLSL's sampler returned them */
+    td[0] = tex[0]; td[1] = tex[1]; td[2] = tex[2]; te[0] = tex[3]; te[1] = tex[4]; te[2] = tex[5];
+    tm[0] = tex[6]; tm[1] = tex[7]; tn[0] = tex[8]; tn[1] = tex[9]; tn[2] = tex[10];
+  }
+  vec3 texDiffuse = v3(td[0], td[1], td[2]);
+  vec3 texEmissive = v3(te[0], te[1], te[2]);
+  float metallic = tm[0], rough = tm[1];
+  vec3 texNormal = v3((tn[0] - 0.5f) * 2.0f, (tn[1] - 0.5f) * 2.0f, (tn[2] - 0.0f) * 1.0f);
+  rough = rough * rough;
+  g->seed = om_fma(origin.z, 4761.52835f, ((origin.x * randBase) * origin.y) * 1.396529836f);
+  o->seed0 = g->seed;
+  const float *nn = s->norm + (size_t)ti * 27;
+  vec3 n1 = v3(nn[0], nn[1], nn[2]), t1 = v3(nn[3], nn[4], nn[5]), b1 = v3(nn[6], nn[7], nn[8]);
+  vec3 n2 = v3(nn[9], nn[10], nn[11]), t2 = v3(nn[12], nn[13], nn[14]), b2 = v3(nn[15], nn[16], nn[17]);
+  vec3 n3 = v3(nn[18], nn[19], nn[20]), t3 = v3(nn[21], nn[22], nn[23]), b3 = v3(nn[24], nn[25], nn[26]);
+  vec3 baryNormal = v_bary(w, n1, n2, n3);
+  vec3 baryTangent = v_bary(w, t1, t2, t3);
+  vec3 baryBitangent = v_bary(w, b1, b2, b3);
+  vec3 macroNormal = v_normalize(
+      v3(om_fma(texNormal.z, baryNormal.x, om_fma(texNormal.y, baryBitangent.x, texNormal.x * baryTangent.x)),
+         om_fma(texNormal.z, baryNormal.y, om_fma(texNormal.y, baryBitangent.y, texNormal.x * baryTangent.y)),
+         om_fma(texNormal.z, baryNormal.z, om_fma(texNormal.y, baryBitangent.z, texNormal.x * baryTangent.z))));
+  if (fh) {
+    fh->origin[0] = origin.x; fh->origin[1] = origin.y; fh->origin[2] = origin.z;
+    fh->bary[0] = w.x; fh->bary[1] = w.y; fh->bary[2] = w.z;
+    fh->uv[0] = tc.x; fh->uv[1] = tc.y;
+    fh->diffuse[0] = td[0]; fh->diffuse[1] = td[1]; fh->diffuse[2] = td[2];
+    fh->emissive[0] = te[0]; fh->emissive[1] = te[1]; fh->emissive[2] = te[2];
+    fh->mr[0] = tm[0]; fh->mr[1] = tm[1];
+    fh->tex_normal[0] = texNormal.x; fh->tex_normal[1] = texNormal.y; fh->tex_normal[2] = texNormal.z;
+    fh->macro_normal[0] = macroNormal.x; fh->macro_normal[1] = macroNormal.y; fh->macro_normal[2] = macroNormal.z;
+    fh->bary_normal[0] = baryNormal.x; fh->bary_normal[1] = baryNormal.y; fh->bary_normal[2] = baryNormal.z;
+  }
+  int inside = v_dot(v_neg(rd), baryNormal) < 0.0f;
+  float nsx = inside ? ior : 1.0f, nsy = inside ? 1.0f : ior;
+  if (inside) macroNormal = v_neg(macroNormal);
+  vec3 off = v_scale(v_scale(macroNormal, EPSILON), 2.0f);
+  ro = v_add(origin, off);
+
+  vec3 incident = v_neg(rd);
+  vec3 envThroughput, bsdfThroughput;
+  float bsdfPdf;
+  vec3 microNormal = sample_microfacet(macroNormal, rough, g);
+  vec3 envDir; float envPdf;
+  sample_env(s, envTheta, g, &envDir, &envPdf);
+  float cosEnv = v_dot(macroNormal, envDir);
+  float F = schlick(incident, microNormal, nsx, nsy);
+  int specular = om_fma(1.0f, metallic, F * (1.0f - metallic)) > rnd(g);
+  int refracted = 0;
+  if (specular) {
+    /* reflect(-incident, microNormal) = I - 2*dot(N,I)*N */
+    vec3 I = v_neg(incident);
+    float k = 2.0f * v_dot(microNormal, I);
+    rd = v3(om_fma(-k, microNormal.x, I.x), om_fma(-k, microNormal.y, I.y), om_fma(-k, microNormal.z, I.z));
+    bsdfPdf = gtr2_pdf(incident, macroNormal, rough, rd);
+    vec3 es = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, rd);
+    float cl = om_clamp(v_dot(macroNormal, rd), 0.0f, 1.0f);
+    bsdfThroughput = v3((es.x * cl) / bsdfPdf, (es.y * cl) / bsdfPdf, (es.z * cl) / bsdfPdf);
+    vec3 ee = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, envDir);
+    float ce = om_clamp(cosEnv, 0.0f, 1.0f);
+    envThroughput = v3((ee.x * ce) / envPdf, (ee.y * ce) / envPdf, (ee.z * ce) / envPdf);
+  } else if (dielectric >= 0.0f) {
+    bsdfPdf = 1.0f;
+    bsdfThroughput = v3(1.0f, 1.0f, 1.0f);
+    envThroughput = v3(0.0f, 0.0f, 0.0f);
+    ro = v_sub(origin, off);
+    /* refract(-incident, microNormal, ns.x/ns.y) */
+    vec3 I = v_neg(incident);
+    float eta = nsx / nsy;
+    float dNI = v_dot(microNormal, I);
+    float kk = 1.0f - (eta * eta) * (1.0f - dNI * dNI);
+    if (kk < 0.0f) rd = v3(0.0f, 0.0f, 0.0f);
+    else {
+      float sc = om_fma(eta, dNI, sqrtf(kk));
+      rd = v3(om_fma(eta, I.x, -(sc * microNormal.x)), om_fma(eta, I.y, -(sc * microNormal.y)),
+              om_fma(eta, I.z, -(sc * microNormal.z)));
+    }
+    refracted = 1; /* i--, tracer.fs:488 */
+  } else {
+    rd = sample_lambert(macroNormal, g);
+    bsdfPdf = om_abs(v_dot(rd, macroNormal)) * INV_PI_F;
+    float cl = om_clamp(v_dot(macroNormal, rd), 0.0f, 1.0f);
+    bsdfThroughput = v3(((texDiffuse.x * INV_PI_F) * cl) / bsdfPdf, ((texDiffuse.y * INV_PI_F) * cl) / bsdfPdf,
+                        ((texDiffuse.z * INV_PI_F) * cl) / bsdfPdf);
+    float ce = om_clamp(cosEnv, 0.0f, 1.0f);
+    envThroughput = v3(((texDiffuse.x * INV_PI_F) * ce) / envPdf, ((texDiffuse.y * INV_PI_F) * ce) / envPdf,
+                       ((texDiffuse.z * INV_PI_F) * ce) / envPdf);
+  }
+  if (inside) { /* tracer.fs:497 */
+    bsdfThroughput = v3(om_max(1.0f - (((1.0f - texDiffuse.x) * result.t) * dielectric), 0.0f),
+                        om_max(1.0f - (((1.0f - texDiffuse.y) * result.t) * dielectric), 0.0f),
+                        om_max(1.0f - (((1.0f - texDiffuse.z) * result.t) * dielectric), 0.0f));
+  }
+  o->origin = origin; o->ro = ro; o->rd = rd;
+  o->texDiffuse = texDiffuse; o->texEmissive = texEmissive;
+  o->macroNormal = macroNormal; o->microNormal = microNormal;
+  o->envDir = envDir; o->envPdf = envPdf; o->cosEnv = cosEnv;
+  o->bsdfThroughput = bsdfThroughput; o->envThroughput = envThroughput;
+  o->bsdfPdf = bsdfPdf; o->weights = mis_weights(envPdf, bsdfPdf);
+  o->dielectric = dielectric;
+  o->inside = inside; o->specular = specular; o->refracted = refracted;
+}
+
 /* ---- tracer.fs main (436-518) for one pixel ----------------------------- */
 static void trace_pixel(const oracle_scene *s, vec3 ro, vec3 rd, uint32_t tick, float randBase,
                         float envTheta, uint32_t numBounces, float *accum /*rgba*/,
                         oracle_counters *c, oracle_first_hit *fh) {
-  float seed = 0.0f;
+  rng_t g = {0.0f, NULL, 0};
   if (c) c->samples++;
   hit_t result = intersect_scene(s, ro, rd, c, NULL, NULL);
   vec3 color = v3(0.0f, 0.0f, 0.0f);
@@ -386,129 +533,29 @@ static void trace_pixel(const oracle_scene *s, vec3 ro, vec3 rd, uint32_t tick, 
     int iters = 0;
     for (int i = 0; i < (int)numBounces && iters < ORACLE_MAX_PATH_ITERS; ++i, ++iters) {
       if (c) c->shades++;
-      int ti = result.index;
-      const float *m = s->mat + (size_t)ti * 12;
-      float layDiffuse = m[0], laySpec = m[1], layNormal = m[2], layRough = m[3];
-      float ior = m[9], dielectric = m[10];
-      vec3 a, b, cc;
-      fetch_tri(s, ti, &a, &b, &cc);
-      const float *tuv = s->uv + (size_t)ti * 6;
-      vec3 origin = v_fma(rd, result.t, ro);
-      vec3 w = bary_weights(a, b, cc, origin);
-      vec2 tc;
-      tc.x = om_fma(w.z, tuv[4], om_fma(w.y, tuv[2], w.x * tuv[0]));
-      tc.y = om_fma(w.z, tuv[5], om_fma(w.y, tuv[3], w.x * tuv[1]));
-      float td[4], te[4], tm[4], tn[4];
-      atlas_fetch(s, tc, layDiffuse, td);
-      atlas_fetch(s, tc, laySpec, te);
-      atlas_fetch(s, tc, layRough, tm);
-      atlas_fetch(s, tc, layNormal, tn);
-      vec3 texDiffuse = v3(td[0], td[1], td[2]);
-      vec3 texEmissive = v3(te[0], te[1], te[2]);
-      float metallic = tm[0], rough = tm[1];
-      vec3 texNormal = v3((tn[0] - 0.5f) * 2.0f, (tn[1] - 0.5f) * 2.0f, (tn[2] - 0.0f) * 1.0f);
-      rough = rough * rough;
-      seed = om_fma(origin.z, 4761.52835f, ((origin.x * randBase) * origin.y) * 1.396529836f);
-      const float *nn = s->norm + (size_t)ti * 27;
-      vec3 n1 = v3(nn[0], nn[1], nn[2]), t1 = v3(nn[3], nn[4], nn[5]), b1 = v3(nn[6], nn[7], nn[8]);
-      vec3 n2 = v3(nn[9], nn[10], nn[11]), t2 = v3(nn[12], nn[13], nn[14]), b2 = v3(nn[15], nn[16], nn[17]);
-      vec3 n3 = v3(nn[18], nn[19], nn[20]), t3 = v3(nn[21], nn[22], nn[23]), b3 = v3(nn[24], nn[25], nn[26]);
-      vec3 baryNormal = v_bary(w, n1, n2, n3);
-      vec3 baryTangent = v_bary(w, t1, t2, t3);
-      vec3 baryBitangent = v_bary(w, b1, b2, b3);
-      vec3 macroNormal = v_normalize(
-          v3(om_fma(texNormal.z, baryNormal.x, om_fma(texNormal.y, baryBitangent.x, texNormal.x * baryTangent.x)),
-             om_fma(texNormal.z, baryNormal.y, om_fma(texNormal.y, baryBitangent.y, texNormal.x * baryTangent.y)),
-             om_fma(texNormal.z, baryNormal.z, om_fma(texNormal.y, baryBitangent.z, texNormal.x * baryTangent.z))));
-      if (fh && iters == 0) {
-        fh->origin[0] = origin.x; fh->origin[1] = origin.y; fh->origin[2] = origin.z;
-        fh->bary[0] = w.x; fh->bary[1] = w.y; fh->bary[2] = w.z;
-        fh->uv[0] = tc.x; fh->uv[1] = tc.y;
-        fh->diffuse[0] = td[0]; fh->diffuse[1] = td[1]; fh->diffuse[2] = td[2];
-        fh->emissive[0] = te[0]; fh->emissive[1] = te[1]; fh->emissive[2] = te[2];
-        fh->mr[0] = tm[0]; fh->mr[1] = tm[1];
-        fh->tex_normal[0] = texNormal.x; fh->tex_normal[1] = texNormal.y; fh->tex_normal[2] = texNormal.z;
-        fh->macro_normal[0] = macroNormal.x; fh->macro_normal[1] = macroNormal.y; fh->macro_normal[2] = macroNormal.z;
-        fh->bary_normal[0] = baryNormal.x; fh->bary_normal[1] = baryNormal.y; fh->bary_normal[2] = baryNormal.z;
-      }
-      int inside = v_dot(v_neg(rd), baryNormal) < 0.0f;
-      float nsx = inside ? ior : 1.0f, nsy = inside ? 1.0f : ior;
-      if (inside) macroNormal = v_neg(macroNormal);
-      vec3 off = v_scale(v_scale(macroNormal, EPSILON), 2.0f);
-      ro = v_add(origin, off);
-
-      color = v3(om_fma((thr.x * texEmissive.x) * texDiffuse.x, 30.0f, color.x),
-                 om_fma((thr.y * texEmissive.y) * texDiffuse.y, 30.0f, color.y),
-                 om_fma((thr.z * texEmissive.z) * texDiffuse.z, 30.0f, color.z));
-      vec3 incident = v_neg(rd);
-      vec3 envThroughput, bsdfThroughput;
-      float bsdfPdf;
-      vec3 microNormal = sample_microfacet(macroNormal, rough, &seed);
-      vec3 envDir; float envPdf;
-      sample_env(s, envTheta, &seed, &envDir, &envPdf);
-      float cosEnv = v_dot(macroNormal, envDir);
-      float F = schlick(incident, microNormal, nsx, nsy);
-      int specular = om_fma(1.0f, metallic, F * (1.0f - metallic)) > rnd(&seed);
-      if (specular) {
-        /* reflect(-incident, microNormal) = I - 2*dot(N,I)*N */
-        vec3 I = v_neg(incident);
-        float k = 2.0f * v_dot(microNormal, I);
-        rd = v3(om_fma(-k, microNormal.x, I.x), om_fma(-k, microNormal.y, I.y), om_fma(-k, microNormal.z, I.z));
-        bsdfPdf = gtr2_pdf(incident, macroNormal, rough, rd);
-        vec3 es = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, rd);
-        float cl = om_clamp(v_dot(macroNormal, rd), 0.0f, 1.0f);
-        bsdfThroughput = v3((es.x * cl) / bsdfPdf, (es.y * cl) / bsdfPdf, (es.z * cl) / bsdfPdf);
-        vec3 ee = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, envDir);
-        float ce = om_clamp(cosEnv, 0.0f, 1.0f);
-        envThroughput = v3((ee.x * ce) / envPdf, (ee.y * ce) / envPdf, (ee.z * ce) / envPdf);
-      } else if (dielectric >= 0.0f) {
-        bsdfPdf = 1.0f;
-        bsdfThroughput = v3(1.0f, 1.0f, 1.0f);
-        envThroughput = v3(0.0f, 0.0f, 0.0f);
-        ro = v_sub(origin, off);
-        /* refract(-incident, microNormal, ns.x/ns.y) */
-        vec3 I = v_neg(incident);
-        float eta = nsx / nsy;
-        float dNI = v_dot(microNormal, I);
-        float kk = 1.0f - (eta * eta) * (1.0f - dNI * dNI);
-        if (kk < 0.0f) rd = v3(0.0f, 0.0f, 0.0f);
-        else {
-          float sc = om_fma(eta, dNI, sqrtf(kk));
-          rd = v3(om_fma(eta, I.x, -(sc * microNormal.x)), om_fma(eta, I.y, -(sc * microNormal.y)),
-                  om_fma(eta, I.z, -(sc * microNormal.z)));
-        }
-        i--; /* tracer.fs:488 */
-      } else {
-        rd = sample_lambert(macroNormal, &seed);
-        bsdfPdf = om_abs(v_dot(rd, macroNormal)) * INV_PI_F;
-        float cl = om_clamp(v_dot(macroNormal, rd), 0.0f, 1.0f);
-        bsdfThroughput = v3(((texDiffuse.x * INV_PI_F) * cl) / bsdfPdf, ((texDiffuse.y * INV_PI_F) * cl) / bsdfPdf,
-                            ((texDiffuse.z * INV_PI_F) * cl) / bsdfPdf);
-        float ce = om_clamp(cosEnv, 0.0f, 1.0f);
-        envThroughput = v3(((texDiffuse.x * INV_PI_F) * ce) / envPdf, ((texDiffuse.y * INV_PI_F) * ce) / envPdf,
-                           ((texDiffuse.z * INV_PI_F) * ce) / envPdf);
-      }
-      if (inside) { /* tracer.fs:497 */
-        bsdfThroughput = v3(om_max(1.0f - (((1.0f - texDiffuse.x) * result.t) * dielectric), 0.0f),
-                            om_max(1.0f - (((1.0f - texDiffuse.y) * result.t) * dielectric), 0.0f),
-                            om_max(1.0f - (((1.0f - texDiffuse.z) * result.t) * dielectric), 0.0f));
-      }
-      vec2 weights = mis_weights(envPdf, bsdfPdf);
-      if (dielectric < 0.0f && cosEnv > 0.0f) {
-        hit_t shadow = intersect_scene(s, ro, envDir, c, NULL, NULL);
+      bounce_t b;
+      bounce_body(s, ro, rd, result, randBase, envTheta, &g, (fh && iters == 0) ? fh : NULL, NULL, &b);
+      ro = b.ro; rd = b.rd;
+      /* tracer.fs:467 */
+      color = v3(om_fma((thr.x * b.texEmissive.x) * b.texDiffuse.x, 30.0f, color.x),
+                 om_fma((thr.y * b.texEmissive.y) * b.texDiffuse.y, 30.0f, color.y),
+                 om_fma((thr.z * b.texEmissive.z) * b.texDiffuse.z, 30.0f, color.z));
+      if (b.refracted) i--; /* tracer.fs:488 */
+      if (b.dielectric < 0.0f && b.cosEnv > 0.0f) {
+        hit_t shadow = intersect_scene(s, ro, b.envDir, c, NULL, NULL);
         if (shadow.index == -1) {
-          vec3 es = env_sample(s, envDir, envTheta, c);
-          color = v3(om_fma((thr.x * envThroughput.x) * es.x, weights.x, color.x),
-                     om_fma((thr.y * envThroughput.y) * es.y, weights.x, color.y),
-                     om_fma((thr.z * envThroughput.z) * es.z, weights.x, color.z));
+          vec3 es = env_sample(s, b.envDir, envTheta, c);
+          color = v3(om_fma((thr.x * b.envThroughput.x) * es.x, b.weights.x, color.x),
+                     om_fma((thr.y * b.envThroughput.y) * es.y, b.weights.x, color.y),
+                     om_fma((thr.z * b.envThroughput.z) * es.z, b.weights.x, color.z));
         }
       }
       result = intersect_scene(s, ro, rd, c, NULL, NULL);
-      thr = v_mul(thr, bsdfThroughput);
+      thr = v_mul(thr, b.bsdfThroughput);
       if (result.index == -1) {
         vec3 es = env_sample(s, rd, envTheta, c);
-        color = v3(om_fma(thr.x * es.x, weights.y, color.x), om_fma(thr.y * es.y, weights.y, color.y),
-                   om_fma(thr.z * es.z, weights.y, color.z));
+        color = v3(om_fma(thr.x * es.x, b.weights.y, color.x), om_fma(thr.y * es.y, b.weights.y, color.y),
+                   om_fma(thr.z * es.z, b.weights.y, color.z));
         break;
       }
     }
@@ -540,17 +587,17 @@ static void camera_pixel(uint32_t x, uint32_t y, uint32_t W, uint32_t H, const f
   screen.y = (om_fma(icy * basisY.y, fovScale, (icx * basisX.y) * fovScale) + Iv.y) + Pv.y;
   screen.z = (om_fma(icy * basisY.z, fovScale, (icx * basisX.z) * fovScale) + Iv.z) + Pv.z;
   /* getAA (camera.fs:26-30) */
-  float theta = (rnd(&seed) * M_PI_F) * 2.0f;
-  float r = sqrtf(rnd(&seed)) * 1.414f;
+  float theta = (rnd_seed(&seed) * M_PI_F) * 2.0f;
+  float r = sqrtf(rnd_seed(&seed)) * 1.414f;
   float ct = om_cos(theta), st = om_sin(theta);
   vec3 aa;
   aa.x = (r * ((basisX.x * ct) / resx + (basisY.x * st) / resy)) * fovScale;
   aa.y = (r * ((basisX.y * ct) / resx + (basisY.y * st) / resy)) * fovScale;
   aa.z = (r * ((basisX.z * ct) / resx + (basisY.z * st) / resy)) * fovScale;
   /* getDOF (camera.fs:32-35) */
-  float theta2 = (rnd(&seed) * M_PI_F) * 2.0f;
+  float theta2 = (rnd_seed(&seed) * M_PI_F) * 2.0f;
   float c2 = om_cos(theta2), s2 = om_sin(theta2);
-  float sq = sqrtf(rnd(&seed));
+  float sq = sqrtf(rnd_seed(&seed));
   vec3 dof;
   dof.x = (om_fma(s2, basisY.x, c2 * basisX.x) * lens[1]) * sq;
   dof.y = (om_fma(s2, basisY.y, c2 * basisX.y) * lens[1]) * sq;
@@ -695,7 +742,7 @@ void oracle_math_eval(int op, const float *a, const float *b, uint32_t n, float 
       case 4: out[i] = om_exp2(x); break;
       case 5: out[i] = x / y; break;
       case 6: out[i] = sqrtf(x); break;
-      case 7: { float sd = x; out[i] = rnd(&sd); break; }
+      case 7: { float sd = x; out[i] = rnd_seed(&sd); break; }
       case 8: out[i] = om_fract(x); break;
       case 9: out[i] = om_log2(x); break;
       case 10: out[i] = om_pow(x, y); break;
@@ -745,6 +792,75 @@ void oracle_brdf_probe(const oracle_scene *s, int which, const float *in, uint32
       vec3 r = env_sample(s, v_normalize(a), rough, NULL);
       o[0] = r.x; o[1] = r.y; o[2] = r.z;
     }
+  }
+}
+
+/* Probes of the STOCHASTIC functions with the reference GLSL's own random numbers replayed
+ * (tools/make_goldens.py records what tracer.fs's rnd() returned for every call; `rec` holds them
+ * in call order, `rec_stride` floats per item), so that everything downstream of rnd() is compared
+ * deterministically and the GLSL implementation's sin() drops out.
+ *   in: n x 4 floats (normal.xyz as given - not re-normalised, tracer.fs passes macroNormal -, metallicRoughness.y)
+ *   which 0: sampleMicrofacet (tracer.fs:256-270)  -> halfvector.xyz, number of rnd() calls
+ *   which 1: sampleLambert    (tracer.fs:272-280)  -> dir.xyz, number of rnd() calls
+ *   which 2: sampleEnv        (tracer.fs:421-434)  -> dir.xyz, pdf */
+void oracle_sampler_probe(const oracle_scene *s, int which, const float *in, const float *rec,
+                          uint32_t rec_stride, float envTheta, uint32_t n, float *out) {
+  for (uint32_t i = 0; i < n; ++i) {
+    const float *p = in + (size_t)i * 4;
+    rng_t g = {0.0f, rec + (size_t)i * rec_stride, 0};
+    vec3 nrm = v3(p[0], p[1], p[2]);
+    float *o = out + (size_t)i * 4;
+    vec3 r = v3(0.0f, 0.0f, 0.0f);
+    float w = 0.0f;
+    if (which == 0) { r = sample_microfacet(nrm, p[3], &g); w = (float)g.used; }
+    else if (which == 1) { r = sample_lambert(nrm, &g); w = (float)g.used; }
+    else if (which == 2) { sample_env(s, envTheta, &g, &r, &w); }
+    o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = w;
+  }
+}
+
+/* One iteration of the bounce loop (bounce_body = tracer.fs:447-499) for caller-supplied rays and hits
+ * (t, index as the GLSL's own intersectScene returned them), rnd() replayed from `rec` (8 per item; NULL:
+ * the oracle's own sin-hash from the tracer.fs:458 seed) and, optionally, the four texture() results of
+ * tracer.fs:453-456 replayed from `tex` (12 per item: diffuse.rgb, emissive.rgb, metallicRoughness.rg,
+ * normal-map.rgb, pad; NULL: the oracle's own bilinear fetch) - the GLSL implementation's sampler precision
+ * is pinned separately (stage D3).  out: n x ORACLE_BOUNCE_FLOATS floats:
+ *   0 seed (tracer.fs:458)  1 inside  2 specular  3 bsdfPdf | 4-6 ray.dir  7 weights.x | 8-10 ray.origin  11 weights.y
+ *   12-14 bsdfThroughput  15 cosEnv | 16-18 envThroughput  19 envDirPdf.a | 20-22 envDirPdf.xyz  23 refracted (i--)
+ *   24-26 colour added by tracer.fs:467 at accumulatedReflectance 1  27 rnd() calls | 28-30 microNormal  31 0
+ *   32-34 macroNormal (after the `inside` flip)  35 mat.dielectric */
+#define ORACLE_BOUNCE_FLOATS 36
+void oracle_bounce_probe(const oracle_scene *s, const float *rays, const float *t_in, const int32_t *index_in,
+                         float randBase, float envTheta, const float *rec, const float *tex, uint32_t n,
+                         float *out) {
+  for (uint32_t i = 0; i < n; ++i) {
+    float *o = out + (size_t)i * ORACLE_BOUNCE_FLOATS;
+    for (int k = 0; k < ORACLE_BOUNCE_FLOATS; ++k) o[k] = 0.0f;
+    if (index_in[i] < 0) continue;
+    vec3 ro = v3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
+    vec3 rd = v3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    hit_t h = {t_in[i], index_in[i]};
+    rng_t g = {0.0f, rec ? rec + (size_t)i * 8 : NULL, 0};
+    bounce_t b;
+    bounce_body(s, ro, rd, h, randBase, envTheta, &g, NULL, tex ? tex + (size_t)i * 12 : NULL, &b);
+    o[0] = b.seed0; o[1] = (float)b.inside; o[2] = (float)b.specular; o[3] = b.bsdfPdf;
+    o[4] = b.rd.x; o[5] = b.rd.y; o[6] = b.rd.z; o[7] = b.weights.x;
+    o[8] = b.ro.x; o[9] = b.ro.y; o[10] = b.ro.z; o[11] = b.weights.y;
+    o[12] = b.bsdfThroughput.x; o[13] = b.bsdfThroughput.y; o[14] = b.bsdfThroughput.z; o[15] = b.cosEnv;
+    o[16] = b.envThroughput.x; o[17] = b.envThroughput.y; o[18] = b.envThroughput.z; o[19] = b.envPdf;
+    o[20] = b.envDir.x; o[21] = b.envDir.y; o[22] = b.envDir.z; o[23] = (float)b.refracted;
+    o[24] = (b.texEmissive.x * b.texDiffuse.x) * 30.0f; o[25] = (b.texEmissive.y * b.texDiffuse.y) * 30.0f;
+    o[26] = (b.texEmissive.z * b.texDiffuse.z) * 30.0f; o[27] = (float)g.used;
+    o[28] = b.microNormal.x; o[29] = b.microNormal.y; o[30] = b.microNormal.z;
+    o[32] = b.macroNormal.x; o[33] = b.macroNormal.y; o[34] = b.macroNormal.z; o[35] = b.dielectric;
+  }
+}
+
+/* rnd() k times from a seed (tracer.fs:181): the sequence the probes above are replayed against. */
+void oracle_rnd_sequence(const float *seeds, uint32_t n, uint32_t k, float *out) {
+  for (uint32_t i = 0; i < n; ++i) {
+    float sd = seeds[i];
+    for (uint32_t j = 0; j < k; ++j) out[(size_t)i * k + j] = rnd_seed(&sd);
   }
 }
 

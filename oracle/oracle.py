@@ -156,6 +156,45 @@ def brdf_probe(arrays, which, inputs):
     return out
 
 
+BOUNCE_FLOATS = 36
+
+
+def sampler_probe(arrays, which, inputs, rec, env_theta=0.0):
+    """which 0 sampleMicrofacet / 1 sampleLambert / 2 sampleEnv with the recorded rnd() values `rec` (n x k) replayed."""
+    s = oscene(arrays)
+    inputs = np.ascontiguousarray(inputs, np.float32).reshape(-1, 4)
+    rec = np.ascontiguousarray(rec, np.float32).reshape(inputs.shape[0], -1)
+    out = np.zeros((inputs.shape[0], 4), np.float32)
+    lib().oracle_sampler_probe(C.byref(s), C.c_int(which), _fp(inputs), _fp(rec), C.c_uint32(rec.shape[1]),
+                               C.c_float(env_theta), C.c_uint32(inputs.shape[0]), _fp(out))
+    return out
+
+
+def bounce_probe(arrays, rays, t, index, rand_base, env_theta, rec=None, tex=None):
+    """One bounce-loop iteration (tracer.fs:447-499) per (ray, hit); rec = n x 8 recorded rnd() values or None,
+    tex = n x 12 recorded texture() results (diffuse.rgb, emissive.rgb, mr.rg, normal.rgb, pad) or None."""
+    s = oscene(arrays)
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    n = rays.shape[0]
+    t = np.ascontiguousarray(t, np.float32).reshape(n); index = np.ascontiguousarray(index, np.int32).reshape(n)
+    if rec is not None:
+        rec = np.ascontiguousarray(rec, np.float32).reshape(n, 8)
+    if tex is not None:
+        tex = np.ascontiguousarray(tex, np.float32).reshape(n, 12)
+    out = np.zeros((n, BOUNCE_FLOATS), np.float32)
+    lib().oracle_bounce_probe(C.byref(s), _fp(rays), _fp(t), index.ctypes.data_as(C.POINTER(C.c_int32)),
+                              C.c_float(rand_base), C.c_float(env_theta), _fp(rec) if rec is not None else None,
+                              _fp(tex) if tex is not None else None, C.c_uint32(n), _fp(out))
+    return out
+
+
+def rnd_sequence(seeds, k):
+    seeds = np.ascontiguousarray(seeds, np.float32).reshape(-1)
+    out = np.zeros((seeds.size, k), np.float32)
+    lib().oracle_rnd_sequence(_fp(seeds), C.c_uint32(seeds.size), C.c_uint32(k), _fp(out))
+    return out
+
+
 def draw(accum, exposure=1.0, saturation=1.0, denoise=False, max_sigma=3.0, scale=1.0):
     accum = np.ascontiguousarray(accum, np.float32)
     H, W = accum.shape[:2]

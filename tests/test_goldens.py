@@ -397,3 +397,244 @@ def test_d2_d3_variant_scene_matches_glsl():
     assert np.array_equal(st["shade3"][..., 3][hit], a.mat.reshape(-1, 12)[ti, 9])    # ior
     assert np.array_equal(st["shade4"][..., 3][hit], a.mat.reshape(-1, 12)[ti, 10])   # dielectric
     assert (a.mat.reshape(-1, 12)[ti, 10] > 0).any() and (st["shade7"][..., :3][hit] > 0).any()  # refractive, emissive hit
+
+
+# ---- the stochastic half of tracer.fs, pinned deterministically ------------------------------------------------
+# tools/make_goldens.py `samplers`: the reference's UNMODIFIED sampleMicrofacet / sampleLambert / sampleEnv and one
+# iteration of main()'s bounce loop (tracer.fs:447-499, cut out of the reference at generation time) run on SwiftShader,
+# with the values its rnd() returned recorded next to the outputs.  The oracle replays those values
+# (oracle_sampler_probe / oracle_bounce_probe), so SwiftShader's sin() - 1e-5 off for seeds of a few thousand, which
+# turns the sin-hash into an unrelated stream - drops out and everything downstream of rnd() is compared to float32
+# rounding.  The bounce probe also replays the four texture() results (the GLSL sampler's 8-bit-ish filter precision is
+# pinned by stage D3 above); `test_bounce_body_with_own_texture_fetch` keeps the oracle's own fetch in the loop.
+#
+# Tolerances: directions 1e-5 abs, pdfs / throughputs / MIS weights 1e-4 rel - plus, where tracer.fs itself evaluates
+# an ill-conditioned expression, the float32 rounding of that expression (GLSL leaves both the rounding of every
+# operation and the contraction of a*b+c to the implementation; the oracle's choice is DESIGN.md section 2):
+#   cosTheta = sqrt((1 - r2) / (1 + (a^2 - 1) r2)), sinTheta = sqrt(1 - cosTheta^2)  (tracer.fs:263-264): the
+#       denominator cancels to ~(1 - r2) and 1 - cosTheta^2 cancels again -> error 2^-23 / sinTheta * (1 + 1 / denominator)
+#       in the half vector (a roughness-0.001 lobe is 1e-3 wide and float32 resolves 1 - cos^2 to 6e-8)
+#   gtr2: t = 1 + (a^2 - 1) ndh^2    (tracer.fs:217)  relative error 2 * 2^-22 / t in D, t down to a^2 = 1e-6
+SAMPLER_SCENES = ["small", "variant", "textured"]
+EPS23 = 2.0 ** -23
+
+
+def _sampler_golden(name):
+    z = np.load(os.path.join(GOLD, f"glsl_samplers_{name}.npz"))
+    a = S.textured_test_scene() if name == "textured" else scene_from_golden(name)
+    return z, a
+
+
+def _same_nonfinite(o, g):
+    """NaN where the GLSL has NaN, the same infinity where it has one."""
+    return np.array_equal(np.isnan(o), np.isnan(g)) and np.array_equal(np.where(np.isinf(o), o, 0), np.where(np.isinf(g), g, 0))
+
+
+def _half_vector_slack(rough, r2, sin_theta):
+    a = np.maximum(0.001, np.asarray(rough, np.float64))
+    den = 1.0 + (a * a - 1.0) * np.asarray(r2, np.float64)
+    return EPS23 / np.maximum(sin_theta, 1e-6) * (1.0 + 1.0 / np.maximum(den, 1e-7))
+
+
+def _gtr2_t(a, ndh):
+    a = np.maximum(0.001, a.astype(np.float64))
+    return 1.0 + (a * a - 1.0) * ndh.astype(np.float64) ** 2
+
+
+def test_rnd_replay_basis():
+    """What the replay rests on: the GLSL advances `seed` exactly like the oracle (binary32 addition), its rnd() values
+    are in [0, 1) - and they are NOT the oracle's (nor anybody's: SwiftShader's sin is ~1e-5 off at |x| ~ 1e4, and
+    43758.5453 * 1e-5 is half a period), while the oracle's sin-hash is within 0.006 of the exact function."""
+    z, _ = _sampler_golden("small")
+    B = z["samp_B"].reshape(-1, 4)
+    rec = np.concatenate([z["samp_rnd_a"], z["samp_rnd_b"]], -1).reshape(-1, 8)
+    assert rec.min() >= 0.0 and rec.max() < 1.0 and 0.45 < rec.mean() < 0.55
+    step = np.float32(0.211324865405187)
+    s2 = ((B[:, 0] + step).astype(np.float32) + step).astype(np.float32)
+    assert np.array_equal(z["samp_microfacet"].reshape(-1, 4)[:, 3].view(np.uint32), s2.view(np.uint32))
+    assert np.array_equal(z["samp_lambert"].reshape(-1, 4)[:, 3].view(np.uint32), s2.view(np.uint32))
+    own = O.rnd_sequence(B[:, 0], 8)
+    sd, truth = B[:, 0].copy(), np.zeros(own.shape)
+    for k in range(8):
+        sd = (sd + step).astype(np.float32)
+        v = np.sin(sd.astype(np.float64)) * 43758.5453123
+        truth[:, k] = v - np.floor(v)
+
+    def circ(x, y):
+        d = np.abs(x - y)
+        return np.minimum(d, 1 - d)
+    assert circ(own, truth).max() < 0.008
+    small = np.abs(B[:, 0]) < 40
+    assert circ(rec, truth)[small].max() < 0.2 and circ(rec, truth)[~small].max() > 0.4
+
+
+@pytest.mark.parametrize("name", SAMPLER_SCENES)
+def test_sample_microfacet_and_lambert_match_glsl(name):
+    """tracer.fs:256-280 on 2 560 (normal, roughness, seed) triples incl. the |n.z| >= 0.999 frame and roughness below
+    the 0.001 clamp."""
+    z, a = _sampler_golden(name)
+    A = z["samp_A"].reshape(-1, 4)
+    rec = np.concatenate([z["samp_rnd_a"], z["samp_rnd_b"]], -1).reshape(-1, 8)
+    assert (np.abs(A[:, 2]) >= 0.999).sum() > 300 and (A[:, 3] < 0.001).sum() > 100
+    o = O.sampler_probe(a, 0, A, rec)
+    g = z["samp_microfacet"].reshape(-1, 4)
+    assert (o[:, 3] == 2).all()
+    d = np.abs(o[:, :3] - g[:, :3]).max(1)
+    sin_theta = np.linalg.norm(np.cross(o[:, :3].astype(np.float64), A[:, :3].astype(np.float64)), axis=1)
+    assert (d <= 1e-5 + _half_vector_slack(A[:, 3], rec[:, 1], sin_theta)).all(), d.max()
+    well = (sin_theta > 0.05) & (rec[:, 1] < 0.9)
+    assert well.mean() > 0.6 and d[well].max() <= 1e-5
+    o = O.sampler_probe(a, 1, A, rec)
+    g = z["samp_lambert"].reshape(-1, 4)
+    assert (o[:, 3] == 2).all()
+    assert np.abs(o[:, :3] - g[:, :3]).max() <= 1e-5
+    assert np.abs(np.linalg.norm(o[:, :3], axis=1) - 1).max() < 1e-5
+    assert ((o[:, :3] * A[:, :3]).sum(1) > -1e-6).all()  # in the normal's hemisphere
+
+
+@pytest.mark.parametrize("name", SAMPLER_SCENES)
+def test_sample_env_matches_glsl(name):
+    """tracer.fs:421-434: bin choice, point in the bin, direction and pdf; bins the Uint16 truncation left empty
+    (env_sampler.js:73) give pdf = inf on both sides."""
+    z, a = _sampler_golden(name)
+    rec = np.concatenate([z["samp_rnd_a"], z["samp_rnd_b"]], -1).reshape(-1, 8)
+    o = O.sampler_probe(a, 2, z["samp_A"].reshape(-1, 4), rec, float(z["env_theta"]))
+    g = z["samp_env"].reshape(-1, 4)
+    assert np.abs(o[:, :3] - g[:, :3]).max() <= 1e-5
+    assert _same_nonfinite(o[:, 3], g[:, 3])
+    fin = np.isfinite(g[:, 3])
+    assert fin.mean() > 0.9
+    sin_phi = np.sqrt(np.maximum(1.0 - g[fin, 1].astype(np.float64) ** 2, 1e-12))
+    rel = np.abs(o[fin, 3] - g[fin, 3]) / np.abs(g[fin, 3])
+    assert (rel <= 1e-5 + 4 * EPS23 / sin_phi).all() and rel.max() <= 1e-4, rel.max()
+    # every bin of the table was drawn from
+    n_bins = a.bins.size // 4
+    assert len(set(np.minimum((n_bins * rec[:, 0]).astype(int), n_bins - 1))) == n_bins
+
+
+def _bounce(name, with_tex=True):
+    z, a = _sampler_golden(name)
+    rays = np.concatenate([z["rays_pos"][..., :3], z["rays_dir"][..., :3]], -1).reshape(-1, 6)
+    t, idx = z["hit_t"].reshape(-1), z["hit_index"].reshape(-1)
+    G = {k: z[f"bounce{k}"].reshape(-1, 4) for k in range(400, 414)}
+    rec = np.concatenate([G[401], G[402]], -1)
+    tex = np.zeros((rays.shape[0], 12), np.float32)
+    tex[:, 0:3], tex[:, 3:6], tex[:, 6], tex[:, 7], tex[:, 8:11] = G[411][:, :3], G[412][:, :3], G[411][:, 3], G[412][:, 3], G[413][:, :3]
+    o = O.bounce_probe(a, rays, t, idx, float(z["rand_base"]), float(z["env_theta"]), rec, tex if with_tex else None)
+    return z, a, rays, t, idx, G, o
+
+
+@pytest.mark.parametrize("name", SAMPLER_SCENES)
+def test_bounce_body_matches_glsl(name):
+    """One iteration of tracer.fs main()'s loop (447-499) on 2 560 rays: camera rays and rays that hit a triangle from
+    behind.  Branch decisions equal on every ray; ray.origin / ray.dir, bsdfThroughput, envThroughput, the pdfs, the MIS
+    weights, the micro / macro normals and the emitted colour to float32 rounding."""
+    z, a, rays, t, idx, G, o = _bounce(name)
+    _, io, _, _ = O.intersect(a, rays)
+    assert np.array_equal(io, idx)                      # the hit the body starts from is the oracle's own, too
+    h = idx >= 0
+    assert h.sum() > 2000
+    inside, specular, refracted = G[400][:, 1] > 0, G[400][:, 2] > 0, G[407][:, 3] < 0
+    assert np.array_equal(o[h, 1] > 0, inside[h]) and np.array_equal(o[h, 2] > 0, specular[h])
+    assert np.array_equal(o[h, 23] > 0, refracted[h]) and np.array_equal(o[h, 35], G[410][h, 3])
+    lambert = h & ~specular & ~refracted
+    for m in (inside, ~inside, specular, lambert):
+        assert (m & h).sum() > 200
+    if name == "variant":   # the dielectric: refraction out of and into the solid, total internal reflection
+        ior = a.mat.reshape(-1, 12)[idx[h], 9]
+        assert (refracted & inside & h).sum() > 10 and (refracted & ~inside & h).sum() > 100
+        cos_i = np.abs((o[h, 28:31] * rays[h, 3:6]).sum(1))
+        tir = inside[h] & (G[410][h, 3] >= 0) & (ior * ior * (1 - cos_i * cos_i) > 1.0001)
+        assert tir.sum() > 20 and specular[h][tir].all()
+    if name != "small":
+        assert (G[408][h, :3] > 0).any()                # emissive hits (tracer.fs:467)
+    # the rnd() calls consumed: 6 on the specular / refraction branches, 8 with sampleLambert
+    assert np.array_equal(o[h, 27], np.where(lambert[h], 8, 6))
+    step = np.float32(0.211324865405187)
+    sd = G[400][h, 0].copy()
+    for _ in range(8):
+        sd = np.where(np.arange(8)[_] < o[h, 27], (sd + step).astype(np.float32), sd)
+    assert np.array_equal(sd.view(np.uint32), G[408][h, 3].view(np.uint32))          # `seed` after the body
+    assert (np.abs(o[h, 0] - G[400][h, 0]) <= 3e-4 * np.maximum(np.abs(G[400][h, 0]), 1.0)).all()  # tracer.fs:458
+
+    def close(cols, key, gcols, tol_abs=0.0, tol_rel=0.0, extra=None, mask=h):
+        x, y = o[mask][:, cols].astype(np.float64), G[key][mask][:, gcols].astype(np.float64)
+        assert _same_nonfinite(x, y), key
+        f = np.isfinite(y)
+        lim = tol_abs + tol_rel * np.abs(y)
+        if extra is not None:
+            lim = lim + (extra[mask][:, None] if y.ndim > 1 else extra[mask])
+        with np.errstate(invalid="ignore"):
+            bad = f & ~(np.abs(np.where(f, x - y, 0)) <= lim)
+        w = np.argwhere(bad)
+        assert not bad.any(), (key, int(bad.sum()), np.flatnonzero(mask)[w[0][0]], x[tuple(w[0])], y[tuple(w[0])], lim[tuple(w[0])])
+    # geometry
+    close(slice(32, 35), 410, slice(0, 3), 1e-6)                                     # macroNormal
+    close(slice(8, 11), 404, slice(0, 3), 2e-6)                                      # ray.origin
+    close(slice(20, 23), 407, slice(0, 3), 1e-5)                                     # envDirPdf.xyz
+    close(15, 405, 3, 1e-5)                                                          # cosEnv
+    close(19, 406, 3, 0.0, 1e-4)                                                     # envDirPdf.a
+    close(slice(24, 27), 408, slice(0, 3), 1e-6, 1e-6)                               # emitted colour
+    mac, mic = o[:, 32:35].astype(np.float64), o[:, 28:31].astype(np.float64)
+    rough = _tex_of(G)[:, 7].astype(np.float64) ** 2
+    slack = _half_vector_slack(rough, G[401][:, 1], np.linalg.norm(np.cross(mic, mac), axis=1))
+    close(slice(28, 31), 409, slice(0, 3), 1e-5, extra=slack)                        # microNormal
+    close(slice(4, 7), 403, slice(0, 3), 1e-5, extra=np.where(specular | refracted, 2 * slack, 0.0))  # ray.dir
+    # pdfs, throughputs, weights: 1e-4 rel + the rounding of gtr2's t on the specular branch
+    inc = -rays[:, 3:6].astype(np.float64)
+    hv = o[:, 4:7] + inc
+    hv_len = np.maximum(np.linalg.norm(hv, axis=1), 1e-6)   # normalize(bsdfDir + incident) at grazing incidence (tracer.fs:230)
+    hv /= np.maximum(np.linalg.norm(hv, axis=1, keepdims=True), 1e-30)
+    t_b = np.abs(_gtr2_t(rough, np.abs((hv * mac).sum(1))))
+    he = o[:, 20:23] + inc
+    he_len = np.maximum(np.linalg.norm(he, axis=1), 1e-6)
+    he /= np.maximum(np.linalg.norm(he, axis=1, keepdims=True), 1e-30)
+    t_e = np.abs(_gtr2_t(rough, np.abs((he * mac).sum(1))))
+    a_ = np.maximum(0.001, rough)
+    den = np.maximum(1.0 + (a_ * a_ - 1.0) * G[401][:, 1].astype(np.float64), 1e-7)
+    cond_b = np.where(specular, 4 * EPS23 * (2.0 + 1.0 / den + 4.0 / hv_len) / np.maximum(t_b, 1e-7), 0.0)  # the half vector's own error moves ndh
+    cond_e = np.where(specular, 4 * EPS23 * (1.0 + 4.0 / he_len) / np.maximum(t_e, 1e-7), 0.0)
+    # ... and its denominator 4 |bsdfDir . halfVec| (tracer.fs:233) = 2 |bsdfDir + incident| with a half vector that is
+    # only known to 4 eps / |bsdfDir + incident| when the reflection grazes the microfacet
+    cond_b = cond_b + np.where(specular, 8 * EPS23 / (hv_len * hv_len), 0.0)
+    gp = np.abs(G[400][:, 3].astype(np.float64))
+    # Lambert: dir.z = sqrt(1 - x^2 - y^2) (tracer.fs:211) cancels at the rim of the disc
+    cl_ = np.maximum(np.abs((o[:, 4:7] * mac).sum(1)), 1e-6)
+    rim = np.where(lambert, 4 * EPS23 / cl_, 0.0)
+    close(3, 400, 3, 1e-6, 1e-4, extra=cond_b * gp + rim)                                               # bsdfPdf
+    # w = a^2 / (a^2 + b^2): dw <= (rel. error of a + rel. error of b) / 2
+    close(7, 403, 3, 5e-5, extra=0.5 * cond_b)                                                          # weights.x
+    close(11, 404, 3, 5e-5, extra=0.5 * cond_b)                                                         # weights.y
+    cl = np.maximum(np.abs((o[:, 4:7] * mac).sum(1)), 1e-7)
+    gt = np.abs(G[405][:, :3].astype(np.float64)).max(1)
+    close(slice(12, 15), 405, slice(0, 3), 1e-6, 1e-4, extra=np.where(specular, (4 * EPS23 / cl + cond_b) * gt, 0.0))   # bsdfThroughput
+    ge = np.abs(G[406][:, :3].astype(np.float64)).max(1)
+    ce = np.maximum(np.abs(o[:, 15].astype(np.float64)), 1e-7)                                          # clamp(cosEnv) at grazing light
+    close(slice(16, 19), 406, slice(0, 3), 1e-6, 1e-4, extra=(cond_e + 4 * EPS23 / ce) * ge)            # envThroughput
+    # how much of it needed no conditioning term at all: 99.5 % of the non-specular pdfs, 99 % of the directions and throughputs
+    # (the specular pdf is the GTR2 lobe itself - at the scenes' roughness^2 of 0.01 its t cancels to 1e-4)
+    plain = np.abs(o[h, 3] - G[400][h, 3]) <= 1e-6 + 1e-4 * np.abs(G[400][h, 3])
+    assert plain[~specular[h]].mean() > 0.995
+    assert (np.abs(o[h, 4:7] - G[403][h, :3]).max(1) <= 1e-5).mean() > 0.99
+    assert (np.abs(o[h, 12:15] - G[405][h, :3]) <= 1e-6 + 1e-4 * np.abs(G[405][h, :3])).all(1).mean() > 0.995
+
+
+def _tex_of(G):
+    tex = np.zeros((G[411].shape[0], 12), np.float32)
+    tex[:, 0:3], tex[:, 3:6], tex[:, 6], tex[:, 7], tex[:, 8:11] = G[411][:, :3], G[412][:, :3], G[411][:, 3], G[412][:, 3], G[413][:, :3]
+    return tex
+
+
+@pytest.mark.parametrize("name", SAMPLER_SCENES)
+def test_bounce_body_with_own_texture_fetch(name):
+    """The same probe with the oracle's OWN atlas fetches (only rnd() replayed): the GLSL sampler's filter precision
+    (<= 3e-4 per channel, stage D3) now reaches the normal map and the roughness - the 'texture-unit rows' at 1e-3."""
+    z, a, rays, t, idx, G, o = _bounce(name, with_tex=False)
+    h = idx >= 0
+    same = h & ((o[:, 1] > 0) == (G[400][:, 1] > 0)) & ((o[:, 2] > 0) == (G[400][:, 2] > 0))
+    assert same[h].mean() > 0.995                        # a Fresnel decision can flip on a 3e-4 roughness difference
+    assert np.abs(o[same, 32:35] - G[410][same, :3]).max() <= 1e-3            # macroNormal
+    assert np.abs(o[same, 8:11] - G[404][same, :3]).max() <= 1e-5             # ray.origin
+    assert np.abs(o[same, 24:27] - G[408][same, :3]).max() <= 2e-2            # emitted colour (x30)
+    d = np.abs(o[same, 4:7] - G[403][same, :3]).max(1)
+    assert np.percentile(d, 99) <= 2e-3                                        # ray.dir

@@ -238,6 +238,173 @@ void main(void) {
 """
 HIT, BRDF = 100, 200
 
+# ---- stochastic half of tracer.fs: samplers and one bounce-loop iteration, with the GLSL's rnd() values recorded ----
+# 300-304: seed = B.x (injected), A = (normal.xyz, metallicRoughness.y).  rnd() eight times; then - seed reset - the
+#          reference's UNMODIFIED sampleMicrofacet / sampleLambert / sampleEnv.
+# 400-410: one iteration of main()'s bounce loop.  BODY1 / BODY2 are the lines of tracer.fs main() from
+#          `Material mat = createMaterial(result.index);` to the seed assignment, and from there to
+#          `vec2 weights = misWeights(envDirPdf.a, bsdfPdf);`, cut out of /root/reference/shader/tracer.fs when the
+#          goldens are generated (bounce_body_parts) - the only inserted statement is the copy of `seed` between them.
+SAMPLER_MAIN = """uniform int probeSel;
+void main(void) {
+  vec2 FC = FCOORD;
+  vec4 A = texelFetch(cameraPosTex, ivec2(FC), 0);
+  vec4 B = texelFetch(cameraDirTex, ivec2(FC), 0);
+  vec4 o = vec4(0.0);
+  if (probeSel == 100) {
+    Hit h = intersectScene(Ray(A.xyz, B.xyz));
+    o = vec4(h.t, float(h.index), 0.0, 1.0);
+  } else if (probeSel < 400) {
+    seed = B.x;
+    float r1 = rnd(); float r2 = rnd(); float r3 = rnd(); float r4 = rnd();
+    float r5 = rnd(); float r6 = rnd(); float r7 = rnd(); float r8 = rnd();
+    if (probeSel == 300) o = vec4(r1, r2, r3, r4);
+    if (probeSel == 301) o = vec4(r5, r6, r7, r8);
+    seed = B.x;
+    if (probeSel == 302) { vec3 m = sampleMicrofacet(A.xyz, vec2(0.0, A.w)); o = vec4(m, seed); }
+    if (probeSel == 303) { vec3 m = sampleLambert(A.xyz); o = vec4(m, seed); }
+    if (probeSel == 304) o = sampleEnv();
+  } else {
+    Ray ray = Ray(A.xyz, B.xyz);
+    Hit result = intersectScene(ray);
+    if (result.index < 0) {
+      o = vec4(0.0, 0.0, 0.0, -1.0);
+    } else {
+      vec3 color = vec3(0);
+      vec3 accumulatedReflectance = vec3(1);
+      int i = 0;
+BODY1
+      float probeSeed0 = seed;
+BODY2
+      if (probeSel == 400) o = vec4(probeSeed0, float(inside), float(specular), bsdfPdf);
+      if (probeSel == 403) o = vec4(ray.dir, weights.x);
+      if (probeSel == 404) o = vec4(ray.origin, weights.y);
+      if (probeSel == 405) o = vec4(bsdfThroughput, cosEnv);
+      if (probeSel == 406) o = vec4(envThroughput, envDirPdf.a);
+      if (probeSel == 407) o = vec4(envDirPdf.xyz, float(i));
+      if (probeSel == 408) o = vec4(color, seed);
+      if (probeSel == 409) o = vec4(microNormal, 0.0);
+      if (probeSel == 410) o = vec4(macroNormal, mat.dielectric);
+      vec2 rawMR = texture(texArray, vec3(texCoord, mat.mapIndices.roughness)).rg;
+      if (probeSel == 411) o = vec4(texDiffuse, rawMR.x);
+      if (probeSel == 412) o = vec4(texEmmissive, rawMR.y);
+      if (probeSel == 413) o = vec4(texture(texArray, vec3(texCoord, mat.mapIndices.normal)).rgb, 0.0);
+      seed = probeSeed0;
+      float r1 = rnd(); float r2 = rnd(); float r3 = rnd(); float r4 = rnd();
+      float r5 = rnd(); float r6 = rnd(); float r7 = rnd(); float r8 = rnd();
+      if (probeSel == 401) o = vec4(r1, r2, r3, r4);
+      if (probeSel == 402) o = vec4(r5, r6, r7, r8);
+    }
+  }
+  fragColor = o;
+}
+"""
+BOUNCE_SELS = (400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 410, 411, 412, 413)
+
+
+def bounce_body_parts():
+    """The bounce-loop body of tracer.fs main() (tracer.fs:447-499), read from the reference NOW."""
+    import glsl_ref as G
+    src = G.read_shader("tracer.fs")
+    main = src[src.index("void main(void) {"):]
+    first = "Material mat = createMaterial(result.index);"
+    seed_line = "seed = origin.x * randBase * origin.y * 1.396529836 + origin.z * 4761.52835;"
+    last = "vec2 weights = misWeights(envDirPdf.a, bsdfPdf);"
+    for anchor in (first, seed_line, last):
+        assert main.count(anchor) == 1, anchor
+    a, b, c = main.index(first), main.index(seed_line) + len(seed_line), main.index(last) + len(last)
+    return main[a:b], main[b:c]
+
+
+def sampler_rays(arrays, W, H, cam, lens, seed):
+    """Rays for the bounce probe: the upper half of the image are camera rays; the lower half start BEHIND a randomly
+    chosen triangle and hit it from the back (inside = true: refraction out of the dielectric, total internal reflection
+    at grazing angles, the Beer override on back-facing non-dielectrics, tracer.fs:461-463,497)."""
+    import oracle as O
+    pos, d = O.camera(W, H, cam["P"], cam["I"], cam["fov_scale"], lens, 777.0)
+    rng = np.random.default_rng(seed)
+    tri = arrays.tri.reshape(-1, 3, 3).astype(np.float64)
+    n = (H // 2) * W
+    pick = rng.integers(0, tri.shape[0], n)
+    v = tri[pick]
+    w = rng.dirichlet([2.0, 2.0, 2.0], n)
+    p = (v * w[:, :, None]).sum(1)
+    e1, e2 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+    nrm = np.cross(e1, e2)
+    size = np.sqrt(np.linalg.norm(nrm, axis=1, keepdims=True))   # ~ edge length
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+    t1 = e1 / np.maximum(np.linalg.norm(e1, axis=1, keepdims=True), 1e-30)
+    t2 = np.cross(nrm, t1)
+    depth = size * rng.uniform(0.3, 2.0, (n, 1))
+    r = depth * np.tan(rng.uniform(0.0, 1.0, (n, 1)) ** 1.5 * 1.35)  # incidence angle up to 77 degrees, half of them below 27
+    phi = rng.uniform(0, 2 * np.pi, (n, 1))
+    side = np.where(rng.uniform(size=(n, 1)) < 0.6, -1.0, 1.0)   # from behind the winding normal, or from the front (shading
+    #                                                             normals may point either way: 'mesh' normals, flipped quads)
+    o = p + side * nrm * depth + (t1 * np.cos(phi) + t2 * np.sin(phi)) * r
+    dd = p - o
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    pos[H // 2:, :, :3] = o.reshape(H // 2, W, 3).astype(np.float32)
+    d[H // 2:, :, :3] = dd.reshape(H // 2, W, 3).astype(np.float32)
+    return pos, d
+
+
+def make_samplers(name):
+    """Deterministic pins for sampleMicrofacet / sampleLambert / sampleEnv and one bounce-loop iteration."""
+    import glsl_ref as G
+    scene_name = name
+    arrays = converged_scene(scene_name)
+    cam = dict(S.BUNNY_CAMERA)
+    if name in CONVERGED and CONVERGED[name][5] is not None:
+        cam["P"], cam["I"] = CONVERGED[name][5], CONVERGED[name][6]
+    lens = S.lens_features(cam["focal_depth"], cam["aperture"])
+    g = G.GlslRef()
+    g.scene(arrays)
+    W, H = 64, 40
+    g.target(W, H, replicate=True)
+    b1, b2 = bounce_body_parts()
+    g.tracer(main_override=SAMPLER_MAIN.replace("BODY1", b1).replace("BODY2", b2).replace("FCOORD", FC_REP))
+    env_theta, rand_base = cam["env_theta"], 4242.5
+    out = dict(W=W, H=H, renderer=g.renderer, env_theta=np.float32(env_theta), rand_base=np.float32(rand_base), scene=scene_name)
+
+    def run(sel):
+        g.set_int("probeSel", sel)
+        g.draw_tracer(0, rand_base, env_theta)
+        img, mism = g.read_screen(0)
+        assert mism == 0, f"{mism} replica mismatches"
+        return img
+
+    # (i)/(ii) samplers on injected (normal, roughness, seed)
+    rng = np.random.default_rng(21)
+    N = rng.normal(size=(H, W, 3))
+    N /= np.linalg.norm(N, axis=-1, keepdims=True)
+    N[:4] = [0.0, 0.0, 1.0]; N[4:8] = [0.0, 0.0, -1.0]           # the |n.z| >= 0.999 frame (tracer.fs:259,275)
+    N[8:10] = N[8:10] * [0.03, 0.03, 1.0]; N[8:10] /= np.linalg.norm(N[8:10], axis=-1, keepdims=True)
+    A = np.zeros((H, W, 4), np.float32); A[..., :3] = N
+    A[..., 3] = rng.uniform(0.0, 1.0, (H, W)) ** 2                # metallicRoughness.y arrives squared (tracer.fs:457)
+    A[::5, ::3, 3] = 0.0004                                       # below the 0.001 clamp (tracer.fs:261)
+    B = np.zeros((H, W, 4), np.float32)
+    B[..., 0] = np.where(rng.uniform(size=(H, W)) < 0.5, rng.uniform(-30, 30, (H, W)), rng.uniform(-2e4, 2e4, (H, W)))
+    g.set_camera(A, B)
+    out["samp_A"], out["samp_B"] = A, B
+    for sel, key in ((300, "samp_rnd_a"), (301, "samp_rnd_b"), (302, "samp_microfacet"), (303, "samp_lambert"), (304, "samp_env")):
+        out[key] = run(sel)
+    # (iii) one bounce-loop iteration
+    pos, d = sampler_rays(arrays, W, H, cam, lens, 5)
+    g.set_camera(pos, d)
+    out["rays_pos"], out["rays_dir"] = pos, d
+    hit = run(HIT)
+    out["hit_t"], out["hit_index"] = hit[..., 0], hit[..., 1].astype(np.int32)
+    for sel in BOUNCE_SELS:
+        out[f"bounce{sel}"] = run(sel)
+    ins = out["bounce400"][..., 1][out["hit_index"] >= 0]
+    spec = out["bounce400"][..., 2][out["hit_index"] >= 0]
+    refr = out["bounce407"][..., 3][out["hit_index"] >= 0]
+    print("samplers", name, "hits", float((out["hit_index"] >= 0).mean()), "inside", float(ins.mean()), "specular", float(spec.mean()),
+          "refracted", float((refr < 0).mean()))
+    np.savez_compressed(os.path.join(GOLD, f"glsl_samplers_{name}.npz"), **out)
+
+
+
 
 def probe(g, sel):
     if not getattr(g, "_probe_ready", False):
@@ -255,7 +422,7 @@ def make_glsl(name="small"):
     import oracle as O
     cam = dict(S.BUNNY_CAMERA)
     if name != "small":  # the camera of the converged golden of the same scene
-        cam["P"], cam["I"] = CONVERGED[name][4], CONVERGED[name][5]
+        cam["P"], cam["I"] = CONVERGED[name][5], CONVERGED[name][6]
     lens = S.lens_features(cam["focal_depth"], cam["aperture"])
     g = G.GlslRef()
     print(g.renderer)
@@ -298,7 +465,16 @@ def make_glsl(name="small"):
 
 
 
-CONVERGED = {"small": (48, 32, 1536, 4, None, None), "variant": (48, 32, 1536, 4, [0.3, 1.2, 3.4], [-0.05, -0.3, -0.95])}
+# key -> (scene, W, H, spp, NUM_BOUNCES, P, I).  16 384 spp: GLSL-vs-GLSL noise floor ~0.015 (small) / ~0.026 (variant);
+# depth 8 is the BASELINE depth (tracer.fs:9 ships 4: kept for 'small_d4'); 'textured' has 16x16 image maps on every layer.
+CONVERGED = {"small": ("small", 48, 32, 16384, 8, None, None),
+             "small_d4": ("small", 48, 32, 16384, 4, None, None),
+             "variant": ("variant", 48, 32, 16384, 8, [0.3, 1.2, 3.4], [-0.05, -0.3, -0.95]),
+             "textured": ("textured", 48, 32, 16384, 8, None, None)}
+
+
+def converged_scene(scene_name):
+    return S.textured_test_scene() if scene_name == "textured" else load_scene(scene_name)
 
 
 def make_converged(name):
@@ -309,9 +485,9 @@ def make_converged(name):
     import oracle as O
     cam = dict(S.BUNNY_CAMERA)
     lens = S.lens_features(cam["focal_depth"], cam["aperture"])
-    Wc, Hc, spp, bounces, P, I = CONVERGED[name]
+    scene_name, Wc, Hc, spp, bounces, P, I = CONVERGED[name]
     P = P or cam["P"]; I = I or cam["I"]
-    arrays = load_scene(name)
+    arrays = converged_scene(scene_name)
     g = G.GlslRef()
     g.scene(arrays)
     g.target(Wc, Hc, replicate=True)
@@ -332,7 +508,7 @@ def make_converged(name):
     np.savez_compressed(os.path.join(GOLD, f"glsl_converged_{name}.npz"), a=imgs[0], b=imgs[1], W=Wc, H=Hc, spp=spp,
                         bounces=bounces, P=np.float32(P), I=np.float32(I), fov_scale=np.float32(cam["fov_scale"]),
                         lens=np.float32(lens), env_theta=np.float32(cam["env_theta"]), renderer=g.renderer,
-                        streams=np.int32([11, 12]))
+                        streams=np.int32([11, 12]), scene=scene_name)
 
 
 def make_bvh_test():
@@ -497,6 +673,11 @@ if __name__ == "__main__":
                 subprocess.check_call([sys.executable, "-u", os.path.abspath(__file__), "converged:" + name])
         elif w == "textured":
             make_textured()
+        elif w == "samplers":
+            for name in ("small", "variant", "textured"):
+                subprocess.check_call([sys.executable, "-u", os.path.abspath(__file__), "samplers:" + name])
+        elif w.startswith("samplers:"):
+            make_samplers(w.split(":", 1)[1])
         elif w == "atlas":
             make_atlas()
         elif w == "bvhtest":
