@@ -517,6 +517,37 @@ static inline void bounce_body(const oracle_scene *s, vec3 ro, vec3 rd, hit_t re
   o->inside = inside; o->specular = specular; o->refracted = refracted;
 }
 
+/* ---- the rest of the iteration, tracer.fs:467 and 500-512: emission, NEE shadow ray, extension ray ------
+ * Returns 1 when the extension ray left the scene (`break`). */
+static inline int bounce_tail(const oracle_scene *s, const bounce_t *b, float envTheta, oracle_counters *c,
+                              vec3 *thr_io, vec3 *color_io, hit_t *result) {
+  vec3 thr = *thr_io, color = *color_io;
+  /* tracer.fs:467 */
+  color = v3(om_fma((thr.x * b->texEmissive.x) * b->texDiffuse.x, 30.0f, color.x),
+             om_fma((thr.y * b->texEmissive.y) * b->texDiffuse.y, 30.0f, color.y),
+             om_fma((thr.z * b->texEmissive.z) * b->texDiffuse.z, 30.0f, color.z));
+  if (b->dielectric < 0.0f && b->cosEnv > 0.0f) {
+    hit_t shadow = intersect_scene(s, b->ro, b->envDir, c, NULL, NULL);
+    if (shadow.index == -1) {
+      vec3 es = env_sample(s, b->envDir, envTheta, c);
+      color = v3(om_fma((thr.x * b->envThroughput.x) * es.x, b->weights.x, color.x),
+                 om_fma((thr.y * b->envThroughput.y) * es.y, b->weights.x, color.y),
+                 om_fma((thr.z * b->envThroughput.z) * es.z, b->weights.x, color.z));
+    }
+  }
+  *result = intersect_scene(s, b->ro, b->rd, c, NULL, NULL);
+  thr = v_mul(thr, b->bsdfThroughput);
+  int left = 0;
+  if (result->index == -1) {
+    vec3 es = env_sample(s, b->rd, envTheta, c);
+    color = v3(om_fma(thr.x * es.x, b->weights.y, color.x), om_fma(thr.y * es.y, b->weights.y, color.y),
+               om_fma(thr.z * es.z, b->weights.y, color.z));
+    left = 1;
+  }
+  *thr_io = thr; *color_io = color;
+  return left;
+}
+
 /* ---- tracer.fs main (436-518) for one pixel ----------------------------- */
 static void trace_pixel(const oracle_scene *s, vec3 ro, vec3 rd, uint32_t tick, float randBase,
                         float envTheta, uint32_t numBounces, float *accum /*rgba*/,
@@ -536,28 +567,8 @@ static void trace_pixel(const oracle_scene *s, vec3 ro, vec3 rd, uint32_t tick, 
       bounce_t b;
       bounce_body(s, ro, rd, result, randBase, envTheta, &g, (fh && iters == 0) ? fh : NULL, NULL, &b);
       ro = b.ro; rd = b.rd;
-      /* tracer.fs:467 */
-      color = v3(om_fma((thr.x * b.texEmissive.x) * b.texDiffuse.x, 30.0f, color.x),
-                 om_fma((thr.y * b.texEmissive.y) * b.texDiffuse.y, 30.0f, color.y),
-                 om_fma((thr.z * b.texEmissive.z) * b.texDiffuse.z, 30.0f, color.z));
       if (b.refracted) i--; /* tracer.fs:488 */
-      if (b.dielectric < 0.0f && b.cosEnv > 0.0f) {
-        hit_t shadow = intersect_scene(s, ro, b.envDir, c, NULL, NULL);
-        if (shadow.index == -1) {
-          vec3 es = env_sample(s, b.envDir, envTheta, c);
-          color = v3(om_fma((thr.x * b.envThroughput.x) * es.x, b.weights.x, color.x),
-                     om_fma((thr.y * b.envThroughput.y) * es.y, b.weights.x, color.y),
-                     om_fma((thr.z * b.envThroughput.z) * es.z, b.weights.x, color.z));
-        }
-      }
-      result = intersect_scene(s, ro, rd, c, NULL, NULL);
-      thr = v_mul(thr, b.bsdfThroughput);
-      if (result.index == -1) {
-        vec3 es = env_sample(s, rd, envTheta, c);
-        color = v3(om_fma(thr.x * es.x, b.weights.y, color.x), om_fma(thr.y * es.y, b.weights.y, color.y),
-                   om_fma(thr.z * es.z, b.weights.y, color.z));
-        break;
-      }
+      if (bounce_tail(s, &b, envTheta, c, &thr, &color, &result)) break;
     }
   }
   color = v3(om_clamp(color.x, 0.0f, 1024.0f), om_clamp(color.y, 0.0f, 1024.0f), om_clamp(color.z, 0.0f, 1024.0f));
@@ -828,8 +839,10 @@ void oracle_sampler_probe(const oracle_scene *s, int which, const float *in, con
  *   0 seed (tracer.fs:458)  1 inside  2 specular  3 bsdfPdf | 4-6 ray.dir  7 weights.x | 8-10 ray.origin  11 weights.y
  *   12-14 bsdfThroughput  15 cosEnv | 16-18 envThroughput  19 envDirPdf.a | 20-22 envDirPdf.xyz  23 refracted (i--)
  *   24-26 colour added by tracer.fs:467 at accumulatedReflectance 1  27 rnd() calls | 28-30 microNormal  31 0
- *   32-34 macroNormal (after the `inside` flip)  35 mat.dielectric */
-#define ORACLE_BOUNCE_FLOATS 36
+ *   32-34 macroNormal (after the `inside` flip)  35 mat.dielectric
+ *   after the rest of the iteration (tracer.fs:467,500-512; the oracle's own shadow / extension rays and environment lookups):
+ *   36-38 color  39 result.index | 40-42 accumulatedReflectance  43 result.t */
+#define ORACLE_BOUNCE_FLOATS 44
 void oracle_bounce_probe(const oracle_scene *s, const float *rays, const float *t_in, const int32_t *index_in,
                          float randBase, float envTheta, const float *rec, const float *tex, uint32_t n,
                          float *out) {
@@ -853,6 +866,11 @@ void oracle_bounce_probe(const oracle_scene *s, const float *rays, const float *
     o[26] = (b.texEmissive.z * b.texDiffuse.z) * 30.0f; o[27] = (float)g.used;
     o[28] = b.microNormal.x; o[29] = b.microNormal.y; o[30] = b.microNormal.z;
     o[32] = b.macroNormal.x; o[33] = b.macroNormal.y; o[34] = b.macroNormal.z; o[35] = b.dielectric;
+    vec3 thr = v3(1.0f, 1.0f, 1.0f), color = v3(0.0f, 0.0f, 0.0f);
+    hit_t next;
+    (void)bounce_tail(s, &b, envTheta, NULL, &thr, &color, &next);
+    o[36] = color.x; o[37] = color.y; o[38] = color.z; o[39] = (float)next.index;
+    o[40] = thr.x; o[41] = thr.y; o[42] = thr.z; o[43] = next.t;
   }
 }
 

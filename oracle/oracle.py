@@ -156,7 +156,7 @@ def brdf_probe(arrays, which, inputs):
     return out
 
 
-BOUNCE_FLOATS = 36
+BOUNCE_FLOATS = 44
 
 
 def sampler_probe(arrays, which, inputs, rec, env_theta=0.0):

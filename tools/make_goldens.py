@@ -241,10 +241,12 @@ HIT, BRDF = 100, 200
 # ---- stochastic half of tracer.fs: samplers and one bounce-loop iteration, with the GLSL's rnd() values recorded ----
 # 300-304: seed = B.x (injected), A = (normal.xyz, metallicRoughness.y).  rnd() eight times; then - seed reset - the
 #          reference's UNMODIFIED sampleMicrofacet / sampleLambert / sampleEnv.
-# 400-410: one iteration of main()'s bounce loop.  BODY1 / BODY2 are the lines of tracer.fs main() from
+# 400-413: one iteration of main()'s bounce loop.  BODY1 / BODY2 are the lines of tracer.fs main() from
 #          `Material mat = createMaterial(result.index);` to the seed assignment, and from there to
 #          `vec2 weights = misWeights(envDirPdf.a, bsdfPdf);`, cut out of /root/reference/shader/tracer.fs when the
 #          goldens are generated (bounce_body_parts) - the only inserted statement is the copy of `seed` between them.
+# 420-421: BODY3 = the rest of the iteration (shadow ray, extension ray, MIS-weighted accumulation, tracer.fs:500-512)
+#          inside a one-trip loop that gives its `break` something to leave.
 SAMPLER_MAIN = """uniform int probeSel;
 void main(void) {
   vec2 FC = FCOORD;
@@ -294,12 +296,19 @@ BODY2
       float r5 = rnd(); float r6 = rnd(); float r7 = rnd(); float r8 = rnd();
       if (probeSel == 401) o = vec4(r1, r2, r3, r4);
       if (probeSel == 402) o = vec4(r5, r6, r7, r8);
+      if (probeSel >= 420) {
+        for (int probeOnce = 0; probeOnce < 1; ++probeOnce) {
+BODY3
+        }
+        if (probeSel == 420) o = vec4(color, float(result.index));
+        if (probeSel == 421) o = vec4(accumulatedReflectance, result.t);
+      }
     }
   }
   fragColor = o;
 }
 """
-BOUNCE_SELS = (400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 410, 411, 412, 413)
+BOUNCE_SELS = (400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 410, 411, 412, 413, 420, 421)
 
 
 def bounce_body_parts():
@@ -313,7 +322,10 @@ def bounce_body_parts():
     for anchor in (first, seed_line, last):
         assert main.count(anchor) == 1, anchor
     a, b, c = main.index(first), main.index(seed_line) + len(seed_line), main.index(last) + len(last)
-    return main[a:b], main[b:c]
+    brk = main.index("break;", c)
+    assert main.count("break;") == 1
+    d = main.index("}", brk) + 1
+    return main[a:b], main[b:c], main[c:d]
 
 
 def sampler_rays(arrays, W, H, cam, lens, seed):
@@ -361,8 +373,8 @@ def make_samplers(name):
     g.scene(arrays)
     W, H = 64, 40
     g.target(W, H, replicate=True)
-    b1, b2 = bounce_body_parts()
-    g.tracer(main_override=SAMPLER_MAIN.replace("BODY1", b1).replace("BODY2", b2).replace("FCOORD", FC_REP))
+    b1, b2, b3 = bounce_body_parts()
+    g.tracer(main_override=SAMPLER_MAIN.replace("BODY1", b1).replace("BODY2", b2).replace("BODY3", b3).replace("FCOORD", FC_REP))
     env_theta, rand_base = cam["env_theta"], 4242.5
     out = dict(W=W, H=H, renderer=g.renderer, env_theta=np.float32(env_theta), rand_base=np.float32(rand_base), scene=scene_name)
 
