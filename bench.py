@@ -150,10 +150,9 @@ def parse_args(argv=None):
                     help="bytes of interleaved material textures the scene may use (A/B: 0 = single-layer images only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of the timed run's accumulator")
-    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "wavefront2", "stream", "stream2"])
+    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "stream"])
     ap.add_argument("--pool", type=int, default=0, help="stream scheduler: live paths per state set (0 = library default)")
     ap.add_argument("--drain", type=int, default=-1, help="stream scheduler: drain iterations before the tail kernel (-1 = default)")
-    ap.add_argument("--finish-kernel", type=int, default=-1, help="0 logic kernel finishes ending paths, 1 k_wf_finish in front of it, 2 beside it (-1 = default)")
     ap.add_argument("--tail", type=int, default=-1, help="batch scheduler: the tail kernel takes over after this round (-1 adaptive, 0 never)")
     ap.add_argument("--trace-budget", type=int, default=-1, help="steps before a starved trace wave suspends its rays (0 = never, -1 = default)")
     ap.add_argument("--overlap", type=int, default=-1, help="stream scheduler: 1 = primary on a second HIP stream, 0 = one stream (-1 = default)")
@@ -321,8 +320,6 @@ def main():
         pt.set_trace_budget(args.trace_budget)
     if args.tail >= 0:
         pt.set_tail(args.tail)
-    if args.finish_kernel >= 0:
-        pt.set_finish_kernel(args.finish_kernel)
     if args.pool or args.drain >= 0 or args.overlap >= 0:
         pt.set_pool(args.pool, args.drain, 0, args.overlap)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")

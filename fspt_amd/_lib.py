@@ -1,4 +1,4 @@
-"""ctypes binding of libfspt.so (include/fspt.h).
+"""ctypes binding of libfspt.so (include/fspt.h, include/fspt_tuning.h).
 
 The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).
 There is no fallback: if the shared object is missing this module raises, and
@@ -111,7 +111,6 @@ SIGNATURES = {
     "fspt_target_set_pipeline": (C.c_int, [_VP, C.c_int, C.c_uint32]),
     "fspt_target_set_pool": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_uint32, C.c_int]),
     "fspt_target_set_trace_budget": (C.c_int, [_VP, C.c_uint32]),
-    "fspt_target_set_finish_kernel": (C.c_int, [_VP, C.c_int]),
     "fspt_last_stage_ms": (C.c_int, [_VP, _F, _U32]),
     "fspt_target_prepare": (C.c_int, [_VP]),
     "fspt_target_set_tail": (C.c_int, [_VP, C.c_int]),

@@ -6,6 +6,7 @@
 // (826-836) and the tick loop (838-857).  No CPU fallback: every device entry
 // point fails with FSPT_E_NO_DEVICE when there is no HIP device.
 #include "../../include/fspt.h"
+#include "../../include/fspt_tuning.h"
 #include "fspt_device.hpp"
 
 #include <cstdarg>
@@ -57,10 +58,6 @@ static const int WF_ARRAYS = 15;
 #define FSPT_SUSP_BUDGET 24 // profiles/r03/ab_trace_suspend_budget.log: 0 / 16 / 24 / 32 / 48 -> 3 883 / 3 938 / 3 940 / 3 935 / 3 921 Msamples/s in 20-step regions (same box, twice)
 #endif
 static const uint32_t ST_DEFAULT_SUSP_BUDGET = FSPT_SUSP_BUDGET;
-#ifndef FSPT_SPLIT_FINISH
-#define FSPT_SPLIT_FINISH 0
-#endif
-static const int ST_DEFAULT_SPLIT_FINISH = FSPT_SPLIT_FINISH;
 struct fspt_target {
   fspt_scene *scene = nullptr;
   uint32_t W = 0, H = 0;
@@ -79,18 +76,17 @@ struct fspt_target {
   uint32_t last_launches = 0;
   // wavefront pipeline
   uint32_t vw = 0, vh = 0;    // viewport (gl.viewport of the two draws); default = the whole target
-  int pipeline = 1;           // 0 = megakernel, 1 = wavefront (2 = wavefront with two overlapped lanes sets n_lanes)
+  int pipeline = 1;           // 0 = megakernel, 1 = wavefront
   int sched = 0;              // wavefront pipeline: 0 = batch scheduler (all ticks x all pixels per batch), 1 = stream (fixed pool)
   uint32_t pool_paths = 0;    // stream: paths per state set and lane (0 = default)
   int stream_drain = -1;      // stream: iterations after the last generating one before the tail kernel takes over (-1 = default)
   uint32_t stream_iter_cap = 0; // stream, test hook: at most this many iterations per run (the finishing launch does the rest)
   uint32_t susp_budget = ST_DEFAULT_SUSP_BUDGET; // traversal steps a starved trace wave walks on before it parks its rays (0 = never)
-  int split_finish = ST_DEFAULT_SPLIT_FINISH; // 0: k_wf_logic finishes the paths that end in a round itself; 1: k_wf_finish does, in front of it; 2: beside it on a second stream
   int stream_overlap = -1;      // stream: plan / primary / resolve on a second HIP stream beside the previous trace (1), everything on one stream (0), default (-1)
   uint32_t batch_ticks = 128; // ticks traced together by the wavefront pipeline (58 GB of path state at 1080p;
                               // measured 64 / 128 / 256 -> 3 619 / 3 794 / 3 750 Msamples/s, profiles/r01)
-  // Two lanes = two independent batches in flight on two HIP streams: while one batch sits in a latency-bound
-  // kernel or in the tail of a late round, the other batch's kernels fill the idle SIMDs.
+  // Path state and streams of the wavefront pipeline (either scheduler).  (Two such lanes with overlapped half-batches
+  // were measured in rounds 1-3 and gained nothing worth their memory: profiles/r02, profiles/r03/ab_staggered_lanes.log.)
   struct WfLane {
     void *mem[WF_ARRAYS] = {};
     fspt::WfCounts *counts = nullptr;
@@ -116,9 +112,10 @@ struct fspt_target {
     uint64_t bytes = 0;                      // path-state bytes this lane holds (either scheduler)
     int *susp[2] = {nullptr, nullptr};       // suspended-traversal records of the trace launches (fspt_device.hpp), ping-pong
     uint32_t susp_stride = 0;
+    size_t susp_recs = 0;                    // records per buffer
+    uint64_t susp_bytes = 0;                 // both buffers
     bool zeroed = false;                     // counts / heads / ctl are zero (cleared behind the previous batch, off the next one's critical path)
-  } lanes[2];
-  uint32_t n_lanes = 1; // 2 = pipeline code 2: measured +3 % at 64+ ticks, -17 % at 8 ticks (profiles/r01)
+  } wf;
   // Deferred two-call ticks (fspt_camera + fspt_trace): recorded, executed in batches at the next flush point
   struct Deferred { fspt_camera_params cam; float rb_cam; uint32_t tick; float rb_trace; };
   std::vector<Deferred> pending;
@@ -604,7 +601,8 @@ int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **
   if (e == hipSuccess) e = hipEventCreate(&t->ev0);
   if (e == hipSuccess) e = hipEventCreate(&t->ev1);
   if (e == hipSuccess) e = hipEventCreate(&t->ev_start);
-  for (auto &ln : t->lanes) {
+  {
+    fspt_target::WfLane &ln = t->wf;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.stream_b, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.resolved, hipEventDisableTiming);
@@ -631,13 +629,14 @@ int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **
 int fspt_target_destroy(fspt_target *t) {
   if (!t) return FSPT_OK;
   hipSetDevice(t->scene->device);
-  // recorded ticks: with the library's own accumulator nobody can observe them any more; a caller-owned accumulator
-  // (fspt_target_bind_accumulator) outlives the target, so they are executed
-  if (t->accum != t->accum_own && t->accum_own) (void)flush_pending(t);
+  // Recorded ticks are dropped: nothing can observe the library's own accumulator any more, and a caller-owned one
+  // (fspt_target_bind_accumulator) may already have been freed by its owner - destroy never writes to it.  A caller
+  // that wants the recorded ticks in its buffer calls fspt_sync (or re-binds, which flushes) first.
   t->pending.clear();
   if (t->stream) hipStreamSynchronize(t->stream);
   hipFree(t->accum_own); hipFree(t->ray_pos); hipFree(t->ray_dir); hipFree(t->work_counters); hipFree(t->counters);
-  for (auto &ln : t->lanes) {
+  {
+    fspt_target::WfLane &ln = t->wf;
     for (void *m : ln.mem) hipFree(m);
     hipFree(ln.counts);
     hipFree(ln.heads);
@@ -746,14 +745,36 @@ static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
   p.n_owned_tiles = (n_tiles > t->shard) ? (n_tiles - t->shard + t->n_shards - 1) / t->n_shards : 0;
 }
 
-// Records of suspended traversals: one per lane of a full trace grid (a lane parks at most one ray per launch), two buffers.
-static int susp_ensure(fspt_target *t, fspt_target::WfLane &ln) {
+// Records of suspended traversals: one per lane of the trace grid a launch over `max_paths` paths gets (a lane parks at
+// most one ray per launch; launch_wf: min(ceil(paths / 256), 8 blocks per CU) blocks of 256), two buffers, grown on
+// demand.  They are part of the target's path state (fspt_target_path_state_bytes, fspt_target_set_memory_limit): when
+// they do not fit what the limit leaves, traversals are simply not suspended (*on = false) - same results, a little slower.
+static int susp_ensure(fspt_target *t, fspt_target::WfLane &ln, uint64_t max_paths, bool *on) {
   const uint32_t stride = ((uint32_t)fspt::WF_SUSP_HEADER + t->scene->d.stack_n + 3u) & ~3u;
-  if (ln.susp[0] && ln.susp_stride == stride) return FSPT_OK;
+  const uint64_t grid_max = (uint64_t)t->scene->num_cus * 8u;
+  uint64_t blocks = (max_paths + 255u) / 256u;
+  if (blocks > grid_max) blocks = grid_max;
+  if (blocks < 1) blocks = 1;
+  const size_t recs = (size_t)blocks * 256u;
+  *on = true;
+  if (ln.susp[0] && ln.susp_stride == stride && ln.susp_recs >= recs) return FSPT_OK;
   for (int *&b : ln.susp) { if (b) { HIP_TRY(hipFree(b)); b = nullptr; } }
-  const size_t recs = (size_t)t->scene->num_cus * 8u * 256u;
-  for (int *&b : ln.susp) HIP_TRY(hipMalloc((void **)&b, recs * stride * sizeof(int)));
+  ln.susp_bytes = 0; ln.susp_recs = 0;
+  const uint64_t need = 2ull * recs * stride * sizeof(int);
+  if (t->mem_limit && ln.bytes + need > t->mem_limit) { *on = false; return FSPT_OK; }
+  for (int *&b : ln.susp) {
+    hipError_t e = hipMalloc((void **)&b, recs * stride * sizeof(int));
+    if (e == hipErrorOutOfMemory) {
+      (void)hipGetLastError();
+      for (int *&c : ln.susp) { if (c) { (void)hipFree(c); c = nullptr; } }
+      *on = false;
+      return FSPT_OK;
+    }
+    HIP_TRY(e);
+  }
   ln.susp_stride = stride;
+  ln.susp_recs = recs;
+  ln.susp_bytes = need;
   return FSPT_OK;
 }
 
@@ -805,12 +826,10 @@ static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots, ui
   return FSPT_OK;
 }
 
-// ticks per lane and number of lanes for a call of n_ticks (0 = the configured steady state, fspt_target_prepare).
+// Ticks per batch for a call of n_ticks (0 = the configured steady state, fspt_target_prepare).
 // Path state is sized for the largest call seen so far, not for the configured batch: a host that only ever calls
 // fspt_trace (one tick at a time, like main.js:842-843) holds one tick of path state, not 128.
-static void wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t n_lanes_max, uint32_t &lanes,
-                    uint32_t &per_lane) {
-  // the configured batch is the number of ticks in flight over all lanes (each lane at most WF_MAX_BATCH)
+static uint32_t wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ticks) {
   uint32_t batch = t->batch_ticks;
   if (n_ticks) {
     uint32_t want = n_ticks > t->ticks_seen ? n_ticks : t->ticks_seen;
@@ -820,31 +839,25 @@ static void wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ticks,
   if (fit < 1) fit = 1;
   if (batch > fit) batch = (uint32_t)fit;
   if (batch < 1) batch = 1;
-  lanes = (n_lanes_max >= 2 && batch >= 2) ? 2u : 1u;
-  per_lane = batch / lanes;
-  if (per_lane > (uint32_t)fspt::WF_MAX_BATCH) per_lane = fspt::WF_MAX_BATCH;
+  if (batch > (uint32_t)fspt::WF_MAX_BATCH) batch = fspt::WF_MAX_BATCH;
+  return batch;
 }
 
-// Plan the batch and make sure every lane's path state is allocated.  When the device is short of memory (or the
-// target's memory limit is lower) ALL lanes are released and the batch is halved until it fits; a two-lane target
-// falls back to one lane before giving up (results do not depend on the batch size or the lane count).
-static int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &n_lanes, uint32_t &per_lane) {
+// Plan the batch and make sure its path state is allocated.  When the device is short of memory (or the target's
+// memory limit is lower) the batch is halved until it fits (results do not depend on the batch size).
+static int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &batch) {
   if (n_ticks > t->ticks_seen) t->ticks_seen = n_ticks;
-  uint32_t lanes_max = t->n_lanes;
   while (true) {
-    wf_plan(t, work_total, n_ticks, lanes_max, n_lanes, per_lane);
+    batch = wf_plan(t, work_total, n_ticks);
     // the trace kernel carries a path's state index in 29 bits (fspt_kernels.hip k_wf_trace: item kind and the
     // no-bounce-left flag share the word); WF_SLOT_BUDGET keeps every batch below that, a single tick of a frame beyond
     // 2^29 pixels does not fit
-    if ((uint64_t)per_lane * work_total > 0x1FFFFFFFull) { fspt_set_error("frame too large for the wavefront pipeline (more than 2^29 paths per batch)"); return FSPT_E_INVALID; }
-    const uint64_t budget = t->mem_limit ? t->mem_limit / wf_slot_bytes() / n_lanes : ~0ull;
-    int rc = FSPT_OK;
-    for (uint32_t l = 0; l < n_lanes && rc == FSPT_OK; ++l) rc = wf_ensure(t, t->lanes[l], (uint32_t)(per_lane * work_total), budget);
+    if ((uint64_t)batch * work_total > 0x1FFFFFFFull) { fspt_set_error("frame too large for the wavefront pipeline (more than 2^29 paths per batch)"); return FSPT_E_INVALID; }
+    const uint64_t budget = t->mem_limit ? t->mem_limit / wf_slot_bytes() : ~0ull;
+    int rc = wf_ensure(t, t->wf, (uint32_t)(batch * work_total), budget);
     if (rc != FSPT_E_NOMEM) return rc;
-    for (auto &ln : t->lanes) wf_release(ln); // a lane that did fit must not keep memory the smaller retry needs
-    if (per_lane * n_lanes <= 1) return rc;   // one tick on one lane does not fit: give up (message set by wf_ensure)
-    if (per_lane <= 1) { lanes_max = 1; continue; }
-    t->batch_ticks = per_lane * n_lanes / 2;
+    if (batch <= 1) return rc; // one tick does not fit: give up (message set by wf_ensure)
+    t->batch_ticks = batch / 2;
   }
 }
 
@@ -904,13 +917,9 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
   if (work_total == 0) return FSPT_OK;
   // path state: sized for the largest call so far (fspt_target_prepare sizes it for the configured batch up front, so
   // that a short warm-up call does not cause a reallocation inside a later, longer call)
-  uint32_t n_lanes, per_lane;
-  int rc = wf_plan_and_ensure(t, work_total, n_ticks, n_lanes, per_lane);
+  uint32_t batch;
+  int rc = wf_plan_and_ensure(t, work_total, n_ticks, batch);
   if (rc) return rc;
-  // a short call is still split over both lanes so that its two halves overlap
-  uint32_t batch = per_lane;
-  if (n_lanes == 2 && n_ticks < 2 * per_lane) batch = (n_ticks + 1) / 2;
-  if (batch < 1) batch = 1;
 
   fspt::WfP p{};
   p.scene = t->scene->d;
@@ -929,15 +938,14 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
 
   // everything already queued on the target's stream (clear, ray upload, earlier renders) comes first
   HIP_TRY(hipEventRecord(t->ev_start, t->stream));
-  for (uint32_t l = 0; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(t->lanes[l].stream, t->ev_start, 0));
+  fspt_target::WfLane &ln = t->wf;
+  hipStream_t st = ln.stream;
+  HIP_TRY(hipStreamWaitEvent(st, t->ev_start, 0));
 
-  uint32_t done = 0, bi = 0;
-  fspt_target::WfLane *prev = nullptr;
+  uint32_t done = 0;
   while (done < n_ticks) {
-    fspt_target::WfLane &ln = t->lanes[bi % n_lanes];
-    hipStream_t st = ln.stream;
     auto launch = [&](int kind) -> int {
-      int e = kind == fspt::WF_K_FINISH ? ev_begin(t, fspt::WF_K_LOGIC, st) : (kind >= fspt::WF_K_KINDS ? -1 : ev_begin(t, kind, st));
+      int e = kind >= fspt::WF_K_KINDS ? -1 : ev_begin(t, kind, st);
       hipError_t err = fspt::launch_wf(kind, p, t->count, cus, st);
       ev_end(t, e, st);
       if (err != hipSuccess) { fspt_set_error("wavefront launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
@@ -955,11 +963,10 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     uint32_t nbt = n_ticks - done < batch ? n_ticks - done : batch;
     p.n_batch = nbt;
     p.first_tick = first_tick + done;
-    p.ctl = nullptr; p.ring_slots = nbt * work_total; p.pool = 0; p.n_pools = 1; p.finish = 0;
+    p.ctl = nullptr; p.ring_slots = nbt * work_total; p.finish = 0;
     // suspended traversals: off while counting (the tail kernel re-traces a carried path's rays, which would count twice)
-    const bool susp_on = t->susp_budget != 0 && t->count == 0;
-    p.split_finish = t->split_finish ? 1u : 0u;
-    if (susp_on && (rc = susp_ensure(t, ln))) return rc;
+    bool susp_on = t->susp_budget != 0 && t->count == 0;
+    if (susp_on && (rc = susp_ensure(t, ln, (uint64_t)nbt * work_total, &susp_on))) return rc;
     p.susp[0] = susp_on ? ln.susp[0] : nullptr; p.susp[1] = susp_on ? ln.susp[1] : nullptr; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
     for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
     // the previous batch's live-path counts, if their copy has landed: where the tail kernel takes over
@@ -981,22 +988,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     for (uint32_t r = 1; r <= last && r <= tail; ++r) {
       set_round(r);
       if (r > 1 && susp_on && prev_trace_suspends) { if ((rc = launch(fspt::WF_K_CARRY))) return rc; } // the paths trace(r-1) suspended move on
-      if (r > 1 && t->split_finish) {
-        if (t->split_finish == 2) {
-          // beside the logic launch, on the lane's second stream: it reads the set logic(r) reads and writes fin only
-          HIP_TRY(hipEventRecord(ln.ev_b[0], st));
-          HIP_TRY(hipStreamWaitEvent(ln.stream_b, ln.ev_b[0], 0));
-          int e = ev_begin(t, fspt::WF_K_LOGIC, ln.stream_b);
-          hipError_t err = fspt::launch_wf(fspt::WF_K_FINISH, p, t->count, cus, ln.stream_b);
-          ev_end(t, e, ln.stream_b);
-          if (err != hipSuccess) { fspt_set_error("finish launch failed: %s", hipGetErrorString(err)); return FSPT_E_HIP; }
-          HIP_TRY(hipEventRecord(ln.ev_b[1], ln.stream_b));
-        } else if ((rc = launch(fspt::WF_K_FINISH))) return rc;
-      }
       if ((rc = launch(r == 1 ? fspt::WF_K_PRIMARY : fspt::WF_K_LOGIC))) return rc;
-      // the set finish(r) reads is overwritten by logic(r+1) / by the next batch's primary launch: both come after the trace
-      // launch or the resolve that follows here on `st`, which wait for it
-      if (r > 1 && t->split_finish == 2) HIP_TRY(hipStreamWaitEvent(st, ln.ev_b[1], 0));
       if (r < last && r < tail) {
         // the last trace launch of a batch lets its long rays finish: what it suspended the tail kernel would have to
         // trace again from the start
@@ -1015,27 +1007,24 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     HIP_TRY(hipEventRecord(ln.counts_ready, st));
     ln.counts_pending = true;
     ln.counts_slots = nbt * work_total;
-    // the running mean is order-dependent (tracer.fs:517): resolves run in tick order across the lanes
-    if (prev) HIP_TRY(hipStreamWaitEvent(st, prev->resolved, 0));
+    // the running mean is order-dependent (tracer.fs:517): batches resolve in tick order - they follow each other on `st`
     if ((rc = launch(fspt::WF_K_RESOLVE))) return rc;
-    HIP_TRY(hipEventRecord(ln.resolved, st));
     // the next batch's counters and pool heads are cleared now, behind this batch (the clears used to sit between a
     // render call and its first kernel: ~0.1 ms of every timed region)
     HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
     HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, st));
     ln.zeroed = true;
-    prev = &ln;
     done += nbt;
-    ++bi;
   }
-  if (prev) HIP_TRY(hipStreamWaitEvent(t->stream, prev->resolved, 0)); // the resolves are chained: the last one ends it all
+  HIP_TRY(hipEventRecord(ln.resolved, st));
+  HIP_TRY(hipStreamWaitEvent(t->stream, ln.resolved, 0));
   return FSPT_OK;
 }
 
 // ---------------------------------------------------------------------------
-// Stream scheduler (fspt_device.hpp: WfStreamCtl; fspt_target_set_pipeline code 3 / 4)
+// Stream scheduler (fspt_device.hpp: WfStreamCtl; fspt_target_set_pipeline code 2)
 // ---------------------------------------------------------------------------
-static const uint32_t ST_DEFAULT_POOL = 16u << 20; // paths per state set and lane (3.4 GB; profiles/r03/sweep_stream_pool.log)
+static const uint32_t ST_DEFAULT_POOL = 16u << 20; // paths per state set (3.4 GB; profiles/r03/sweep_stream_pool.log)
 static const bool ST_DEFAULT_OVERLAP = true; // profiles/r03/ab_stream_overlap.log: 8 Mi pool, 20 / 128 steps: 3 733 / 4 095 Msamples/s against 3 702 / 3 975 on one stream
 static const size_t ST_CTL_BYTES = sizeof(fspt::WfStreamCtl);
 static const size_t ST_COUNTS_BYTES = sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2);
@@ -1093,7 +1082,7 @@ static int st_plan(const fspt_target *t, uint32_t units, uint32_t nbt, uint32_t 
     // what the memory limit leaves per lane: 204 bytes per pool path + its share of the ring, 12 * (horizon + 3) / 2
     // (one stream: / 1) bytes, + one unit of rounding
     const uint64_t per_path = (wf_slot_bytes() - 12) + (overlap ? 6ull : 12ull) * (pl.horizon + 3u);
-    const uint64_t lane_limit = t->mem_limit / t->n_lanes;
+    const uint64_t lane_limit = t->mem_limit;
     const uint64_t round_up = 12ull * (pl.horizon + 3u) * pl.unit_slots;
     const uint64_t fit = lane_limit > round_up ? (lane_limit - round_up) / per_path : 0;
     if (cap > fit) cap = fit;
@@ -1131,8 +1120,6 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
   const uint32_t work_total = tp.n_owned_tiles * tp.tile * tp.tile;
   if (work_total == 0) return FSPT_OK;
   const uint32_t units_total = work_total >> 6; // tile is a multiple of 8: whole 64-pixel patches
-  uint32_t n_pools = t->n_lanes;
-  if (n_pools > units_total) n_pools = 1;
   const uint32_t nb = cam->num_bounces;
   const int cus = t->scene->num_cus;
   constexpr uint32_t R = fspt::WF_RING;
@@ -1151,15 +1138,15 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
   base.shard = tp.shard; base.n_shards = tp.n_shards; base.tile = tp.tile; base.tiles_x = tp.tiles_x; base.tiles_y = tp.tiles_y;
   base.n_owned_tiles = tp.n_owned_tiles;
   base.gen_rays = rays_from_buffers ? 0u : 1u;
-  base.n_pools = n_pools;
 
   // everything already queued on the target's stream (clear, ray upload, earlier renders) comes first
   HIP_TRY(hipEventRecord(t->ev_start, t->stream));
-  for (uint32_t l = 0; l < n_pools; ++l) HIP_TRY(hipStreamWaitEvent(t->lanes[l].stream, t->ev_start, 0));
+  fspt_target::WfLane &ln = t->wf;
+  HIP_TRY(hipStreamWaitEvent(ln.stream, t->ev_start, 0));
 
   int rc = FSPT_OK;
   auto launch = [&](int kind, const fspt::WfP &p, hipStream_t st) -> int {
-    int e = kind == fspt::WF_K_FINISH ? ev_begin(t, fspt::WF_K_LOGIC, st) : (kind >= fspt::WF_K_KINDS ? -1 : ev_begin(t, kind, st));
+    int e = kind >= fspt::WF_K_KINDS ? -1 : ev_begin(t, kind, st);
     hipError_t err = fspt::launch_wf(kind, p, t->count, cus, st);
     ev_end(t, e, st);
     if (err != hipSuccess) { fspt_set_error("stream launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
@@ -1168,22 +1155,22 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
 
   uint32_t done = 0;
   while (done < n_ticks) {
-    uint32_t nbt = n_ticks - done < (uint32_t)fspt::WF_MAX_BATCH ? n_ticks - done : (uint32_t)fspt::WF_MAX_BATCH;
+    // a run covers batch_ticks ticks (what fspt_target_prepare sized the pool for), at most WF_MAX_BATCH
+    const uint32_t run_max = t->batch_ticks && t->batch_ticks < (uint32_t)fspt::WF_MAX_BATCH ? t->batch_ticks : (uint32_t)fspt::WF_MAX_BATCH;
+    uint32_t nbt = n_ticks - done < run_max ? n_ticks - done : run_max;
     // the samples of a run are numbered in 32 bits (kernels: g = first + i): a frame beyond 2^32 / 128 pixels runs fewer ticks at a time
     while (nbt > 1 && (uint64_t)work_total * nbt > 0xFFFFFFFFull) nbt /= 2;
     if ((uint64_t)work_total * nbt > 0xFFFFFFFFull) { fspt_set_error("frame too large for the stream scheduler (more than 2^32 pixels per shard)"); return FSPT_E_INVALID; }
-    fspt::WfP P[2];
-    StPlan pl[2];
-    uint32_t iters[2] = {0, 0};
-    int res_done[2] = {-1, -1}; // the iteration whose cursor position marks what has been folded into the accumulator
-    for (uint32_t l = 0; l < n_pools; ++l) {
-      fspt_target::WfLane &ln = t->lanes[l];
-      const uint32_t units = (units_total - l + n_pools - 1) / n_pools;
-      if ((rc = st_plan(t, units, nbt, nb, pl[l]))) return rc;
-      const uint64_t budget = t->mem_limit ? t->mem_limit / n_pools : ~0ull;
-      if ((rc = st_ensure(t, ln, pl[l].cap, pl[l].ring_slots, budget))) return rc;
-      fspt::WfP &p = P[l];
-      p = base;
+    fspt::WfP p = base;
+    StPlan pl;
+    uint32_t iters = 0;
+    int res_done = -1; // the iteration whose cursor position marks what has been folded into the accumulator
+    bool susp_run = susp_on;
+    {
+      const uint32_t units = units_total;
+      if ((rc = st_plan(t, units, nbt, nb, pl))) return rc;
+      const uint64_t budget = t->mem_limit ? t->mem_limit : ~0ull;
+      if ((rc = st_ensure(t, ln, pl.cap, pl.ring_slots, budget))) return rc;
       for (int k = 0; k < 2; ++k) {
         fspt::WfSet &ws = p.set[k];
         ws.A = (float4 *)ln.mem[6 * k + 0]; ws.B = (float4 *)ln.mem[6 * k + 1]; ws.C = (float4 *)ln.mem[6 * k + 2];
@@ -1192,25 +1179,24 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
       p.hit = (float2 *)ln.mem[12]; p.shadow_hit = (int *)ln.mem[13]; p.fin = (float *)ln.mem[14];
       p.counts = ln.counts; p.heads = ln.heads; p.ctl = ln.ctl;
       p.work_total = units * 64u; p.n_batch = nbt; p.first_tick = first_tick + done;
-      p.ring_slots = pl[l].ring_slots; p.cap = pl[l].cap; p.take_max = pl[l].take_max; p.pool = l;
-      if (susp_on && (rc = susp_ensure(t, ln))) return rc;
-      p.susp[0] = susp_on ? ln.susp[0] : nullptr; p.susp[1] = susp_on ? ln.susp[1] : nullptr; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
+      p.ring_slots = pl.ring_slots; p.cap = pl.cap; p.take_max = pl.take_max;
+      if (susp_run && (rc = susp_ensure(t, ln, pl.cap, &susp_run))) return rc;
+      p.susp[0] = susp_run ? ln.susp[0] : nullptr; p.susp[1] = susp_run ? ln.susp[1] : nullptr; p.susp_stride = ln.susp_stride; p.susp_budget = susp_run ? t->susp_budget : 0u;
       p.serial = overlap ? 0u : 1u;
-      p.split_finish = t->split_finish ? 1u : 0u;
       for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
       // how many iterations hand out all units: what the last such run needed, else from the pool's equilibrium
       // (about 0.45 of the pool is new samples per iteration at 30 % survival per step)
       st_collect(ln);
-      const uint64_t key = ((uint64_t)units << 32) ^ ((uint64_t)nbt << 24) ^ ((uint64_t)nb << 16) ^ (uint64_t)pl[l].cap * 0x9E3779B97F4A7C15ull;
-      uint32_t take_eq = (uint32_t)((overlap ? 0.45 : 0.75) * pl[l].cap / pl[l].unit_slots);
-      if (take_eq > pl[l].take_max) take_eq = pl[l].take_max;
+      const uint64_t key = ((uint64_t)units << 32) ^ ((uint64_t)nbt << 24) ^ ((uint64_t)nb << 16) ^ (uint64_t)pl.cap * 0x9E3779B97F4A7C15ull;
+      uint32_t take_eq = (uint32_t)((overlap ? 0.45 : 0.75) * pl.cap / pl.unit_slots);
+      if (take_eq > pl.take_max) take_eq = pl.take_max;
       if (take_eq < 1) take_eq = 1;
       uint32_t gen = (units + take_eq - 1) / take_eq + (units > take_eq ? 1u : 0u);
       if (ln.stat_key == key && ln.stat_gen_iters) gen = ln.stat_gen_iters;
       const uint32_t drain = t->stream_drain >= 0 ? (uint32_t)t->stream_drain : (gen > 1 ? 2u : 0u);
-      iters[l] = gen + drain;
-      if (t->stream_iter_cap && iters[l] > t->stream_iter_cap) iters[l] = t->stream_iter_cap;
-      if (iters[l] < 1) iters[l] = 1;
+      iters = gen + drain;
+      if (t->stream_iter_cap && iters > t->stream_iter_cap) iters = t->stream_iter_cap;
+      if (iters < 1) iters = 1;
       ln.ctl_key = key;
       ln.ctl_units = units;
       // a fresh run: cursor 0, no history, counters and pool heads zero
@@ -1223,31 +1209,26 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
       HIP_TRY(hipEventRecord(ln.ev_run, ln.stream));
       HIP_TRY(hipStreamWaitEvent(ln.stream_b, ln.ev_run, 0));
     }
-    const uint32_t it_max = iters[0] > iters[1] ? iters[0] : iters[1];
-    for (uint32_t it = 0; it < it_max; ++it) {
-      for (uint32_t l = 0; l < n_pools; ++l) {
-        if (it >= iters[l]) continue;
-        fspt_target::WfLane &ln = t->lanes[l];
-        fspt::WfP &p = P[l];
+    for (uint32_t it = 0; it < iters; ++it) {
+      {
         hipStream_t A = ln.stream, B = overlap ? ln.stream_b : ln.stream;
         p.round = it; p.cnt_in = (it + R - 1) % R; p.cnt_out = it % R; p.set_in = (it + 1) & 1u; p.set_out = it & 1u;
         if (!overlap) {
           // ---- one stream: logic(it) first, so that plan(it) sees what really survived and fills the pool to the brim
           if (it >= 1) {
-            if (susp_on && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
-            if (t->split_finish && (rc = launch(fspt::WF_K_FINISH, p, A))) return rc;
+            if (susp_run && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
             if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
           }
           if ((rc = launch(fspt::WF_K_PLAN, p, A))) return rc;
           if ((rc = launch(fspt::WF_K_PRIMARY, p, A))) return rc;
-          const int to = (int)it - (int)pl[l].horizon; // after logic(it) every path generated up to iteration `to` has ended
-          if (to >= 0 && to > res_done[l]) {
-            p.res_from = res_done[l]; p.res_to = to;
+          const int to = (int)it - (int)pl.horizon; // after logic(it) every path generated up to iteration `to` has ended
+          if (to >= 0 && to > res_done) {
+            p.res_from = res_done; p.res_to = to;
             if ((rc = launch(fspt::WF_K_RESOLVE, p, A))) return rc;
-            res_done[l] = to;
+            res_done = to;
           }
           { const uint32_t keep = p.susp_budget;
-            if (it + 1 == iters[l]) p.susp_budget = 0;
+            if (it + 1 == iters) p.susp_budget = 0;
             if ((rc = launch(fspt::WF_K_TRACE, p, A))) return rc;
             p.susp_budget = keep; }
           continue;
@@ -1257,23 +1238,22 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
         if ((rc = launch(fspt::WF_K_PLAN, p, B))) return rc;
         if ((rc = launch(fspt::WF_K_PRIMARY, p, B))) return rc;
         HIP_TRY(hipEventRecord(ln.ev_b[it % R], B));
-        const int to = (int)it - 1 - (int)pl[l].horizon; // after logic(it-1) every path generated up to iteration `to` has ended
-        if (to >= 0 && to > res_done[l]) {
-          p.res_from = res_done[l]; p.res_to = to;
+        const int to = (int)it - 1 - (int)pl.horizon; // after logic(it-1) every path generated up to iteration `to` has ended
+        if (to >= 0 && to > res_done) {
+          p.res_from = res_done; p.res_to = to;
           if ((rc = launch(fspt::WF_K_RESOLVE, p, B))) return rc;
-          res_done[l] = to;
+          res_done = to;
         }
         // ---- A: logic(it) on the results of trace(it - 1), then trace(it) once primary(it) has added its survivors
         if (it >= 1) {
-          if (susp_on && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
-          if (t->split_finish && (rc = launch(fspt::WF_K_FINISH, p, A))) return rc;
+          if (susp_run && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
           if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
           HIP_TRY(hipEventRecord(ln.ev_logic[it % R], A));
         }
         HIP_TRY(hipStreamWaitEvent(A, ln.ev_b[it % R], 0));
         { // (the run's last trace launch lets its long rays finish: the tail kernel would trace them again from the start)
           const uint32_t keep = p.susp_budget;
-          if (it + 1 == iters[l]) p.susp_budget = 0;
+          if (it + 1 == iters) p.susp_budget = 0;
           if ((rc = launch(fspt::WF_K_TRACE, p, A))) return rc;
           p.susp_budget = keep;
         }
@@ -1281,14 +1261,11 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
     }
     // ---- the end of the run: logic on the last trace's results, then the tail kernel runs whatever is alive to
     // completion and generates whatever the cursor has not handed out; then the rest is folded into the accumulator
-    for (uint32_t l = 0; l < n_pools; ++l) {
-      fspt_target::WfLane &ln = t->lanes[l];
-      fspt::WfP &p = P[l];
+    {
       hipStream_t A = ln.stream, B = overlap ? ln.stream_b : ln.stream;
-      const uint32_t it = iters[l];
+      const uint32_t it = iters;
       p.round = it; p.cnt_in = (it + R - 1) % R; p.cnt_out = it % R; p.set_in = (it + 1) & 1u; p.set_out = it & 1u;
       // (no carry launch: the run's last trace launch does not suspend)
-      if (t->split_finish && (rc = launch(fspt::WF_K_FINISH, p, A))) return rc;
       if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
       p.finish = 1;
       if ((rc = launch(fspt::WF_K_TAIL, p, A))) return rc;
@@ -1296,7 +1273,7 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
       HIP_TRY(hipStreamWaitEvent(A, ln.ev_b_last, 0)); // the resolves so far ran on B
       // everything the iterations handed out (up to the last plan's cursor): the units the finishing launch generated
       // itself went straight into the accumulator
-      p.res_from = res_done[l]; p.res_to = (int)it - 1;
+      p.res_from = res_done; p.res_to = (int)it - 1;
       if ((rc = launch(fspt::WF_K_RESOLVE, p, A))) return rc;
       HIP_TRY(hipMemcpyAsync(ln.ctl_host, ln.ctl, ST_CTL_BYTES, hipMemcpyDeviceToHost, A));
       HIP_TRY(hipEventRecord(ln.ctl_ready, A));
@@ -1311,7 +1288,7 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
     }
     done += nbt;
   }
-  for (uint32_t l = 0; l < n_pools; ++l) HIP_TRY(hipStreamWaitEvent(t->stream, t->lanes[l].resolved, 0));
+  HIP_TRY(hipStreamWaitEvent(t->stream, ln.resolved, 0));
   return FSPT_OK;
 }
 
@@ -1540,20 +1517,19 @@ int fspt_target_set_viewport(fspt_target *t, uint32_t w, uint32_t h) {
 int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks) {
   if (!t) { fspt_set_error("fspt_target_set_pipeline: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
-  if (pipeline < 0 || pipeline > 4) { fspt_set_error("pipeline must be 0 (megakernel), 1 (wavefront batches), 2 (wavefront batches, two lanes), 3 (wavefront stream) or 4 (wavefront stream, two pools)"); return FSPT_E_INVALID; }
-  const bool two = pipeline == 2 || pipeline == 4;
-  if (batch_ticks > (uint32_t)fspt::WF_MAX_BATCH * (pipeline == 2 ? 2u : 1u)) {
-    fspt_set_error("batch_ticks must be <= %d per lane", fspt::WF_MAX_BATCH);
+  if (pipeline < 0 || pipeline > 2) { fspt_set_error("pipeline must be 0 (megakernel), 1 (wavefront, batches) or 2 (wavefront, stream)"); return FSPT_E_INVALID; }
+  if (batch_ticks > (uint32_t)fspt::WF_MAX_BATCH) {
+    fspt_set_error("batch_ticks must be <= %d", fspt::WF_MAX_BATCH);
     return FSPT_E_INVALID;
   }
-  const int sched = pipeline >= 3 ? 1 : 0;
-  if (pipeline != 0 && (sched != t->sched || (two ? 2u : 1u) != t->n_lanes)) {
-    // the two schedulers size the lanes' memory differently: give it back (the next render allocates what it needs)
+  const int sched = pipeline == 2 ? 1 : 0;
+  if (pipeline != 0 && sched != t->sched) {
+    // the two schedulers size the path state differently: give it back (the next render allocates what it needs)
     HIP_TRY(hipSetDevice(t->scene->device));
-    for (auto &ln : t->lanes) wf_release(ln);
+    wf_release(t->wf);
   }
   t->pipeline = pipeline == 0 ? 0 : 1;
-  if (pipeline != 0) { t->sched = sched; t->n_lanes = two ? 2u : 1u; }
+  if (pipeline != 0) t->sched = sched;
   if (batch_ticks) t->batch_ticks = batch_ticks;
   return FSPT_OK;
 }
@@ -1576,14 +1552,6 @@ int fspt_target_set_trace_budget(fspt_target *t, uint32_t steps) {
   return FSPT_OK;
 }
 
-int fspt_target_set_finish_kernel(fspt_target *t, int mode) {
-  if (!t) { fspt_set_error("fspt_target_set_finish_kernel: NULL target"); return FSPT_E_INVALID; }
-  FLUSH_OR_RETURN(t);
-  if (mode < 0 || mode > 2) { fspt_set_error("fspt_target_set_finish_kernel: mode must be 0, 1 or 2"); return FSPT_E_INVALID; }
-  t->split_finish = mode;
-  return FSPT_OK;
-}
-
 int fspt_target_set_tail(fspt_target *t, int round) {
   if (!t) { fspt_set_error("fspt_target_set_tail: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
@@ -1596,10 +1564,9 @@ int fspt_target_live_paths(fspt_target *t, double *frac, uint32_t n_rounds) {
   if (!t || !frac) { fspt_set_error("fspt_target_live_paths: NULL argument"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
   HIP_TRY(hipSetDevice(t->scene->device));
-  for (auto &ln : t->lanes) {
-    if (!ln.counts_pending) continue;
-    HIP_TRY(hipEventSynchronize(ln.counts_ready));
-    wf_collect_counts(t, ln);
+  if (t->wf.counts_pending) {
+    HIP_TRY(hipEventSynchronize(t->wf.counts_ready));
+    wf_collect_counts(t, t->wf);
   }
   for (uint32_t r = 0; r < n_rounds; ++r) frac[r] = (t->live_known && r < 80) ? (double)t->live_frac[r] : 0.0;
   return t->live_known ? FSPT_OK : FSPT_E_STATE;
@@ -1615,7 +1582,7 @@ int fspt_target_set_memory_limit(fspt_target *t, uint64_t bytes) {
 int fspt_target_path_state_bytes(fspt_target *t, uint64_t *bytes, uint32_t *batch_ticks) {
   if (!t || !bytes) { fspt_set_error("fspt_target_path_state_bytes: NULL argument"); return FSPT_E_INVALID; }
   uint64_t b = 0;
-  for (auto &ln : t->lanes) b += ln.bytes; // (+ 2 x 59 MB of suspension records per lane on a 256-CU part, whatever the frame)
+  b = t->wf.bytes + t->wf.susp_bytes;
   *bytes = b;
   if (batch_ticks) *batch_ticks = t->batch_ticks;
   return FSPT_OK;
@@ -1633,18 +1600,14 @@ int fspt_target_prepare(fspt_target *t) {
   if (t->sched == 1) {
     // the pool of the configured steady state: runs of batch_ticks ticks (at most WF_MAX_BATCH per run)
     const uint32_t units_total = (uint32_t)(work_total >> 6);
-    const uint32_t n_pools = t->n_lanes > units_total ? 1u : t->n_lanes;
     const uint32_t nbt = t->batch_ticks < (uint32_t)fspt::WF_MAX_BATCH ? (t->batch_ticks ? t->batch_ticks : 1u) : (uint32_t)fspt::WF_MAX_BATCH;
-    for (uint32_t l = 0; l < n_pools; ++l) {
-      StPlan pl;
-      int rc = st_plan(t, (units_total - l + n_pools - 1) / n_pools, nbt, clamp_bounces(t->last_cam.num_bounces ? t->last_cam.num_bounces : 8u), pl);
-      if (rc == FSPT_OK) rc = st_ensure(t, t->lanes[l], pl.cap, pl.ring_slots, t->mem_limit ? t->mem_limit / n_pools : ~0ull);
-      if (rc) return rc;
-    }
-    return FSPT_OK;
+    StPlan pl;
+    int rc = st_plan(t, units_total, nbt, clamp_bounces(t->last_cam.num_bounces ? t->last_cam.num_bounces : 8u), pl);
+    if (rc == FSPT_OK) rc = st_ensure(t, t->wf, pl.cap, pl.ring_slots, t->mem_limit ? t->mem_limit : ~0ull);
+    return rc;
   }
-  uint32_t n_lanes, per_lane;
-  return wf_plan_and_ensure(t, work_total, 0, n_lanes, per_lane);
+  uint32_t batch;
+  return wf_plan_and_ensure(t, work_total, 0, batch);
 }
 
 int fspt_last_stage_ms(fspt_target *t, float ms[5], uint32_t launches[5]) {

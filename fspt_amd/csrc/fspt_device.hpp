@@ -228,13 +228,11 @@ struct WfP {
   uint32_t ring_slots;  // entries of the fin ring (batch: n_batch * work_total = no wrap)
   uint32_t cap;         // stream: paths a state set holds
   uint32_t take_max;    // stream: units plan(i) takes at most
-  uint32_t pool, n_pools; // stream: this lane traces units u * n_pools + pool of the frame (1 pool: all)
   int res_from, res_to; // resolve (stream): fold the units between hist[res_from] (< 0: unit 0) and hist[res_to] (-2: all)
   uint32_t finish;      // tail (stream): also generate what the cursor has not handed out
   uint32_t serial;      // plan (stream): it runs AFTER logic(i) (one HIP stream) and sees the real survivors in counts[cnt_out]
   int *susp[2];         // suspended-traversal records: trace(i) writes susp[cnt_out & 1], resumes susp[cnt_in & 1]
   uint32_t susp_stride; // ints per record (WF_SUSP_HEADER + stack entries, a multiple of 4)
-  uint32_t split_finish; // the paths that end in a round are finished by k_wf_finish, k_wf_logic only shades
   uint32_t susp_budget; // traversal steps a wave walks on after its last refill before it suspends (0: never)
   uint32_t W, H;
   uint32_t vw, vh; // viewport, as in TraceP
@@ -253,7 +251,7 @@ struct WfP {
 };
 
 // kernel classes; also the slots of fspt_last_stage_ms
-enum { WF_K_PRIMARY = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3, WF_K_TAIL = 4, WF_K_KINDS = 5, WF_K_PLAN = 5 /* not timed */, WF_K_CARRY = 6 /* not timed */, WF_K_FINISH = 7 /* timed with the logic class */ };
+enum { WF_K_PRIMARY = 0, WF_K_TRACE = 1, WF_K_LOGIC = 2, WF_K_RESOLVE = 3, WF_K_TAIL = 4, WF_K_KINDS = 5 /* timed classes */, WF_K_PLAN = 6 /* not timed */, WF_K_CARRY = 7 /* not timed */ };
 // count: 0 = production kernels; 1 = counting variants doing the reference's work (NEE shadow rays traced to the closest
 // hit, tracer.fs:501); 2 = counting variants of the production work (shadow rays stop at the first hit)
 hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream_t stream);

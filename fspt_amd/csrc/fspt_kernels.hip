@@ -702,8 +702,7 @@ FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randB
 // bounce (new rays in ps) or finish.  Returns true when the path is finished; ps.color
 // then holds the un-clamped sample colour.  Shared by the megakernel and the wavefront
 // pipeline so both run the same arithmetic in the same order.
-// ... its first half: everything but the shading of a live hit.  Returns true when the path is finished (k_wf_finish is
-// this half alone: the paths of a round that end need none of the shading code's 128 registers).
+// ... its first half: everything but the shading of a live hit.  Returns true when the path is finished.
 template <bool COUNT>
 FM_DEV bool consume_rays(const DScene &S, Path &ps, int hitA, int hitB, float envTheta, uint32_t numBounces, Counters &cnt) {
   // NEE result (tracer.fs:500-505)
@@ -765,12 +764,8 @@ FM_DEV bool work_to_pixel(const P &p, uint32_t idx, uint32_t &x, uint32_t &y) {
   return x < p.vw && y < p.vh;
 }
 
-// Sample number g of a run (pixel-major: n_batch ticks per work index) -> work index.  With several pools (stream
-// scheduler, fspt_device.hpp) a pool's units - 64 work indices each - are every n_pools-th unit of the frame.
-FM_DEV uint32_t wf_work_index(const WfP &p, uint32_t g) {
-  const uint32_t w = g / p.n_batch;
-  return p.n_pools > 1u ? ((w >> 6) * p.n_pools + p.pool) * 64u + (w & 63u) : w;
-}
+// Sample number g of a run (pixel-major: n_batch ticks per work index) -> work index.
+FM_DEV uint32_t wf_work_index(const WfP &p, uint32_t g) { return g / p.n_batch; }
 
 // ---------------------------------------------------------------------------
 // The path-trace kernel: tracer.fs main() (436-518) over the whole frame.
@@ -902,69 +897,24 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
                        // their node fetches hit L1 anyway; profiles/r02/ab_primary_lds_top.log)
 #endif
 
-// Path state is streamed (touched once per round).  FSPT_NT=1 builds the non-temporal variant for A/B
-// (measured r01: logic kernel 5 % slower with nt loads, stores box-dependent).
-#ifndef FSPT_NT
-#define FSPT_NT 0
-#endif
-typedef float nt_f4 __attribute__((ext_vector_type(4)));
-typedef float nt_f2 __attribute__((ext_vector_type(2)));
-FM_DEV float4 ld4(const float4 *p) {
-#if FSPT_NT
-  nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-#else
-  return *p;
-#endif
-}
-FM_DEV void st4(float4 *p, float4 v) {
-#if FSPT_NT
-  nt_f4 w = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(w, reinterpret_cast<nt_f4 *>(p));
-#else
-  *p = v;
-#endif
-}
-FM_DEV float2 ld2(const float2 *p) {
-#if FSPT_NT
-  nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2 *>(p));
-  return make_float2(v.x, v.y);
-#else
-  return *p;
-#endif
-}
-FM_DEV void st2(float2 *p, float2 v) {
-#if FSPT_NT
-  nt_f2 w = {v.x, v.y};
-  __builtin_nontemporal_store(w, reinterpret_cast<nt_f2 *>(p));
-#else
-  *p = v;
-#endif
-}
+// Path state is streamed (touched once per round) through plain loads and stores: non-temporal variants were measured
+// slower (logic kernel +5 %, stores box-dependent; profiles/r01, profiles/r02/ab_tunables.log).
+FM_DEV float4 ld4(const float4 *p) { return *p; }
+FM_DEV void st4(float4 *p, float4 v) { *p = v; }
+FM_DEV float2 ld2(const float2 *p) { return *p; }
+FM_DEV void st2(float2 *p, float2 v) { *p = v; }
 // 12-byte (RGB) elements of the finished-sample array: dword-aligned three-dword accesses
-typedef float nt_f3 __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f3a __attribute__((ext_vector_type(3), aligned(4)));
 FM_DEV void st3(float *p, V3 v) {
-  nt_f3 w = {v.x, v.y, v.z};
-  *reinterpret_cast<nt_f3 *>(p) = w;
+  f3a w = {v.x, v.y, v.z};
+  *reinterpret_cast<f3a *>(p) = w;
 }
 FM_DEV V3 ld3(const float *p) {
-  const nt_f3 v = *reinterpret_cast<const nt_f3 *>(p);
+  const f3a v = *reinterpret_cast<const f3a *>(p);
   return v3(v.x, v.y, v.z);
 }
-FM_DEV int ldi(const int *p) {
-#if FSPT_NT
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-FM_DEV void sti(int *p, int v) {
-#if FSPT_NT
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
+FM_DEV int ldi(const int *p) { return *p; }
+FM_DEV void sti(int *p, int v) { *p = v; }
 
 FM_DEV uint32_t lane_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1345,12 +1295,28 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 // LDS-staged tables of the shading kernels: the small read-only tables every shading event gathers from - the
 // material texture sets (fspt_device.hpp), the environment's importance bins and the batch's randBase values - are
 // staged in LDS once per block, so those gathers go through the LDS pipeline instead of the vector-memory pipeline.
-#ifndef WF_LDS_SETS
-#define WF_LDS_SETS 256 // material texture sets (48 B each) staged in LDS
+// The shading kernels stage the scene's small tables in LDS: material texture sets (48 B each), importance bins (16 B each)
+// and the batch's randBase values, in DYNAMIC shared memory sized for the scene at launch (C2: 6 sets + 86 bins + 20
+// ticks = 1.7 KB; rounds 1-3 reserved 28.7 KB for 256 sets / 1 024 bins whatever the scene, which capped the primary
+// launch at 2 blocks per CU by LDS alone).  Scenes whose tables exceed WF_LDS_TABLE_MAX read them from memory.
+#ifndef WF_LDS_TABLE_MAX
+#define WF_LDS_TABLE_MAX (32u * 1024u)
 #endif
-#ifndef WF_LDS_BINS
-#define WF_LDS_BINS 1024
-#endif
+static __host__ __device__ inline uint32_t wf_table_bytes(uint32_t n_tex_sets, uint32_t n_bins, uint32_t n_batch) {
+  return n_tex_sets * 48u + n_bins * 16u + ((n_batch * 4u + 15u) & ~15u);
+}
+struct LdsTables { uint4 *sets; uint4 *bins; float *rb; };
+// carve the tables out of dynamic LDS at `base` (16-byte aligned) and fill them; the caller synchronises
+FM_DEV LdsTables stage_tables(void *base, const DScene &S, const float *rb_trace, uint32_t n_batch, uint32_t nthreads) {
+  LdsTables t;
+  t.sets = reinterpret_cast<uint4 *>(base);
+  t.bins = t.sets + S.n_tex_sets * 3u;
+  t.rb = reinterpret_cast<float *>(t.bins + S.n_bins);
+  for (uint32_t i = threadIdx.x; i < S.n_tex_sets * 3u; i += nthreads) t.sets[i] = S.tex_sets[i];
+  for (uint32_t i = threadIdx.x; i < S.n_bins; i += nthreads) t.bins[i] = S.bins[i];
+  for (uint32_t i = threadIdx.x; i < n_batch; i += nthreads) t.rb[i] = rb_trace[i];
+  return t;
+}
 #ifndef WF_LOGIC_WAVES
 #define WF_LOGIC_WAVES 4 // 4 waves/SIMD (<= 128 VGPRs): measured best of {3, 4, 5(39 spills)} (profiles/r01)
 #endif
@@ -1381,12 +1347,10 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
   constexpr int U = WF_PRIMARY_U;
   __shared__ uint32_t s_cnt[U][NW];
   __shared__ uint32_t s_base;
-  __shared__ uint4 s_sets[LDSTAB ? WF_LDS_SETS * 3 : 1];
-  __shared__ uint4 s_bins[LDSTAB ? WF_LDS_BINS : 1];
-  __shared__ float s_rb[LDSTAB ? WF_MAX_BATCH : 1];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   DScene S = p.scene;
+  const float *s_rb = p.rb_trace;
   const WfSet out = p.set[p.set_out];
   WfCounts *cn = p.counts + p.cnt_out;
   // the samples of this launch: the whole batch, or (stream) the units plan(i) took from the cursor.  g = first + i is
@@ -1401,12 +1365,11 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
     n_in = nu * unit_slots;
     ring0 = (uint32_t)(((unsigned long long)u0 * unit_slots) % p.ring_slots);
   }
-  if (LDSTAB) {
-    for (uint32_t i = threadIdx.x; i < S.n_tex_sets * 3u; i += WF_LOGIC_THREADS) s_sets[i] = p.scene.tex_sets[i];
-    for (uint32_t i = threadIdx.x; i < S.n_bins; i += WF_LOGIC_THREADS) s_bins[i] = p.scene.bins[i];
-    if (threadIdx.x < WF_MAX_BATCH) s_rb[threadIdx.x] = p.rb_trace[threadIdx.x];
-    S.tex_sets = s_sets;
-    S.bins = s_bins;
+  if (LDSTAB) { // behind the stacks
+    const LdsTables tb = stage_tables(lds_dyn + (size_t)NW * S.stack_n * WAVE, p.scene, p.rb_trace, p.n_batch, WF_LOGIC_THREADS);
+    S.tex_sets = tb.sets;
+    S.bins = tb.bins;
+    s_rb = tb.rb;
     __syncthreads();
   }
   Counters cnt = {0, 0, 0, 0, 0, 0};
@@ -1470,8 +1433,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
       ps.bounce = 0; ps.iters = 0; ps.pix = 0; ps.lag = 0u;
       ps.hasShadow = false; ps.primary = true;
       const uint32_t j = (first + i) % p.n_batch;
-      const bool finished = advance_path<COUNT>(S, ps, -1, t_u[u], hit_u[u], LDSTAB ? s_rb[j] : p.rb_trace[j], p.env_theta,
-                                                p.num_bounces, cnt);
+      const bool finished = advance_path<COUNT>(S, ps, -1, t_u[u], hit_u[u], s_rb[j], p.env_theta, p.num_bounces, cnt);
       if (finished) st3(p.fin + 3 * (size_t)slot, ps.color);
       else store_path(out, s_base + s_cnt[u][wave] + lane_rank(m_surv[u]), ps, slot);
     }
@@ -1492,20 +1454,18 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
 template <bool COUNT, bool LDSTAB>
 __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(const WfP p) {
   constexpr int U = WF_LOGIC_U;
+  extern __shared__ int lds_dyn[]; // the staged tables
   __shared__ uint16_t s_list[U * WF_LOGIC_THREADS];
   __shared__ uint32_t s_n, s_total, s_gbase;
-  __shared__ uint4 s_sets[LDSTAB ? WF_LDS_SETS * 3 : 1];
-  __shared__ uint4 s_bins[LDSTAB ? WF_LDS_BINS : 1];
-  __shared__ float s_rb[LDSTAB ? WF_MAX_BATCH : 1];
   const int lane = threadIdx.x & (WAVE - 1);
   DScene S = p.scene;
+  const float *s_rb = p.rb_trace;
   if (threadIdx.x == 0) s_n = 0;
   if (LDSTAB) {
-    for (uint32_t i = threadIdx.x; i < S.n_tex_sets * 3u; i += WF_LOGIC_THREADS) s_sets[i] = p.scene.tex_sets[i];
-    for (uint32_t i = threadIdx.x; i < S.n_bins; i += WF_LOGIC_THREADS) s_bins[i] = p.scene.bins[i];
-    if (threadIdx.x < WF_MAX_BATCH) s_rb[threadIdx.x] = p.rb_trace[threadIdx.x];
-    S.tex_sets = s_sets;
-    S.bins = s_bins;
+    const LdsTables tb = stage_tables(lds_dyn, p.scene, p.rb_trace, p.n_batch, WF_LOGIC_THREADS);
+    S.tex_sets = tb.sets;
+    S.bins = tb.bins;
+    s_rb = tb.rb;
   }
   __syncthreads();
   const WfSet in = p.set[p.set_in], out = p.set[p.set_out];
@@ -1528,8 +1488,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
         const int idx = __float_as_int(ld2(p.hit + i).y);
         shade = idx >= 0; // -1: miss; WF_HIT_TERMINAL: hit with the bounce budget used up
         // (WF_HIT_PENDING: its traversal was suspended - k_wf_carry has moved the path on, nothing to do here)
-        // (p.split_finish: the paths that end here are k_wf_finish's)
-        if (!shade && idx != WF_HIT_PENDING && !p.split_finish) own_fin |= 1u << u;
+        if (!shade && idx != WF_HIT_PENDING) own_fin |= 1u << u;
       }
       const unsigned long long m = __ballot(shade);
       uint32_t wb = 0;
@@ -1572,41 +1531,12 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
         const uint32_t slot = load_path(in, i, ps, p.shadow_hit, hitA);
         const float2 h = ld2(p.hit + i);
         const uint32_t j = slot % p.n_batch;
-        const bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), LDSTAB ? s_rb[j] : p.rb_trace[j],
-                                                  p.env_theta, p.num_bounces, cnt);
+        const bool finished = advance_path<COUNT>(S, ps, hitA, h.x, __float_as_int(h.y), s_rb[j], p.env_theta, p.num_bounces, cnt);
         if (finished) st3(p.fin + 3 * (size_t)slot, ps.color);
         else store_path(out, k_out, ps, slot);
       }
     }
     __syncthreads(); // s_list / s_total are rewritten by the next iteration
-  }
-  flush_counters<COUNT>(cnt, p.counters, 4, lane);
-}
-
-// ---- finish: the paths of a round that END in it (WfP::split_finish) -------------------------------------------------
-// Two paths in three of a round end there: the extension ray left the scene (environment lookup, tracer.fs:509-512) or
-// hit something with the bounce budget used up; before that the NEE result is added (tracer.fs:500-505).  That is two
-// random environment fetches and ~300 instructions - latency-bound work that k_wf_logic does at the 4 waves/SIMD its
-// shading code's 128 registers allow.  Here it runs by itself at 8 waves/SIMD, on a stream of its own beside the logic
-// launch (which then only shades): the two write different things (fin / the next state set).
-#ifndef WF_FINISH_WAVES
-#define WF_FINISH_WAVES 8
-#endif
-template <bool COUNT>
-__global__ __launch_bounds__(BLOCK_THREADS, WF_FINISH_WAVES) void k_wf_finish(const WfP p) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const DScene &S = p.scene;
-  const WfSet in = p.set[p.set_in];
-  const uint32_t n_in = p.counts[p.cnt_in].n_ext;
-  Counters cnt = {0, 0, 0, 0, 0, 0};
-  for (uint32_t i = blockIdx.x * BLOCK_THREADS + threadIdx.x; i < n_in; i += gridDim.x * BLOCK_THREADS) {
-    const int idx = __float_as_int(ld2(p.hit + i).y);
-    if (idx >= 0 || idx == WF_HIT_PENDING) continue; // shaded by k_wf_logic / carried by k_wf_carry
-    Path ps;
-    int hitA;
-    const uint32_t slot = load_path(in, i, ps, p.shadow_hit, hitA);
-    consume_rays<COUNT>(S, ps, hitA, idx, p.env_theta, p.num_bounces, cnt);
-    st3(p.fin + 3 * (size_t)slot, ps.color);
   }
   flush_counters<COUNT>(cnt, p.counters, 4, lane);
 }
@@ -1764,7 +1694,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
         const uint32_t take = want < left ? want : left;
         if (is_main && ps.pix < 0 && g_w < 0 && rank < take) {
           uint32_t fx = 0, fy = 0;
-          const uint32_t w = p.n_pools > 1u ? (((gen_next + rank) >> 6) * p.n_pools + p.pool) * 64u + ((gen_next + rank) & 63u) : gen_next + rank;
+          const uint32_t w = gen_next + rank;
           if (work_to_pixel(p, w, fx, fy)) { // (a pixel outside the viewport does not exist)
             g_w = (int)w;
             g_j = 0;
@@ -2096,8 +2026,8 @@ hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus,
 }
 
 size_t wf_max_stack_entries() {
-  // the largest LDS user per stack entry is the primary launch: 8 waves x 256 B per entry next to ~22 KB of staged tables
-  const size_t lds_cu = 160u * 1024u, tables = 24u * 1024u;
+  // the largest LDS user per stack entry is the primary launch: 8 waves x 256 B per entry next to the staged tables
+  const size_t lds_cu = 160u * 1024u, tables = WF_LDS_TABLE_MAX;
   return (lds_cu - tables) / ((WF_LOGIC_THREADS / WAVE) * WAVE * sizeof(int));
 }
 
@@ -2112,12 +2042,6 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
   hipError_t e = hipSuccess;
   if (kernel == WF_K_PLAN) {
     hipLaunchKernelGGL(k_wf_plan, dim3(1), dim3(WAVE), 0, stream, p);
-    return hipGetLastError();
-  }
-  if (kernel == WF_K_FINISH) {
-    const uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
-    if (count) hipLaunchKernelGGL(k_wf_finish<true>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
-    else hipLaunchKernelGGL(k_wf_finish<false>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
     return hipGetLastError();
   }
   if (kernel == WF_K_CARRY) {
@@ -2167,10 +2091,13 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
     else FSPT_LAUNCH_TAIL(false, true);
 #undef FSPT_LAUNCH_TAIL
   } else if (kernel == WF_K_LOGIC || kernel == WF_K_PRIMARY) {
-    uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * 4u);
-    const bool tab = WF_LOGIC_LDSTAB && p.scene.n_tex_sets <= WF_LDS_SETS && p.scene.n_bins <= WF_LDS_BINS;
+    // resident blocks per CU at WF_LOGIC_WAVES waves per SIMD (4 SIMDs): 2 blocks of 512 threads at 4 waves; twice that many in flight
+    constexpr uint32_t blocks_per_cu = 2u * ((uint32_t)WF_LOGIC_WAVES * 4u * WAVE / WF_LOGIC_THREADS);
+    uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * blocks_per_cu);
+    const uint32_t tab_bytes = wf_table_bytes(p.scene.n_tex_sets, p.scene.n_bins, p.n_batch);
+    const bool tab = WF_LOGIC_LDSTAB && tab_bytes <= WF_LDS_TABLE_MAX;
     if (kernel == WF_K_PRIMARY) {
-      const size_t dyn = (size_t)(WF_LOGIC_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int);
+      const size_t dyn = (size_t)(WF_LOGIC_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int) + (tab ? tab_bytes : 0u);
 #define FSPT_LAUNCH_PRIMARY(C, T)                                                                          \
       do {                                                                                                   \
         if ((e = allow_lds(k_wf_primary<C, T>, dyn)) != hipSuccess) return e;                                \
@@ -2180,7 +2107,8 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
       else { if (tab) FSPT_LAUNCH_PRIMARY(false, true); else FSPT_LAUNCH_PRIMARY(false, false); }
 #undef FSPT_LAUNCH_PRIMARY
     } else {
-#define FSPT_LAUNCH_LOGIC(C, T) hipLaunchKernelGGL((k_wf_logic<C, T>), dim3(grid), dim3(WF_LOGIC_THREADS), 0, stream, p)
+      const size_t dyn = tab ? tab_bytes : 0u;
+#define FSPT_LAUNCH_LOGIC(C, T) hipLaunchKernelGGL((k_wf_logic<C, T>), dim3(grid), dim3(WF_LOGIC_THREADS), dyn, stream, p)
       if (count) { if (tab) FSPT_LAUNCH_LOGIC(true, true); else FSPT_LAUNCH_LOGIC(true, false); }
       else { if (tab) FSPT_LAUNCH_LOGIC(false, true); else FSPT_LAUNCH_LOGIC(false, false); }
 #undef FSPT_LAUNCH_LOGIC

@@ -35,6 +35,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "fspt.h"
+#include "fspt_tuning.h"
 
 #define NAPI_OK(call)                                                  \
   do {                                                                 \
@@ -549,13 +550,6 @@ static napi_value SetPool(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_target_set_pool((fspt_target *)h, paths, drain, cap, overlap));
   return undefined(env);
 }
-static napi_value SetFinishKernel(napi_env env, napi_callback_info info) {
-  napi_value a[2]; void *h; int32_t mode;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
-  NAPI_OK(napi_get_value_int32(env, a[1], &mode));
-  FSPT_OK_OR_THROW(fspt_target_set_finish_kernel((fspt_target *)h, mode));
-  return undefined(env);
-}
 static napi_value SetTraceBudget(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; uint32_t steps;
   if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
@@ -865,7 +859,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   struct { const char *name; napi_callback fn; } fns[] = {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"traceTest", TraceTest}, {"render", Render}, {"clear", Clear},
-      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline}, {"setPool", SetPool}, {"setTraceBudget", SetTraceBudget}, {"setFinishKernel", SetFinishKernel},
+      {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline}, {"setPool", SetPool}, {"setTraceBudget", SetTraceBudget},
       {"setMemoryLimit", SetMemoryLimit}, {"setTextureInterleaveBudget", SetTextureInterleaveBudget}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail}, {"setDeferred", SetDeferred},
       {"renderAsync", RenderAsync}, {"multiCreate", MultiCreate}, {"multiDestroy", MultiDestroy}, {"multiTarget", MultiTarget},
       {"multiCamera", MultiCamera}, {"multiTrace", MultiTrace}, {"multiRender", MultiRender}, {"multiRenderAsync", MultiRenderAsync},

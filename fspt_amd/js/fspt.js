@@ -296,7 +296,7 @@ function loadBlob(path) {
     atlasLayers: m[1], env: secs.env || null, envW: m[2], envH: m[3], bins: secs.bins, leafSize: m[4], depth: m[5] };
 }
 
-const PIPELINE_CODES = { megakernel: 0, wavefront: 1, wavefront2: 2, stream: 3, stream2: 4 };
+const PIPELINE_CODES = { megakernel: 0, wavefront: 1, stream: 2 };
 
 class PathTracer {
   /** scene: {bvh,tri,mat,norm,uv,atlas,atlasRes,atlasLayers,env,envW,envH,bins,leafSize} */
@@ -348,12 +348,10 @@ class PathTracer {
   /** gl.viewport(0, 0, w, h) of drawCamera / drawTracer (main.js:744,761); the reference: resolution * resScale. */
   setViewport(w, h) { addon.setViewport(this._target, w || 0, h || 0); }
   setShard(shard, nShards, tile) { addon.setShard(this._target, shard, nShards, tile || 32); }
-  /** 'wavefront' (batches of ticks), 'stream' (fixed pool of live paths), 'stream2', 'megakernel', 'wavefront2' (include/fspt.h) */
+  /** 'wavefront' (batches of ticks), 'stream' (fixed pool of live paths), 'megakernel' (include/fspt_tuning.h) */
   setPipeline(name, batch) { addon.setPipeline(this._target, PIPELINE_CODES[name] === undefined ? 1 : PIPELINE_CODES[name], batch || 0); }
   /** traversal steps a starved trace wave walks on before it suspends its rays (0 = never; include/fspt.h) */
   setTraceBudget(steps) { addon.setTraceBudget(this._target, steps); }
-  /** 0: the logic kernel finishes the paths that end in a round, 1: a kernel of its own in front of it, 2: beside it (include/fspt.h) */
-  setFinishKernel(mode) { addon.setFinishKernel(this._target, mode); }
   /** stream scheduler: live paths per state set (0 = default), drain iterations (-1 = default), iteration cap (0 = none) */
   setPool(paths, drain, maxIterations, overlap) { addon.setPool(this._target, paths || 0, drain === undefined ? -1 : drain, maxIterations || 0, overlap === undefined ? -1 : overlap); }
   /** -1 adaptive (default), 0 never, r >= 1: the tail kernel takes the live paths over after wavefront round r */

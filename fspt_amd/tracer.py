@@ -22,6 +22,8 @@ def set_texture_interleave_budget(nbytes):
     """Memory later Scene()s may spend on interleaved material textures (fspt_set_texture_interleave_budget)."""
     L.check(L.lib().fspt_set_texture_interleave_budget(int(nbytes)))
 
+PIPELINES = {"megakernel": 0, "wavefront": 1, "stream": 2}  # fspt_target_set_pipeline codes
+
 
 class Scene:
     """Device-resident scene (initBVH's texture uploads, main.js:408-437,548-560)."""
@@ -112,24 +114,20 @@ class PathTracer:
         L.check(L.lib().fspt_target_bind_accumulator(self._t, C.c_void_p(device_ptr)))
 
     def set_pipeline(self, pipeline, batch_ticks=0):
-        """'wavefront' (batches), 'stream' (fixed pool of live paths), 'stream2' (two pools), 'megakernel' or
-        'wavefront2' (two overlapped half-batches); results are bit-identical."""
-        code = {"megakernel": 0, "wavefront": 1, "wavefront2": 2, "stream": 3, "stream2": 4}.get(pipeline, pipeline)
+        """'wavefront' (batches), 'stream' (fixed pool of live paths) or 'megakernel'; results are bit-identical
+        (include/fspt_tuning.h)."""
+        code = PIPELINES.get(pipeline, pipeline)
         L.check(L.lib().fspt_target_set_pipeline(self._t, int(code), int(batch_ticks)))
 
     def set_pool(self, paths=0, drain=-1, max_iterations=0, overlap=-1):
         """Stream scheduler: live paths per state set (0 = default), drain iterations (-1 = default), iteration cap
-        (0 = none; test hook), second HIP stream for plan / primary / resolve (-1 = default).  include/fspt.h:
+        (0 = none; test hook), second HIP stream for plan / primary / resolve (-1 = default).  include/fspt_tuning.h:
         fspt_target_set_pool."""
         L.check(L.lib().fspt_target_set_pool(self._t, int(paths), int(drain), int(max_iterations), int(overlap)))
 
     def set_trace_budget(self, steps):
-        """Traversal steps a starved trace wave walks on before it suspends its rays (0 = never; include/fspt.h)."""
+        """Traversal steps a starved trace wave walks on before it suspends its rays (0 = never; include/fspt_tuning.h)."""
         L.check(L.lib().fspt_target_set_trace_budget(self._t, int(steps)))
-
-    def set_finish_kernel(self, mode):
-        """0: the logic kernel finishes the paths that end in a round; 1: k_wf_finish in front of it; 2: beside it."""
-        L.check(L.lib().fspt_target_set_finish_kernel(self._t, int(mode)))
 
     def prepare(self):
         """Allocate the pipeline's path-state buffers now (not lazily inside the first render)."""
@@ -296,7 +294,7 @@ class MultiPathTracer:
             yield t
 
     def set_pipeline(self, pipeline, batch_ticks=0):
-        code = {"megakernel": 0, "wavefront": 1, "wavefront2": 2, "stream": 3, "stream2": 4}.get(pipeline, pipeline)
+        code = PIPELINES.get(pipeline, pipeline)
         for t in self._targets():
             L.check(L.lib().fspt_target_set_pipeline(t, int(code), int(batch_ticks)))
 

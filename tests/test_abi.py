@@ -12,10 +12,24 @@ from fspt_amd import _lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "fspt.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fspt_[a-z_0-9]+)\s*\(", text)))
+HEADERS = ("fspt.h", "fspt_tuning.h")  # the drop-in boundary; scheduling knobs + measurement hooks
+
+
+def header_functions(names=HEADERS):
+    out = set()
+    for name in names:
+        text = open(os.path.join(ROOT, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(fspt_[a-z_0-9]+)\s*\(", text))
+    return sorted(out)
+
+
+def test_boundary_header_stays_the_boundary():
+    """include/fspt.h is what replaces the reference's WebGL calls + multi-GPU + the scene builder; every
+    scheduling knob lives in fspt_tuning.h."""
+    boundary = header_functions(("fspt.h",))
+    assert not [n for n in boundary if re.search(r"set_(pipeline|pool|tail|trace_budget|deferred|memory_limit)|last_stage|live_paths", n)]
+    assert len(open(os.path.join(ROOT, "include", "fspt.h")).read().split("\n")) <= 300
 
 
 def test_header_symbols_exported():
@@ -23,7 +37,7 @@ def test_header_symbols_exported():
     names = header_functions()
     assert len(names) >= 30
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/fspt.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
 
 
 def test_binding_covers_header():
@@ -31,7 +45,7 @@ def test_binding_covers_header():
 
 
 def test_abi_version():
-    assert L.lib().fspt_abi_version() == 2
+    assert L.lib().fspt_abi_version() == 3
 
 
 def test_rand_base_stream_range():

@@ -186,25 +186,59 @@ def test_d1_camera_rays_statistics(stages):
     assert abs(gd[..., :3].mean() - d[..., :3].mean()) < 2e-3
 
 
-@pytest.mark.parametrize("name", ["small", "variant"])
+def _env_decode_bias(a, env_theta):
+    """SwiftShader's RGBE decode relative to the exact one, on THIS environment map: its RGBA8 -> float conversion is
+    ~6e-5 off, which envColor multiplies by 255 in the exponent (tracer.fs:412) - a deterministic factor (0.989 on the
+    test maps) measured by the reference's own envSample on a fixed set of directions ('brdf3' of the stage goldens) and
+    here against the oracle's lookup of the same directions.  Every photon of these scenes comes from the environment, so
+    the GLSL's converged mean carries exactly this factor."""
+    for name in ("small", "variant"):
+        st = np.load(os.path.join(GOLD, f"glsl_stages_{name}.npz"))
+        sc = scene_from_golden(name)
+        if sc.env_w == a.env_w and sc.env_h == a.env_h and np.array_equal(sc.env, a.env):
+            inp = np.concatenate([st["brdf_A"], st["brdf_B"]], -1).reshape(-1, 8).copy()
+            inp[:, 3] = float(st["env_theta"])
+            o = O.brdf_probe(sc, 3, inp)[:, :3].astype(np.float64)
+            g = st["brdf3"].reshape(-1, 4)[:, :3].astype(np.float64)
+            fin = np.isfinite(g).all(1) & np.isfinite(o).all(1)
+            return float(g[fin].sum() / o[fin].sum())
+    raise AssertionError("no stage golden with this environment map")
+
+
+@pytest.mark.parametrize("name", ["small", "small_d4", "variant", "textured"])
 def test_d5_converged_mean_matches_glsl(name):
-    path = os.path.join(GOLD, f"glsl_converged_{name}.npz")
-    z = np.load(path)
-    a = scene_from_golden(name)
+    """Stage D5: 16 384 spp of the UNMODIFIED tracer.fs on SwiftShader (two randBase streams) against 16 384 spp of the
+    oracle (its own stream): depth 8 (the BASELINE depth) on the flat-colour, the refractive / emissive and the
+    image-mapped scene, depth 4 (tracer.fs:9 as shipped) on the first.  After dividing out the deterministic RGBE-decode
+    factor of SwiftShader (see _env_decode_bias) the whole-image mean agrees within 0.5 %, and the per-pixel difference is
+    the Monte-Carlo noise of the two renders: rel-L2 within 1.3x the GLSL-vs-GLSL floor (0.015 / 0.026 / 0.02)."""
+    z = np.load(os.path.join(GOLD, f"glsl_converged_{name}.npz"))
+    scene_name = str(z["scene"])
+    a = S.textured_test_scene() if scene_name == "textured" else scene_from_golden(scene_name)
     W, H, spp, bounces = int(z["W"]), int(z["H"]), int(z["spp"]), int(z["bounces"])
-    ga, gb = z["a"][..., :3], z["b"][..., :3]
+    assert spp >= 16384 and bounces == (4 if name == "small_d4" else 8)
+    ga, gb = z["a"][..., :3].astype(np.float64), z["b"][..., :3].astype(np.float64)
 
     def rel_l2(x, y):
         return float(np.linalg.norm(x - y) / np.linalg.norm(y))
     floor = rel_l2(ga, gb)  # GLSL-vs-GLSL, two randBase streams
+    assert floor <= 0.03
     acc = np.zeros((H, W, 4), np.float32)
     O.render(a, W, H, [float(x) for x in z["P"]], [float(x) for x in z["I"]], float(z["fov_scale"]),
              [float(x) for x in z["lens"]], float(z["env_theta"]), bounces, 0, spp, 99, acc)
-    o = acc[..., :3]
+    bias = _env_decode_bias(a, float(z["env_theta"]))
+    assert 0.985 <= bias <= 0.993, bias
+    o = acc[..., :3].astype(np.float64)
     gm = 0.5 * (ga + gb)
-    # whole-image mean within 1 % (+ the ~1 % SwiftShader RGBE-exponent bias on environment light)
-    assert abs(o.mean() / gm.mean() - 1.0) <= 0.025, (o.mean(), gm.mean())
-    assert rel_l2(o, ga) <= 3.0 * floor and rel_l2(o, gb) <= 3.0 * floor, (rel_l2(o, ga), rel_l2(o, gb), floor)
+    r = gm.mean() / o.mean()
+    if scene_name == "small":
+        assert abs(r / bias - 1.0) <= 0.005, (r, bias)   # every photon comes from the environment
+    else:
+        # emitted light (tracer.fs:467: an MTL Kem / an emissive map) does not pass through the RGBE decode: the
+        # GLSL's mean lies between the fully biased and the unbiased one
+        assert bias - 0.005 <= r <= 1.005, (r, bias)
+    o = o * r
+    assert rel_l2(o, ga) <= 1.3 * floor and rel_l2(o, gb) <= 1.3 * floor, (rel_l2(o, ga), rel_l2(o, gb), floor)
 
 
 def test_d0_env_bins_odd_image():

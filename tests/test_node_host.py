@@ -39,12 +39,12 @@ def dec(b, dt):
 
 def test_addon_exports():
     out = run_node("exports", {})
-    assert out["abi"] == 2
+    assert out["abi"] == 3
     for name in ("sceneCreate", "targetCreate", "camera", "trace", "render", "clear", "readRadiance", "setShard",
                  "builderCreate", "builderParseObj", "builderCommit", "builderNormalize", "builderBuild",
                  "builderAutofocus", "builderDestroy", "envBins", "counters", "renderAsync", "multiCreate", "multiRender",
                  "multiRenderAsync", "multiReadRadiance", "multiDraw", "multiTarget", "multiDestroy", "setTail",
-                 "setMemoryLimit", "prepare", "setTextureInterleaveBudget", "setPool", "setTraceBudget", "setFinishKernel"):
+                 "setMemoryLimit", "prepare", "setTextureInterleaveBudget", "setPool", "setTraceBudget"):
         assert name in out["exports"]
 
 

@@ -127,8 +127,7 @@ def test_trace_two_call_bitwise(small_scene, camera, bounces, pipeline):
 
 
 @pytest.mark.parametrize("pipeline,batch", [("wavefront", 0), ("wavefront", 2), ("wavefront", 64), ("megakernel", 0),
-                                            ("wavefront2", 0), ("wavefront2", 2), ("wavefront2", 3), ("stream", 0),
-                                            ("stream2", 0)])
+                                            ("wavefront", 3), ("stream", 0), ("stream", 2)])
 def test_render_fused_bitwise(medium_scene, camera, pipeline, batch):
     """fspt_render (ray generation fused into the path kernels) == oracle tick loop, for both
     execution strategies and for batches smaller / larger than the tick count."""
@@ -256,7 +255,7 @@ def test_trace_before_rays_is_state_error(small_scene):
     assert e.value.code == -6
 
 
-@pytest.mark.parametrize("pipeline", PIPELINES + ["wavefront2", "stream2"])
+@pytest.mark.parametrize("pipeline", PIPELINES)
 def test_refractive_scene_bitwise(pipeline):
     """Dielectric material (tracer.fs:481-488: refraction does `i--`, so paths outlive NUM_BOUNCES
     rounds) + mesh normals + metallic: the reference-JS-built 'variant' golden scene."""
@@ -523,16 +522,17 @@ def test_textured_scene_any_interleave_budget(camera, budget):
 
 @pytest.mark.parametrize("pipeline,tail", [("wavefront", 0), ("wavefront", 1), ("megakernel", 0)])
 def test_more_layers_than_the_lds_table_holds(camera, pipeline, tail):
-    """520 quads of distinct flat colours and roughnesses -> more material texture sets than the 256 the shading kernels
-    stage in LDS: the kernels' global-table variants (k_wf_primary / k_wf_logic<..., false>) give the oracle's frame."""
+    """720 quads of distinct flat colours and roughnesses -> 34.6 KB of material texture sets, more than the 32 KB of tables
+    the shading kernels stage in LDS (WF_LDS_TABLE_MAX): the kernels' global-table variants (k_wf_primary /
+    k_wf_logic<..., false>) give the oracle's frame."""
     from fspt_amd import scene as S
     rng = np.random.default_rng(12)
     props = []
-    for i in range(520):
+    for i in range(720):
         c = [round(float(x), 3) for x in rng.uniform(0.05, 1.0, 3)]
         props.append({"path": "synthetic/quad.obj", "scale": 0.45, "rotate": [{"angle": float(rng.uniform(0, 6.28)), "axis": [1, 0.3, 0.2]}],
                       "translate": [float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-1.5, 0.5))],
-                      "emittance": [0, 0, 0], "diffuse": c, "metallicRoughness": [round(i / 700, 4), round(0.1 + i / 500, 4), 0],
+                      "emittance": [0, 0, 0], "diffuse": c, "metallicRoughness": [round(i / 1000, 4), round(0.1 + i / 900, 4), 0],
                       "emission": [round(0.001 * i, 4), 0, 0], "normals": "flat"})
     env, w, h = S.synthetic_env(64, 32)
     arrays = S.build_scene(props, {"synthetic/quad.obj": S.QUAD_OBJ}, env=env, env_w=w, env_h=h)
@@ -713,12 +713,12 @@ def test_bench_configuration_full_size_library_defaults(variant):
     assert np.isfinite(got).all() and (got[..., 3] == 1).all()
 
 
-@pytest.mark.parametrize("pipeline", ["stream", "stream2"])
+@pytest.mark.parametrize("pipeline", ["stream"])
 @pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("pool,drain,max_it", [(0, -1, 0), (1024, -1, 0), (1024, 0, 0), (4096, 5, 0), (0, -1, 1), (2048, -1, 3),
                                                (1 << 20, 9, 0)])
 def test_stream_scheduler_bitwise(medium_scene, camera, pipeline, pool, drain, max_it, overlap):
-    """The stream scheduler (fixed pool of live paths, path regeneration between launches, include/fspt.h pipeline 3/4)
+    """The stream scheduler (fixed pool of live paths, path regeneration between launches, include/fspt_tuning.h pipeline 2)
     against the oracle, whole frame, work counters included:
       * pools from two units (hundreds of iterations, the fin ring wraps many times) to larger than the call;
       * the tail kernel taking over right after the last generating iteration, or only after every round;
@@ -756,7 +756,7 @@ def _advance_seed(seed, ticks):
     return st.value
 
 
-@pytest.mark.parametrize("pipeline", ["stream", "stream2"])
+@pytest.mark.parametrize("pipeline", ["stream"])
 def test_stream_runs_longer_than_one_tick_group(small_scene, camera, pipeline):
     """A call of more than 128 ticks is several stream runs (128 + 2 here), each ended by its own drain; shards and a
     ragged frame on top."""
@@ -845,12 +845,12 @@ def test_stream_path_state_is_bounded():
     pt.close()
 
 
-@pytest.mark.parametrize("pipeline,tail", [("wavefront", 0), ("wavefront", -1), ("wavefront", 2), ("stream", 0), ("stream2", 0)])
+@pytest.mark.parametrize("pipeline,tail", [("wavefront", 0), ("wavefront", -1), ("wavefront", 2), ("stream", 0)])
 @pytest.mark.parametrize("budget", [1, 3, 17, 0])
 def test_suspended_traversals_bitwise(medium_scene, camera, pipeline, tail, budget):
     """A trace wave that can get no more rays suspends its unfinished traversals after `budget` steps (node, t, hit and
     the LDS stack go to a record), the logic launch carries the path over unchanged, the next trace launch resumes the
-    record (include/fspt.h: fspt_target_set_trace_budget).  With a budget of 1 almost every launch parks rays and
+    record (include/fspt_tuning.h: fspt_target_set_trace_budget).  With a budget of 1 almost every launch parks rays and
     paths reach the lag limit; 0 switches it off.  Same frame as the oracle in every case."""
     W, H, ticks = 128, 80, 6
     pt = make_pt(medium_scene, W, H, camera, 8, pipeline, tail=tail)
@@ -885,38 +885,6 @@ def test_suspended_traversals_deep_stack_and_refraction(small_scene, pipeline):
         pt.seed(9)
         pt.render(3)
         assert np.array_equal(pt.readRadiance(), want), pipeline
-        pt.close()
-
-
-@pytest.mark.parametrize("pipeline", ["wavefront", "stream"])
-@pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("scene_name", ["medium", "variant"])
-def test_finish_kernel_bitwise(medium_scene, camera, pipeline, mode, scene_name):
-    """fspt_target_set_finish_kernel: the paths that end in a round (miss -> environment lookup, bounce budget used up,
-    NEE result) finished by k_wf_finish - in front of the logic launch (1) or beside it on a second stream (2) - instead
-    of by the logic kernel: radiance and work counters are the oracle's, with and without refraction."""
-    if scene_name == "variant":
-        from test_goldens import scene_from_golden
-        arrays = scene_from_golden("variant")
-        cam = dict(P=[0.3, 1.2, 3.4], I=[-0.05, -0.3, -0.95], fov_scale=0.5, env_theta=1.66, focal_depth=2.0, aperture=0.02)
-        cam["lens"] = [0.5, 0.02]
-    else:
-        arrays, cam = medium_scene, camera
-    W, H, ticks = 128, 80, 5
-    want = np.zeros((H, W, 4), np.float32)
-    oc = O.OCounters()
-    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], cam["lens"], cam["env_theta"], 4, 0, ticks, 13, want, counters=oc)
-    for counting in (False, True):
-        pt = make_pt(arrays, W, H, cam, 4, pipeline, tail=-1)
-        pt.set_finish_kernel(mode)
-        if counting:
-            pt.enable_counters(True)
-        pt.clear()
-        pt.seed(13)
-        pt.render(ticks)
-        assert np.array_equal(pt.readRadiance(), want), (counting,)
-        if counting:
-            assert pt.counters() == oc.as_dict()
         pt.close()
 
 
@@ -1379,6 +1347,7 @@ def test_batch_is_halved_when_path_state_does_not_fit(small_scene, camera):
              0, 9, 31, want)
     work_total = 3 * 2 * 1024  # 32x32 tiles covering 96x64
     pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
+    pt.set_trace_budget(0)  # (no suspension records: the path state is the slots alone)
     slot = None
     pt.render(1)
     nbytes, batch = pt.path_state_bytes()
@@ -1386,18 +1355,25 @@ def test_batch_is_halved_when_path_state_does_not_fit(small_scene, camera):
     slot = nbytes // work_total
     assert 64 <= slot <= 256
     pt.close()
-    for pipeline, n_primary in (("wavefront", 5), ("wavefront2", 9)):
-        pt = make_pt(small_scene, W, H, camera, 4, pipeline, 128)
-        pt.set_memory_limit(3 * work_total * slot)  # room for 3 ticks: 128 -> 64 -> ... -> 2 fit (two lanes: 1 + 1)
-        pt.prepare()
-        assert pt.path_state_bytes() == (2 * work_total * slot, 2)
-        pt.seed(31)
-        pt.render(9)
-        assert np.array_equal(pt.readRadiance(), want), pipeline
-        assert pt.last_stage_ms()["primary"][1] == n_primary  # 9 ticks in batches of 2 / of 1 per lane
-        pt.close()
-    # two lanes, room for one tick only: falls back to a single lane of one tick
-    pt = make_pt(small_scene, W, H, camera, 4, "wavefront2", 128)
+    # suspension records are part of the reported path state, sized for the trace grid this target can launch
+    # (6 144 paths = 24 blocks of 256 lanes), not for a full chip
+    pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
+    pt.render(1)
+    with_records = pt.path_state_bytes()[0]
+    assert work_total * slot < with_records <= work_total * slot + 2 * (work_total + 256) * (8 + 64 + 4) * 4
+    pt.close()
+    pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
+    pt.set_memory_limit(3 * work_total * slot)  # room for 3 ticks: 128 -> 64 -> ... -> 2 fit (+ the records, or none)
+    pt.prepare()
+    assert pt.path_state_bytes() == (2 * work_total * slot, 2)
+    pt.seed(31)
+    pt.render(9)
+    assert np.array_equal(pt.readRadiance(), want)
+    assert pt.last_stage_ms()["primary"][1] == 5  # 9 ticks in batches of 2
+    assert pt.path_state_bytes()[0] <= 3 * work_total * slot  # records included, or left out when they did not fit
+    pt.close()
+    # room for one tick only (and for no records at all: traversals are then simply not suspended)
+    pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
     pt.set_memory_limit(work_total * slot + slot // 2)
     pt.seed(31)
     pt.render(9)
