@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2  # 1 228.8 G wave64 VALU instructions per second: CDNA4's SIMDs are 32 lanes wide, a
                                       # wave64 instruction issues over 2 cycles (MI355X_MICROARCH.md 'Wave scheduling')
+L2_GATHER_GUIDE_TBPS = (16.8, 18.8)  # MI355X_MICROARCH.md 'Indexed rows: gather into LDS': rows shared by every workgroup (the XCD's L2)
 L1_PEAK_FALLBACK = 8.6e11     # 16-byte lane-requests/s of divergent 64-byte record gathers, all CUs (profiles/r03/l1_peak.json);
                               # bench.py measures it on the box it runs on (tools/microbench/l1_peak) and only falls
                               # back to this when the microbenchmark binary is missing
@@ -159,6 +160,11 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="multi-GPU read-out: gather each rank's own tiles to rank 0 (default) or sum-reduce the full frame")
     ap.add_argument("--batch", type=int, default=128, help="ticks per wavefront batch")
+    ap.add_argument("--l1-peak", type=float, default=None,
+                    help="16-byte lane-requests/s to price the trace kernel against (measured by tools/microbench/l1_peak "
+                         "outside this run, e.g. under a profiler where no child process may be started)")
+    ap.add_argument("--no-l1-microbench", action="store_true", help="never start tools/microbench/l1_peak: use --l1-peak or the fallback constant")
+    ap.add_argument("--rendezvous-timeout", type=float, default=180.0, help="seconds a rank waits for the process group / an exchange before it exits non-zero")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / exchange plumbing only, on CPU over gloo (no GPU, no rendering)")
     args = ap.parse_args(argv)
@@ -274,10 +280,19 @@ def main():
         return dry_run(args, rank, local_rank, world)
 
     # The request-rate peak the trace kernel is priced against is measured first, by a child process started BEFORE this
-    # process touches the GPU (no fork of a process that holds a HIP context).
+    # process touches the GPU (no fork of a process that holds a HIP context).  Under a profiler the preloaded library
+    # has initialised the GPU before main() runs: such runs pass --l1-peak (tools/prof_r04.sh measures it once, outside
+    # rocprofv3) or --no-l1-microbench, and no child is ever started from this process.
     global _L1_PEAK
     if rank == 0 and _L1_PEAK is None:
-        _L1_PEAK = l1_request_peak()
+        if args.l1_peak is not None:
+            _L1_PEAK = (float(args.l1_peak), {"source": "--l1-peak (tools/microbench/l1_peak, measured outside this run)",
+                                              "gather_lane_requests_per_s": float(args.l1_peak)})
+        elif args.no_l1_microbench or _under_profiler():
+            _L1_PEAK = (L1_PEAK_FALLBACK, {"source": "fallback constant (microbenchmark not started: "
+                                                     + ("--no-l1-microbench" if args.no_l1_microbench else "profiler preload detected") + ")"})
+        else:
+            _L1_PEAK = l1_request_peak()
 
     import numpy as np
     import torch
@@ -290,10 +305,20 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     from fspt_amd import distributed as D
-    dist = D.init_process_group(backend="nccl", device=torch.device("cuda", local_rank)) if n_gpus > 1 else None
+    dist = (D.init_process_group(backend="nccl", device=torch.device("cuda", local_rank), timeout_s=args.rendezvous_timeout)
+            if n_gpus > 1 else None)
     world_seen = dist.get_world_size() if dist is not None else 1
     if world_seen != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but RCCL sees {world_seen} ranks")
+    rank_info = None
+    if n_gpus > 1:
+        # every rank says who it is before anything can hang (stderr; rank 0's JSON line stays alone on stdout)
+        rank_info = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
+                     "visible_devices": torch.cuda.device_count(),
+                     "peer_access_to_rank0_device": bool(local_rank == 0 or torch.cuda.can_device_access_peer(local_rank, 0)),
+                     "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                     "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+        sys.stderr.write("[bench rank] " + json.dumps(rank_info) + "\n"); sys.stderr.flush()
 
     t0 = time.perf_counter()
     if args.textured:
@@ -329,11 +354,12 @@ def main():
     exch = D.TileGather(rank, n_gpus, W, H, accum.device, channels=3) if (n_gpus > 1 and args.exchange == "gather") else None
     pt.prepare()  # path-state allocation happens here, never inside a timed region (even with --warmup 0)
 
-    def barrier():
+    def barrier(what="barrier"):
         pt.sync()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            with D.Watchdog(args.rendezvous_timeout, what, rank):
+                dist.barrier()
         torch.cuda.synchronize()
 
     # ---- warmup (untimed) ----
@@ -341,23 +367,26 @@ def main():
         pt.render(args.warmup)
     barrier()
     # ---- timed: --reps regions of exactly K steps each, every one closed by the path's one exchange step ----
-    own = torch.from_numpy(D.owner_mask(rank, n_gpus, W, H)).to(accum.device) if (n_gpus > 1 and args.exchange == "reduce") else None
-    times, kernel_ms_all, stages_all, exch_ms = [], [], [], []
-    for _ in range(args.reps):
-        barrier()
+    foreign = (~torch.from_numpy(D.owner_mask(rank, n_gpus, W, H))).to(accum.device) if (n_gpus > 1 and args.exchange == "reduce") else None
+    times, kernel_ms_all, stages_all, exch_ms, render_ms = [], [], [], [], []
+    for rep_i in range(args.reps):
+        barrier(f"barrier before region {rep_i}")
         t_start = time.perf_counter()
         pt.render(args.steps)
         pt.sync()
         t_render = time.perf_counter()
-        if exch is not None:
-            exch.exchange(accum)  # RCCL over xGMI: rank 0 ends up with the whole frame
-        elif n_gpus > 1:
-            # sum-reduce of the full frame; the other ranks' pixels rank 0 received in the previous region are zeroed
-            # first (own_mask), or they would be added again
-            D.reduce_radiance(accum, dst=0, own_mask=own)
-        barrier()
+        with D.Watchdog(args.rendezvous_timeout if n_gpus > 1 else 0, f"read-out exchange ({args.exchange}) of region {rep_i}", rank):
+            if exch is not None:
+                exch.exchange(accum)  # RCCL over xGMI: rank 0 ends up with the whole frame
+            elif n_gpus > 1:
+                # sum-reduce of the full frame; the other ranks' pixels rank 0 received in the previous region are zeroed
+                # first (foreign mask), or they would be added again
+                D.reduce_radiance(accum, dst=0, foreign_mask=foreign)
+            torch.cuda.synchronize()
+        barrier(f"barrier after region {rep_i}")
         elapsed = time.perf_counter() - t_start
         exch_ms.append((time.perf_counter() - t_render) * 1e3)
+        render_ms.append((t_render - t_start) * 1e3)
         if dist is not None:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -373,12 +402,17 @@ def main():
 
     total_samples = float(W) * H * args.steps
     value = total_samples / elapsed / 1e6
+    if n_gpus > 1:
+        sys.stderr.write("[bench rank] " + json.dumps(dict(rank_info, frame=[W, H], render_ms=[round(x, 3) for x in render_ms],
+                                                           exchange_and_barrier_ms=[round(x, 3) for x in exch_ms],
+                                                           kernel_ms=[round(k[0], 3) for k in kernel_ms_all])) + "\n")
+        sys.stderr.flush()
 
     if rank == 0:
         # the frame as the timed regions left it (rank 0 holds the whole frame after the exchange), checked against the
         # oracle BEFORE the counting ticks of report() add to it
         check = None
-        if not args.no_parity_check:
+        if not args.no_parity_check or n_gpus > 1:  # N > 1: mandatory - the first time bytes that crossed xGMI are verified
             check = parity_check(arrays, W, H, cam, lens, args.bounces, args.warmup + args.reps * args.steps, 1,
                                  accum.cpu().numpy())
         out = report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed, times, kernel_ms, launches,
@@ -386,6 +420,7 @@ def main():
         out["parity_check"] = check
         if n_gpus > 1:
             out["exchange_ms"] = round(exch_ms[med], 3)  # read-out exchange + closing barrier of the median region (inside `value`)
+            out["rank0"] = rank_info
         print(json.dumps(out), flush=True)
         if check is not None and not check["equal"]:
             raise SystemExit("bench.py: the timed run's accumulator differs from the oracle")
@@ -419,6 +454,11 @@ def count_work(pt, mode, bounces=None):
 
 
 _L1_PEAK = None  # (peak, source) measured at the start of main()
+
+
+def _under_profiler():
+    """rocprofv3 preloads its tool library (which initialises the GPU) into this process: no child may be exec'd from it."""
+    return any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"))
 
 
 def l1_request_peak():
@@ -475,7 +515,7 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
         tr_leaf = act["leaves"] - ref0["leaves"]
         tr_paths = ref["shades"]  # one path item per shaded hit (its extension ray [+ shadow ray])
         tr_req = 4.0 * max(0, tr_int - act["trace_lds_steps"]) + 9.0 * tr_leaf + 4.0 * tr_paths
-        l1_peak, l1_src = _L1_PEAK if _L1_PEAK is not None else l1_request_peak()
+        l1_peak, l1_src = _L1_PEAK if _L1_PEAK is not None else (L1_PEAK_FALLBACK, {"source": "fallback constant"})
         kernels = {}
         for k, (ms, n) in stages.items():
             name, bound = KERNELS[k]
@@ -488,17 +528,32 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
                 tb = tps * spt * steps
                 kj["traffic_bytes_per_launch"] = round(tb / max(1, n))
                 kj["traffic_GBps"] = round(tb / (ms / 1e3) / 1e9, 1) if ms > 0 else None
+            if prof and name.replace("fspt::", "") in prof["kernels"]:
+                pk = prof["kernels"][name.replace("fspt::", "")]
+                if "ta_busy" in pk:  # stamped SQ / TA / TD counters of the same code (tools/collect_r04.py)
+                    kj["counters"] = {c: pk[c] for c in ("ta_busy", "td_busy", "valu_active_share", "wait_share", "l2_hit", "waves_per_simd") if c in pk}
             if k == "trace":
                 rps = tr_req * steps / (ms / 1e3) if ms > 0 else 0.0
+                # the same requests as bytes (16 per lane-request) next to the guide's own L2-resident gather rate, and the
+                # reference-layout bytes (60 per step, 144 per leaf) next to it: cross-checks of `frac` that use no
+                # builder-measured peak
+                req_tbps = rps * 16.0 / 1e12
                 kj.update({"lane_requests_per_step": round(tr_req), "achieved_Greq_per_s": round(rps / 1e9, 1),
                            "peak_Greq_per_s": round(l1_peak / 1e9, 1), "frac": round(rps / l1_peak, 4),
-                           "lds_served_interior_steps": round(act["trace_lds_steps"] / max(1, tr_int), 3)})
+                           "lds_served_interior_steps": round(act["trace_lds_steps"] / max(1, tr_int), 3),
+                           "l2_gather": {"requested_TBps": round(req_tbps, 2), "reference_layout_TBps": round(gbps / 1e3, 2),
+                                         "guide_TBps": list(L2_GATHER_GUIDE_TBPS),
+                                         "requested_frac_of_guide": [round(req_tbps / g, 3) for g in reversed(L2_GATHER_GUIDE_TBPS)],
+                                         "reference_layout_frac_of_guide": [round(gbps / 1e3 / g, 3) for g in reversed(L2_GATHER_GUIDE_TBPS)],
+                                         "guide": "MI355X_MICROARCH.md, 'Indexed rows: gather into LDS', rows shared by every workgroup"}})
             elif bound == "hbm":
                 # HBM kernels are priced on what they really move between L2 and the fabric when the counters are available
                 # (cache-resident scene data never has to come from HBM), else on the algorithmic bytes
                 # (no fraction without counters: algorithmic bytes of cache-resident scene data are not HBM bytes)
                 kj.update({"peak_GBps": HBM_PEAK_GBS,
-                           "frac": round(kj["traffic_GBps"] / HBM_PEAK_GBS, 4) if kj["traffic_GBps"] is not None else None})
+                           "frac": round(kj["traffic_GBps"] / HBM_PEAK_GBS, 4) if kj["traffic_GBps"] is not None else None,
+                           "traffic_is": "bytes between L2 and the fabric, (2*FETCH_SIZE + WRITE_SIZE)*1024, Infinity-Cache hits "
+                                         "INCLUDED: an upper bound on DRAM bytes, so `frac` can exceed what a DRAM copy reaches (6.29 TB/s)"})
             kernels[k] = kj
         # The pipeline's instruction work against the chip's VALU issue rate.  Wave-instructions per sample of every
         # kernel class (SQ_INSTS_VALU, same stamped profile) x samples/s against 256 CUs x 4 SIMD-32s x 2.4 GHz / 2 cycles
@@ -547,7 +602,19 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
                          "bytes_per_sample": round(bps, 1), "per_sample": per_sample,
                          "per_sample_timed_variant": {k: round(act[k] / max(1, spt), 4) for k in ("rays", "steps", "leaves")},
                          "kernels": kernels, "valu": valu,
-                         "pipeline_alg_GBps": round(sum(alg.values()) * steps / (kernel_ms / 1e3) / 1e9, 1)})
+                         "pipeline_alg_GBps": round(sum(alg.values()) * steps / (kernel_ms / 1e3) / 1e9, 1),
+                         # SURVEY 8d's figure, stated rather than left to be discovered: algorithmic bytes / s over the HBM
+                         # peak.  Above 1 for a cache-resident scene (25 MB; counter traffic: hbm_counter) - the reason the
+                         # dominant kernel is priced in lane-requests instead
+                         "alg_over_hbm_peak": {"pipeline_reference_work": round(bps * value * 1e6 / 1e9 / HBM_PEAK_GBS, 3),
+                                               "pipeline_timed_kernels": round(sum(alg.values()) * steps / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 3),
+                                               "dominant_kernel": round(dom["alg_GBps"] / HBM_PEAK_GBS, 3)},
+                         "dominant_kernel_counters": dom.get("counters")})
+        if args.pipeline == "stream":
+            # two HIP streams: the classes' event times overlap, their sum exceeds the wall time of the kernels
+            roofline["stage_times_overlap"] = True
+            roofline["share_of_gpu_time"] = round(d_ms / max(kernel_ms, 1e-9), 3)
+            roofline["share_is"] = "this class's summed event time / the ev0..ev1 time of the region (classes overlap on two streams)"
     else:
         avg_launch_ms = kernel_ms / max(1, launches)
         achieved = bps * spt / (avg_launch_ms / 1e3) / 1e9

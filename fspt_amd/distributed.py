@@ -17,7 +17,36 @@ def env_rank():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend=None, device=None):
+class Watchdog:
+    """Hard deadline around a step that can hang for ever - the rendezvous, a collective whose peer has died.  When it
+    fires the rank says on stderr what it was doing and the PROCESS exits with code 3 (os._exit: the main thread may be
+    stuck inside RCCL, where no exception can reach it).  The launcher (torchrun / bench.py's self-launch) then sees a
+    failed rank and takes the others down - a multi-GPU run cannot fail silently or hang until an outer timeout."""
+
+    def __init__(self, seconds, what, rank=0):
+        self.seconds, self.what, self.rank, self._t = float(seconds), what, rank, None
+
+    def _fire(self):
+        import sys
+        sys.stderr.write(f"[rank {self.rank}] TIMEOUT after {self.seconds:.0f} s in: {self.what}\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        import threading
+        if self.seconds > 0:
+            self._t = threading.Timer(self.seconds, self._fire)
+            self._t.daemon = True
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._t is not None:
+            self._t.cancel()
+        return False
+
+
+def init_process_group(backend=None, device=None, timeout_s=None):
     """torch.distributed rendezvous from the torchrun environment (MASTER_ADDR etc.)."""
     import torch.distributed as dist
     rank, _, world = env_rank()
@@ -29,7 +58,11 @@ def init_process_group(backend=None, device=None):
     kw = {}
     if backend == "nccl" and device is not None:
         kw["device_id"] = device
-    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    if timeout_s:
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+    with Watchdog((timeout_s or 0) + 30 if timeout_s else 0, f"init_process_group({backend}, world {world})", rank):
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return dist
 
 
@@ -151,14 +184,18 @@ class TileGather:
         return accum
 
 
-def reduce_radiance(accum, dst=0, own_mask=None):
+def reduce_radiance(accum, dst=0, own_mask=None, foreign_mask=None):
     """The one exchange step as a sum-reduce (the RCCL reduce north_star names): the ranks' full-size buffers are summed
     onto `dst` in place.  Every rank's buffer must be zero outside its own tiles.  That holds for a fresh buffer, but
     after a reduce `dst` holds the other ranks' pixels too - a second reduce would add them again - so a caller that
-    reduces repeatedly passes `own_mask` (bool [H, W], this rank's pixels): everything else is zeroed first."""
+    reduces repeatedly passes `foreign_mask` (bool [H, W], True where the pixel is NOT this rank's; computed once,
+    outside the timed exchange) or `own_mask` (its complement): those pixels are set to zero first - masked_fill_, so
+    that a non-finite value left there cannot survive as 0 * inf = NaN, and without a full-frame temporary."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        if own_mask is not None:
-            accum.mul_(own_mask.unsqueeze(-1).to(accum.dtype))
+        if foreign_mask is None and own_mask is not None:
+            foreign_mask = ~own_mask
+        if foreign_mask is not None:
+            accum.masked_fill_(foreign_mask.unsqueeze(-1), 0.0)
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum

@@ -8,7 +8,29 @@ const job = JSON.parse(fs.readFileSync(process.argv[3], 'utf8'));
 const out = {};
 const b64 = (ta) => Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength).toString('base64');
 const env = job.env ? { rgbe: Uint8Array.from(Buffer.from(job.env.rgbe_b64, 'base64')), width: job.env.width, height: job.env.height } : null;
-if (mode === 'exports') {
+const SF = require(path.join(__dirname, '..', 'fspt_amd', 'js', 'scene_file.js'));
+if (mode === 'scene_file') {
+  // scene JSON + OBJ / MTL / PNG maps / RGBE sky on disk -> arrays (loadSceneFile: main.js:915-950 + initBVH)
+  const { scene: s, settings } = SF.loadSceneFile(job.scene_path);
+  for (const k of ['bvh', 'tri', 'mat', 'norm', 'uv', 'bins', 'atlas', 'env']) out[k] = b64(s[k]);
+  out.depth = s.depth; out.atlasLayers = s.atlasLayers; out.atlasRes = s.atlasRes; out.layers = s.layers;
+  out.focus = b64(new Float64Array(s.focus)); out.settings = settings; out.envW = s.envW; out.envH = s.envH;
+} else if (mode === 'png') {
+  // decodePng on files PIL wrote (every colour type / depth / interlacing the test made), encodePng back
+  out.decoded = {};
+  for (const f of job.files) { const im = SF.decodePng(fs.readFileSync(f)); out.decoded[f] = { width: im.width, height: im.height, rgba: b64(im.data) }; }
+  const px = Uint8Array.from(Buffer.from(job.encode.rgba_b64, 'base64'));
+  fs.writeFileSync(job.encode.out4, SF.encodePng(px, job.encode.width, job.encode.height, 4));
+  const rgb = new Uint8Array(job.encode.width * job.encode.height * 3);
+  for (let i = 0, j = 0; i < px.length; i += 4, j += 3) { rgb[j] = px[i]; rgb[j + 1] = px[i + 1]; rgb[j + 2] = px[i + 2]; }
+  fs.writeFileSync(job.encode.out3, SF.encodePng(rgb, job.encode.width, job.encode.height, 3));
+  let err = null;
+  try { SF.decodePng(Buffer.from('GIF89a-not-a-png')); } catch (e) { err = String(e.message); }
+  out.not_png = err;
+} else if (mode === 'render_scene_file') {
+  const fr = SF.renderToPng(job.scene_path, job.out_png, job.W, job.H, { samples: job.samples, bounces: job.bounces, seed: job.seed, denoise: job.denoise });
+  out.radiance = b64(fr.radiance); out.rgba = b64(fr.rgba);
+} else if (mode === 'exports') {
   out.exports = Object.keys(F.addon).sort();
   out.abi = F.addon.abiVersion();
   out.devices = F.addon.deviceCount();

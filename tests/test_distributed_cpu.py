@@ -60,9 +60,17 @@ def _worker(rank, world, port, tmp):
     own = torch.from_numpy(mask)
     for _ in range(3):
         D.reduce_radiance(t5, dst=0, own_mask=own)
+    # ... and a non-finite value left on a foreign pixel must not survive the zeroing (0 * inf = NaN would): ADVICE r3
+    t6 = torch.from_numpy(acc.copy())
+    foreign = ~own
+    D.reduce_radiance(t6, dst=0, foreign_mask=foreign)
+    fy, fx = np.argwhere(~mask)[0]
+    t6[fy, fx, 0] = float("inf"); t6[fy, fx, 1] = float("nan")
+    D.reduce_radiance(t6, dst=0, foreign_mask=foreign)
     if rank == 0:
         np.save(os.path.join(tmp, "cleared_rgb.npy"), t4.numpy())
         np.save(os.path.join(tmp, "reduced3.npy"), t5.numpy())
+        np.save(os.path.join(tmp, "reduced_nonfinite.npy"), t6.numpy())
         np.save(os.path.join(tmp, "reduced.npy"), t.numpy())
         np.save(os.path.join(tmp, "gathered.npy"), t2.numpy())
         np.save(os.path.join(tmp, "gathered_rgb.npy"), t3.numpy())
@@ -86,6 +94,28 @@ def test_two_rank_tile_shard_and_reduce(tmp_path):
     assert np.array_equal(np.load(os.path.join(str(tmp_path), "gathered_rgb.npy")), want)  # ... shipping RGB only
     assert np.array_equal(np.load(os.path.join(str(tmp_path), "cleared_rgb.npy")), want)   # ... after a clear
     assert np.array_equal(np.load(os.path.join(str(tmp_path), "reduced3.npy")), want)      # three reduces in a row
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "reduced_nonfinite.npy")), want)  # inf / NaN on a foreign pixel
+
+
+def test_watchdog_ends_a_hung_rank():
+    """A rank stuck in a collective whose peer never arrives must END, non-zero, and say where (the
+    first multi-GPU run on hardware must not be able to hang silently).  One rank of a 2-rank gloo group whose peer
+    never starts: init_process_group's own timeout or the watchdog behind it fires."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from fspt_amd import distributed as D\n"
+            "with D.Watchdog(1.5, 'a collective whose peer never arrives', 0):\n"
+            "    import time; time.sleep(60)\n" % root)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3 and time.time() - t0 < 45
+    assert "TIMEOUT after 2 s in: a collective whose peer never arrives" in p.stderr
+    # and a block that finishes in time is left alone
+    with D.Watchdog(5.0, "nothing", 0):
+        pass
 
 
 def test_tile_ownership_partitions_frame():

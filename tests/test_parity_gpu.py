@@ -1045,6 +1045,35 @@ def test_multi_device_target_bitwise(medium_scene, camera, n_dev):
     mp.close()
 
 
+def test_multi_two_physical_devices(medium_scene, camera):
+    """Arms itself on a node with >= 2 GPUs (skips on the 1-GPU pool): fspt_multi_* on devices [0, 1] - the packed tiles
+    of device 1 really cross to device 0 (hipMemcpyPeerAsync between distinct devices, xGMI when the peers can map each
+    other), the assembled frame equals the oracle, and the peer-access report says how the bytes travelled."""
+    from fspt_amd import MultiPathTracer
+    if L.lib().fspt_device_count() < 2:
+        pytest.skip("needs two physical GPUs")
+    W, H = 328, 200
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 8,
+             0, 5, 3, want)
+    mp = MultiPathTracer(medium_scene, W, H, [0, 1], num_bounces=8)
+    mp.set_camera(camera["P"], camera["I"], camera["fov_scale"], camera["env_theta"], camera["focal_depth"], camera["aperture"])
+    mp.seed(3)
+    mp.render(5)
+    got = mp.readRadiance()
+    assert np.array_equal(got, want)
+    assert mp.peer_access(0) == 3 and mp.peer_access(1) in (0, 1, 2, 3)
+    n_tiles = 11 * 7
+    assert mp.last_gather_bytes() == len(range(1, n_tiles, 2)) * 32 * 32 * 16
+    # a second read-out after more ticks (the gather buffers are reused), then the tone-mapped frame
+    mp.render(2)
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 8,
+             5, 2, _advance_seed(3, 5), want)
+    assert np.array_equal(mp.readRadiance(), want)
+    assert np.array_equal(mp.draw(1.0, 1.0, False, 3.0), O.draw(want, 1.0, 1.0, False, 3.0))
+    mp.close()
+
+
 def test_multi_device_eight_way_full_hd(medium_scene, camera):
     """BASELINE configs[3]'s sharding (32x32 tiles dealt round-robin to 8 devices) through fspt_multi_* at 1920x1080:
     eight targets (the box's devices cycled), one read-out gather of 7/8 of the frame - equal to the single-target
