@@ -55,6 +55,7 @@ using namespace fm;
 // bit-identical results.
 // ---------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4u __attribute__((ext_vector_type(4)));
 FM_DEV f2 mk2(float a, float b) { return (f2){a, b}; }
 FM_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 FM_DEV float slab(f2 txy1, f2 txy2, f2 tz) {
@@ -117,7 +118,6 @@ FM_DEV f2 ray_tri2(V3 o, V3 d, f2 v1x, f2 v1y, f2 v1z, f2 e1x, f2 e1y, f2 e1z, f
 // `hit` becomes the leaf SLOT (leaf * LEAF_SIZE + i): the index the hit records are stored under; slot_to_tri gives
 // the reference's triangle index where one is reported (fspt_intersect).
 // ---------------------------------------------------------------------------
-typedef float f4u __attribute__((ext_vector_type(4)));
 FM_DEV void process_leaf(const float *__restrict__ leaves, uint32_t leaf_size, int leaf, V3 o, V3 d, float &t, int &hit) {
   if (leaf_size == 4) {
     const f4u *q = reinterpret_cast<const f4u *>(leaves) + (size_t)leaf * TRI_FLOATS;
@@ -889,13 +889,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 #ifndef WF_LOGIC_U
 #define WF_LOGIC_U 8
 #endif
-#ifndef WF_PRIMARY_U
-#define WF_PRIMARY_U 1 // paths per thread and block iteration.  r01: U = 1 / 2 / 4 / 8 -> 0.327 / 0.320 / 0.331 / 0.357 ms per tick;
-                       // re-measured on this round's kernel: 1 / 2 / 4 -> 15.0 / 15.4 / 16.9 ms per 128 ticks (U = 1 is the
-                       // only one without register spills at 4 waves/SIMD; profiles/r02/ab_primary_paths_per_thread.log).
-                       // (The top of the tree in LDS, as in k_wf_trace, makes this launch 10 % SLOWER: its rays are coherent,
-                       // their node fetches hit L1 anyway; profiles/r02/ab_primary_lds_top.log)
-#endif
+// k_wf_primary takes ONE path per thread and block iteration: r01: 1 / 2 / 4 / 8 -> 0.327 / 0.320 / 0.331 / 0.357 ms per tick;
+// r02: 1 / 2 / 4 -> 15.0 / 15.4 / 16.9 ms per 128 ticks (one is the only count without register spills at 4 waves/SIMD;
+// profiles/r02/ab_primary_paths_per_thread.log).  (The top of the tree in LDS, as in k_wf_trace, makes this launch 10 %
+// SLOWER: its rays are coherent, their node fetches hit L1 anyway; profiles/r02/ab_primary_lds_top.log)
 
 // Path state is streamed (touched once per round) through plain loads and stores: non-temporal variants were measured
 // slower (logic kernel +5 %, stores box-dependent; profiles/r01, profiles/r02/ab_tunables.log).
@@ -1340,13 +1337,25 @@ FM_DEV void flush_counters(const Counters &cnt, unsigned long long *counters, in
 // slot of the batch: the primary ray never travels through HBM, thr / colour / flags are constants, and the VALU-bound
 // shading of some waves overlaps the memory-bound traversal of others on the same SIMD (measured +5.6 % over
 // separate gen / trace / logic launches, profiles/r01).  Survivors go to consecutive indices of state set 1.
+//
+// The survivors' indices are reserved per BLOCK iteration with ONE device-scope atomic, before the shading (same-line
+// atomics serialise at the memory side, ~15 ns each: 128-thread blocks already cost 40 %).  256-thread blocks: the four
+// waves of a SIMD then come from four different blocks and sit in different phases - traversal (memory latency) and
+// shading (VALU) overlap - where the two waves a 512-thread block puts on a SIMD run in step: primary 0.135 -> 0.126 ms
+// per tick at 20-tick batches, 0.240 -> 0.207 on the 1 M-triangle scene (profiles/r04/ab_primary_block_ticket_uniform*.log).
+// Measured with it and NOT adopted: a barrier-free reservation (waves take an LDS ticket, the last arriver does the
+// global atomic, a wave only waits for the published base when it stores its survivors: +-0 at 256 threads - it is the
+// phase mix, not the barrier); a wave-uniform fast path that fetches the node once through the scalar cache
+// (s_load_dwordx16) when all descending lanes stand on the same node (+-0); 96 registers / 5 waves per SIMD (-11 %);
+// tables in dynamic LDS alone (no change: the registers hold the kernel at 4 waves per SIMD).
+#ifndef WF_PRIMARY_THREADS
+#define WF_PRIMARY_THREADS 256
+#endif
 template <bool COUNT, bool LDSTAB>
-__global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary(const WfP p) {
+__global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_primary(const WfP p) {
   extern __shared__ int lds_dyn[]; // the waves' traversal stacks
-  constexpr int NW = WF_LOGIC_THREADS / WAVE;
-  constexpr int U = WF_PRIMARY_U;
-  __shared__ uint32_t s_cnt[U][NW];
-  __shared__ uint32_t s_base;
+  constexpr int NW = WF_PRIMARY_THREADS / WAVE;
+  __shared__ uint32_t s_off[2], s_base[2];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   DScene S = p.scene;
@@ -1365,66 +1374,57 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
     n_in = nu * unit_slots;
     ring0 = (uint32_t)(((unsigned long long)u0 * unit_slots) % p.ring_slots);
   }
+  if (threadIdx.x < 2) s_off[threadIdx.x] = 0u;
   if (LDSTAB) { // behind the stacks
-    const LdsTables tb = stage_tables(lds_dyn + (size_t)NW * S.stack_n * WAVE, p.scene, p.rb_trace, p.n_batch, WF_LOGIC_THREADS);
+    const LdsTables tb = stage_tables(lds_dyn + (size_t)NW * S.stack_n * WAVE, p.scene, p.rb_trace, p.n_batch, WF_PRIMARY_THREADS);
     S.tex_sets = tb.sets;
     S.bins = tb.bins;
     s_rb = tb.rb;
-    __syncthreads();
   }
+  __syncthreads();
   Counters cnt = {0, 0, 0, 0, 0, 0};
   int *stack = lds_dyn + (size_t)wave * S.stack_n * WAVE + lane;
 
-  const uint32_t span = (uint32_t)U * WF_LOGIC_THREADS;
-  for (uint32_t base = blockIdx.x * span; base < n_in; base += gridDim.x * span) {
-    V3 o_u[U], d_u[U];
-    float t_u[U];
-    int hit_u[U];
-    bool valid_u[U];
-    unsigned long long m_surv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t i = base + (uint32_t)u * WF_LOGIC_THREADS + threadIdx.x;
-      const uint32_t g = first + i;
-      uint32_t fx = 0, fy = 0;
-      bool valid = i < n_in && work_to_pixel(p, wf_work_index(p, g), fx, fy);
-      V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
-      float tB = MAX_T;
-      int hitB = -1;
-      if (valid) {
-        if (p.gen_rays) {
-          camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[g % p.n_batch], o, d);
-        } else {
-          float4 po = p.ray_pos[fy * p.W + fx], di = p.ray_dir[fy * p.W + fx];
-          o = v3(po.x, po.y, po.z);
-          d = v3(di.x, di.y, di.z);
-        }
-        if (COUNT) cnt.samples++;
-        int hitA;
-        trace_rays<COUNT, false>(S, stack, o, false, d, d, hitA, tB, hitB, cnt);
+  uint32_t par = 0;
+  for (uint32_t base = blockIdx.x * WF_PRIMARY_THREADS; base < n_in; base += gridDim.x * WF_PRIMARY_THREADS, par ^= 1u) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t g = first + i;
+    uint32_t fx = 0, fy = 0;
+    const bool valid = i < n_in && work_to_pixel(p, wf_work_index(p, g), fx, fy);
+    V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
+    float tB = MAX_T;
+    int hitB = -1;
+    if (valid) {
+      if (p.gen_rays) {
+        camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[g % p.n_batch], o, d);
+      } else {
+        float4 po = p.ray_pos[fy * p.W + fx], di = p.ray_dir[fy * p.W + fx];
+        o = v3(po.x, po.y, po.z);
+        d = v3(di.x, di.y, di.z);
       }
-      o_u[u] = o; d_u[u] = d; t_u[u] = tB; hit_u[u] = hitB; valid_u[u] = valid;
-      // advance_path: a hit is shaded (and the path lives on) unless the bounce budget is already used up
-      m_surv[u] = __ballot(valid && hitB != -1 && p.num_bounces > 0u);
-      if (lane == 0) s_cnt[u][wave] = (uint32_t)__popcll(m_surv[u]);
+      if (COUNT) cnt.samples++;
+      int hitA;
+      trace_rays<COUNT, false>(S, stack, o, false, d, d, hitA, tB, hitB, cnt);
     }
-    // block-aggregated reservation of the survivors' state indices: ONE atomic per U*512 paths, before the shading
+    // advance_path: a hit is shaded (and the path lives on) unless the bounce budget is already used up
+    const unsigned long long m_surv = __ballot(valid && hitB != -1 && p.num_bounces > 0u);
+    // block-aggregated reservation: the waves' offsets from an LDS counter, ONE global atomic per block iteration.
+    // The two LDS words alternate between iterations (parity), so one barrier pair per iteration is enough.
+    uint32_t my_off = 0;
+    if (lane == 0) my_off = atomicAdd(&s_off[par], (uint32_t)__popcll(m_surv));
+    my_off = __builtin_amdgcn_readfirstlane(my_off);
     __syncthreads();
     if (threadIdx.x == 0) {
-      uint32_t tot = 0;
-      for (int u = 0; u < U; ++u)
-        for (int w2 = 0; w2 < NW; ++w2) { uint32_t c = s_cnt[u][w2]; s_cnt[u][w2] = tot; tot += c; }
-      s_base = tot ? atomicAdd(&cn->n_ext, tot) : 0u;
+      const uint32_t tot = s_off[par];
+      s_base[par] = tot ? atomicAdd(&cn->n_ext, tot) : 0u;
+      s_off[par ^ 1u] = 0u;
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!valid_u[u]) continue;
-      const uint32_t i = base + (uint32_t)u * WF_LOGIC_THREADS + threadIdx.x;
+    if (valid) {
       uint32_t slot = ring0 + i; // < 2 * ring_slots: a launch is shorter than the ring
       if (slot >= p.ring_slots) slot -= p.ring_slots;
       Path ps;
-      ps.ro = o_u[u]; ps.rd = d_u[u];
+      ps.ro = o; ps.rd = d;
       ps.thr = v3(1.0f, 1.0f, 1.0f);
       ps.color = v3(0.0f, 0.0f, 0.0f);
       ps.envDir = v3(0.0f, 0.0f, 0.0f);
@@ -1433,11 +1433,10 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_primary
       ps.bounce = 0; ps.iters = 0; ps.pix = 0; ps.lag = 0u;
       ps.hasShadow = false; ps.primary = true;
       const uint32_t j = (first + i) % p.n_batch;
-      const bool finished = advance_path<COUNT>(S, ps, -1, t_u[u], hit_u[u], s_rb[j], p.env_theta, p.num_bounces, cnt);
+      const bool finished = advance_path<COUNT>(S, ps, -1, tB, hitB, s_rb[j], p.env_theta, p.num_bounces, cnt);
       if (finished) st3(p.fin + 3 * (size_t)slot, ps.color);
-      else store_path(out, s_base + s_cnt[u][wave] + lane_rank(m_surv[u]), ps, slot);
+      else store_path(out, s_base[par] + my_off + lane_rank(m_surv), ps, slot);
     }
-    __syncthreads();
   }
   flush_counters<COUNT>(cnt, p.counters, 0, lane);
 }
@@ -1541,25 +1540,25 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
   flush_counters<COUNT>(cnt, p.counters, 4, lane);
 }
 
-// intersectScene (tracer.fs:366-404) for ONE ray per lane (the loop of trace_rays without the second ray); `anyhit`:
-// stop at the first hit (NEE shadow rays, tracer.fs:502).  Inactive lanes fall straight through.
+// intersectScene (tracer.fs:366-404) for ONE ray per lane, in SLICES: the traversal state (node reference, stack depth,
+// t, hit; the stack itself is the lane's LDS column) is the caller's and survives the call.  A lane walks on from
+// where it stands until its ray is finished (cur == REF_SENTINEL) or it has done `budget` loop iterations in this call;
+// the call returns when no lane has anything left to do within its budget.  `anyhit`: stop at the first hit (NEE
+// shadow rays, tracer.fs:502).  Same node sequence and arithmetic as trace_rays, whatever the slicing.
 template <bool COUNT>
-FM_DEV void trace_one(const DScene &S, int *stack, V3 o, V3 d, bool anyhit, bool active, float &tOut, int &hitOut, Counters &cnt) {
+FM_DEV void trace_slice(const DScene &S, int *stack, V3 o, V3 d, bool anyhit, int &cur, int &sp, float &t, int &hit, uint32_t budget,
+                        uint32_t &n /* loop iterations this lane has used of the budget */, Counters &cnt) {
   const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  float t = MAX_T;
-  int hit = -1;
-  int cur = active ? S.root_ref : REF_SENTINEL;
-  int sp = 0;
-  if (COUNT && active) cnt.rays++;
   const float4 *__restrict__ nodes = S.nodes;
   const float *__restrict__ leaves = S.leaves;
   const uint32_t leaf_size = S.leaf_size;
-  while (cur != REF_SENTINEL) {
-    while (cur >= 0) {
+  while (cur != REF_SENTINEL && n < budget) {
+    while (cur >= 0 && n < budget) {
       if (COUNT) cnt.steps++;
-      const float4 *n = nodes + (size_t)cur * NODE_F4;
-      float4 n0 = n[0], n1 = n[1], n2 = n[2];
-      const int2 n3 = node_refs(n);
+      ++n;
+      const float4 *nd = nodes + (size_t)cur * NODE_F4;
+      float4 n0 = nd[0], n1 = nd[1], n2 = nd[2];
+      const int2 n3 = node_refs(nd);
       float tl, tr;
       node_test(n0, n1, n2, o, inv, tl, tr);
       bool hl = tl < t, hr = tr < t;
@@ -1581,15 +1580,14 @@ FM_DEV void trace_one(const DScene &S, int *stack, V3 o, V3 d, bool anyhit, bool
         cur = REF_SENTINEL;
       }
     }
-    if (cur == REF_SENTINEL) break;
+    if (cur >= 0 || cur == REF_SENTINEL) break; // out of budget on an interior node / finished
     if (COUNT) { cnt.steps++; cnt.leaves++; }
+    ++n;
     process_leaf(leaves, leaf_size, ~cur, o, d, t, hit);
     if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
     else cur = REF_SENTINEL;
     if (anyhit && hit != -1) cur = REF_SENTINEL;
   }
-  tOut = t;
-  hitOut = hit;
 }
 
 FM_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src, WAVE), __shfl(v.y, src, WAVE), __shfl(v.z, src, WAVE)); }
@@ -1607,6 +1605,13 @@ FM_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src, WAVE), __shfl(v.y, s
 // is all that speeds it up - K=20 +1.3 %, 5 waves (spills) no better (profiles/r02/ab_ref8_tail_waves.log)
 #ifndef WF_TAIL_WAVES
 #define WF_TAIL_WAVES 4
+#endif
+#ifndef WF_TAIL_SLICE
+#define WF_TAIL_SLICE 32u // traversal steps of a lane per T phase.  No slicing / 64 / 32 / 16: tail 0.126 / 0.115 / 0.100 / 0.092 ms per
+// tick on the 1 M-triangle scene at 20-tick batches, 0.755 / 0.762 / 0.760 / 0.803 ms for a single tick of the 70 k scene,
+// 0.032 everywhere at 20 ticks of it (profiles/r04/ab_tail_slice*.log).  One lane per path (both rays one after the other,
+// shading waves twice as dense) instead of the pair: 0.79 -> 1.09 ms single tick (ab_tail_lane*.log): once the list is
+// used up the kernel is as long as its longest path CHAIN, and the pair takes the shadow rays off that chain.
 #endif
 // GEN (stream scheduler, the last launch of a run): when the list is used up the wave also takes whole UNITS the cursor
 // has not handed out (the host only estimated how many iterations the run needs) and runs their samples itself.  A
@@ -1633,6 +1638,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
   ps.lag = 0u;
   ps.ro = ps.rd = ps.envDir = v3(0.0f, 0.0f, 1.0f);
   uint32_t slot = 0;
+  // this lane's ray (even lanes: the path's extension ray, odd lanes: its NEE shadow ray): RAY_NONE, RAY_GOING (its
+  // traversal state below is valid; the stack is the lane's LDS column) or RAY_DONE (result in r_t / r_hit)
+  enum { RAY_NONE = 0, RAY_GOING = 1, RAY_DONE = 2 };
+  int r_state = RAY_NONE, r_cur = REF_SENTINEL, r_sp = 0, r_hit = -1;
+  float r_t = MAX_T;
   // pool as in k_wf_trace: chunks of 32 paths; every wave's first chunk is its own, the rest is dealt out by the
   // wave's stripe head
   const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
@@ -1729,7 +1739,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
       }
     }
     if (__ballot(is_main && ps.pix >= 0) == 0ull) break;
-    // ---- T: even lanes trace their path's extension ray, odd lanes the same path's shadow ray ----
+    // ---- T: even lanes trace their path's extension ray, odd lanes the same path's shadow ray - in slices of
+    // WF_TAIL_SLICE steps.  A wave used to sit in this phase until its LONGEST ray was done (a few hundred dependent node
+    // fetches walked by one lane, ten times the average ray) while 63 lanes waited: VALU lane utilisation 0.09.  Now a
+    // ray that is not finished when the slice ends simply keeps its traversal state and goes on in the next T phase; the
+    // pairs whose rays ARE finished are shaded and get their next rays (or a new path) in between.
     const int src = lane & ~1;
     const bool m_live = ps.pix >= 0; // (false on odd lanes)
     const bool pair_live = __shfl((int)m_live, src, WAVE) != 0;
@@ -1737,12 +1751,25 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
     const V3 o = shfl3(ps.ro, src);
     const V3 d_sh = shfl3(ps.envDir, src);
     const V3 d = is_main ? ps.rd : d_sh;
-    float tR;
-    int hitR;
-    trace_one<COUNT>(S, stack, o, d, ANYHIT && !is_main, is_main ? pair_live : pair_shadow, tR, hitR, cnt);
-    const int hitA = __shfl(hitR, lane | 1, WAVE); // the shadow ray's result, back on the even lane (-1 when there was none)
+    if (r_state == RAY_NONE && (is_main ? pair_live : pair_shadow)) { // a new ray starts at the root
+      r_state = RAY_GOING; r_cur = S.root_ref; r_sp = 0; r_t = MAX_T; r_hit = -1;
+      if (COUNT) cnt.rays++;
+    }
+    if (r_state != RAY_GOING) r_cur = REF_SENTINEL;
+    uint32_t used = 0;
+    trace_slice<COUNT>(S, stack, o, d, ANYHIT && !is_main, r_cur, r_sp, r_t, r_hit, WF_TAIL_SLICE, used, cnt);
+    if (r_state == RAY_GOING && r_cur == REF_SENTINEL) r_state = RAY_DONE;
+    // a pair is ready when its extension ray is done and its shadow ray is done or was never cast
+    const int st_other = __shfl(r_state, lane | 1, WAVE);
+    const bool ready = m_live && r_state == RAY_DONE && st_other != RAY_GOING;
+    const int hit_other = __shfl(r_hit, lane | 1, WAVE);
+    const int hitA = st_other == RAY_DONE ? hit_other : -1; // the shadow ray's result, back on the even lane
+    const bool pair_ready = __shfl((int)ready, src, WAVE) != 0;
     // ---- S: consume them ----
-    if (m_live) {
+    if (pair_ready) r_state = RAY_NONE; // both lanes of the pair: their rays are consumed now
+    const float tR = r_t;
+    const int hitR = r_hit;
+    if (ready) {
       if (advance_path<COUNT>(S, ps, hitA, tR, hitR, p.rb_trace[slot % p.n_batch], p.env_theta, p.num_bounces, cnt)) {
         if (GEN && g_path) {
           g_acc = accumulate_sample(g_acc, ps.color, p.first_tick + g_j);
@@ -2028,7 +2055,7 @@ hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus,
 size_t wf_max_stack_entries() {
   // the largest LDS user per stack entry is the primary launch: 8 waves x 256 B per entry next to the staged tables
   const size_t lds_cu = 160u * 1024u, tables = WF_LDS_TABLE_MAX;
-  return (lds_cu - tables) / ((WF_LOGIC_THREADS / WAVE) * WAVE * sizeof(int));
+  return (lds_cu - tables) / ((WF_PRIMARY_THREADS / WAVE) * WAVE * sizeof(int));
 }
 
 hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream_t stream) {
@@ -2092,16 +2119,17 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
 #undef FSPT_LAUNCH_TAIL
   } else if (kernel == WF_K_LOGIC || kernel == WF_K_PRIMARY) {
     // resident blocks per CU at WF_LOGIC_WAVES waves per SIMD (4 SIMDs): 2 blocks of 512 threads at 4 waves; twice that many in flight
-    constexpr uint32_t blocks_per_cu = 2u * ((uint32_t)WF_LOGIC_WAVES * 4u * WAVE / WF_LOGIC_THREADS);
-    uint32_t grid = min((total + WF_LOGIC_THREADS - 1) / WF_LOGIC_THREADS, (uint32_t)num_cus * blocks_per_cu);
+    const uint32_t threads = kernel == WF_K_PRIMARY ? (uint32_t)WF_PRIMARY_THREADS : (uint32_t)WF_LOGIC_THREADS;
+    const uint32_t blocks_per_cu = 2u * ((uint32_t)WF_LOGIC_WAVES * 4u * WAVE / threads);
+    uint32_t grid = min((total + threads - 1) / threads, (uint32_t)num_cus * blocks_per_cu);
     const uint32_t tab_bytes = wf_table_bytes(p.scene.n_tex_sets, p.scene.n_bins, p.n_batch);
     const bool tab = WF_LOGIC_LDSTAB && tab_bytes <= WF_LDS_TABLE_MAX;
     if (kernel == WF_K_PRIMARY) {
-      const size_t dyn = (size_t)(WF_LOGIC_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int) + (tab ? tab_bytes : 0u);
+      const size_t dyn = (size_t)(WF_PRIMARY_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int) + (tab ? tab_bytes : 0u);
 #define FSPT_LAUNCH_PRIMARY(C, T)                                                                          \
       do {                                                                                                   \
         if ((e = allow_lds(k_wf_primary<C, T>, dyn)) != hipSuccess) return e;                                \
-        hipLaunchKernelGGL((k_wf_primary<C, T>), dim3(grid), dim3(WF_LOGIC_THREADS), dyn, stream, p);        \
+        hipLaunchKernelGGL((k_wf_primary<C, T>), dim3(grid), dim3(WF_PRIMARY_THREADS), dyn, stream, p);      \
       } while (0)
       if (count) { if (tab) FSPT_LAUNCH_PRIMARY(true, true); else FSPT_LAUNCH_PRIMARY(true, false); }
       else { if (tab) FSPT_LAUNCH_PRIMARY(false, true); else FSPT_LAUNCH_PRIMARY(false, false); }
