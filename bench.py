@@ -531,7 +531,7 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
             if prof and name.replace("fspt::", "") in prof["kernels"]:
                 pk = prof["kernels"][name.replace("fspt::", "")]
                 if "ta_busy" in pk:  # stamped SQ / TA / TD counters of the same code (tools/collect_r04.py)
-                    kj["counters"] = {c: pk[c] for c in ("ta_busy", "td_busy", "valu_active_share", "wait_share", "l2_hit", "waves_per_simd") if c in pk}
+                    kj["counters"] = {c: pk[c] for c in ("ta_busy", "td_busy", "valu_active_share", "valu_lane_utilisation", "wait_share", "l2_hit") if c in pk}
             if k == "trace":
                 rps = tr_req * steps / (ms / 1e3) if ms > 0 else 0.0
                 # the same requests as bytes (16 per lane-request) next to the guide's own L2-resident gather rate, and the

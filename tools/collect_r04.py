@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Derive the committed profile files from a tools/prof_r03.sh session.
-    python tools/collect_r03.py <tag> <workload-key> [<tag> <workload-key> ...]
- -> profiles/r03/<tag>_kernel_stats.csv, <tag>_bench.json.log, <tag>_pmc_summary.txt and profiles/hbm_traffic.json
+"""Derive the committed profile files from a tools/prof_r04.sh session.
+    python tools/collect_r04.py <tag> <workload-key> [<tag> <workload-key> ...]
+ -> profiles/r04/<tag>_kernel_stats.csv, <tag>_bench.json.log, <tag>_pmc_summary.txt and profiles/hbm_traffic.json
     (bytes per sample per kernel, stamped with the hash of the kernel sources the numbers were measured on)."""
 import collections, csv, glob, json, os, re, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
-G, P = "gpurun_out", os.path.join("profiles", "r03")
+G, P = "gpurun_out", os.path.join("profiles", "r04")
 os.makedirs(P, exist_ok=True)
 pairs = list(zip(sys.argv[1::2], sys.argv[2::2]))
 out = {"source_sha": bench.source_sha(),
@@ -131,8 +131,15 @@ for tag, wl in pairs:
             if "SQ_INSTS_VALU" in v and k in kern:
                 kern[k]["valu_wave_instr_per_sample"] = v["SQ_INSTS_VALU"] / sq_samples
                 derived[k]["valu_wave_instr_per_sample"] = round(v["SQ_INSTS_VALU"] / sq_samples, 2)
+    # the counters bench.py attaches to its kernel classes (roofline.kernels.*.counters, roofline.dominant_kernel_counters)
+    for k, d in derived.items():
+        if k in kern:
+            for src, dst in (("TA_busy", "ta_busy"), ("TD_busy", "td_busy"), ("valu_active_share", "valu_active_share"),
+                             ("wait_any_share", "wait_share"), ("l2_hit_rate", "l2_hit"), ("valu_lane_utilisation", "valu_lane_utilisation")):
+                if src in d:
+                    kern[k][dst] = d[src]
     if derived:
-        json.dump({"note": "from <tag>_pmc_summary.txt: bench.py --steps 32 --batch 32 (one 32-tick batch); busy = *_BUSY_sum / "
+        json.dump({"note": "from <tag>_pmc_summary.txt: one timed region of bench.py (SQ_ARGS of tools/prof_r04.sh, default --steps 20); busy = *_BUSY_sum / "
                            "GRBM_GUI_ACTIVE / 31.33 instances (profiles/r01/l1_pipe.json)", "kernels": derived},
                   open(os.path.join(P, f"{base}_derived.json"), "w"), indent=1)
         for k, d in derived.items():

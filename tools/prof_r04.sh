@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-3 profile session (run on the GPU box through gpurun):
-#   tools/prof_r03.sh <tag> [bench args...]     -> gpurun_out/<tag>_{kt,fetch,write,sq*}/ + logs
+# Round-4 profile session (run on the GPU box through gpurun):
+#   tools/prof_r04.sh <tag> [bench args...]     -> gpurun_out/<tag>_{kt,fetch,write,sq*}/ + logs
 # kernel trace + stats of the default bench command, then PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, as the
 # guide prescribes; SQ / TA / TD sets) over one timed batch.  rocprofv3 gets the program itself after `--`.
 set -u
@@ -9,6 +9,15 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 T=$1; shift
 O=$R/gpurun_out
 cd /tmp
+# the request-rate peak bench.py prices the trace kernel against: measured ONCE here, outside the profiler (a process
+# rocprofv3 started has the GPU initialised by the preloaded tool library before main() runs and must not start children)
+L1=$($R/tools/microbench/l1_peak 2>/dev/null | python3 -c "import sys,json
+for l in sys.stdin:
+    if l.startswith('{'): print(json.loads(l)['gather_lane_requests_per_s'])" | tail -1)
+L1ARG=${L1:+--l1-peak $L1}
+[ -z "$L1" ] && L1ARG=--no-l1-microbench
+echo "l1_peak: $L1" > $O/${T}_l1_peak.txt
+set -- $L1ARG "$@"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -- python3 $R/bench.py --no-cpu-baseline ${KT_ARGS:---steps 20 --warmup 5} "$@" > $O/${T}_kt.log 2>&1
 find $O/${T}_kt -name "*kernel_trace.csv" -size +8M -delete
 # traffic passes: the timed configuration itself (TRAFFIC_ARGS, default: the driver's 20-step regions - one warm-up
@@ -27,6 +36,6 @@ for set in \
  "TCP_PERF_SEL_TOTAL_HIT_LRU_READ TCP_PERF_SEL_TOTAL_MISS_LRU_READ TCP_PERF_SEL_TOTAL_MISS_EVICT_READ" \
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --output-format csv -d $O/${T}_sq$i -- python3 $R/bench.py --steps 32 --batch 32 --warmup 0 --reps 1 --no-cpu-baseline --no-parity-check "$@" > $O/${T}_sq$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d $O/${T}_sq$i -- python3 $R/bench.py ${SQ_ARGS:---steps 20 --warmup 0 --reps 1} --no-cpu-baseline --no-parity-check "$@" > $O/${T}_sq$i.log 2>&1
 done
 echo prof done
