@@ -241,61 +241,49 @@ def _js_split_spaces(line):
     return re.split(r"[ ]+", line.strip(" \t\r\n\f\v\ufeff\xa0"))
 
 
-def get_material(prop, packer, images=None, group_material=None, base_path=""):
-    """getMaterial (main.js:206-270) for one OBJ group: the group's MTL entry (map_kd / kd, map_pmr / pmr,
-    map_kem / kem, map_bump, ior, dielectric) wins over the prop's scene-JSON fields.  Colour-valued maps
-    become flat layers; string-valued maps name an entry of `images` ({path: uint8 [h, w, 4], row 0 = top})
-    and become resampled image layers (diffuse maps sRGB-decoded, main.js:214-219; metallicRoughness honours
-    pmr_swizzle / mrSwizzle, main.js:226-236)."""
-    images = images or {}
-    gm = group_material or {}
+# The four atlas layers of a material, in the order their ids are handed out (the packer numbers layers by first use, so
+# the order is part of the result).  Per layer the first source that exists wins: the group's MTL image map, the group's
+# MTL colour, the prop's scene-JSON field (an image URL, or - where `prop_colour` - a colour), the default colour.
+# Same table as fspt_amd/js/fspt.js MATERIAL_LAYERS; semantics: getMaterial, main.js:206-270.
+MATERIAL_LAYERS = (
+    dict(id="diffuseIndex", map="map_kd", colour="kd", prop="diffuse", prop_colour=True, default=[0.5, 0.5, 0.5], srgb=True),
+    dict(id="roughnessIndex", map="map_pmr", colour="pmr", prop="metallicRoughness", prop_colour=True, default=[0.0, 0.3, 0],
+         map_swizzle="pmr_swizzle", prop_swizzle="mrSwizzle"),
+    dict(id="specularIndex", map="map_kem", colour="kem", prop="emission", prop_colour=False, default=[0, 0, 0]),
+    dict(id="normalIndex", map="map_bump", colour=None, prop="normal", prop_colour=False, any_truthy_prop=True, default=[0.5, 0.5, 1]),
+)
 
-    def tex(url, corrected=False, **kw):
+
+def get_material(prop, packer, images=None, group_material=None, base_path=""):
+    """One OBJ group's material: atlas layer ids + ior / dielectric / emittance.  `images` = {path: uint8 [h, w, 4],
+    row 0 = top}; image layers are resampled by the packer (diffuse maps sRGB-decoded, metallic-roughness maps through
+    their swizzle).  An array-valued scene-JSON `emission` / `normal` is not a colour source (MATERIAL_LAYERS)."""
+    images = images or {}
+    mtl = group_material or {}
+
+    def image(url, layer, swizzle):
         if url not in images:
             raise KeyError(f"texture {url!r} is not in `images`")
-        return packer.add_texture(url, images[url], corrected, **kw)
+        kw = {"swizzle": swizzle} if "map_swizzle" in layer else {}
+        return packer.add_texture(url, images[url], bool(layer.get("srgb")), **kw)
 
-    if gm.get("map_kd"):
-        diffuse = tex(base_path + "/" + gm["map_kd"], True)
-    elif gm.get("kd"):
-        diffuse = packer.add_color(gm["kd"])
-    elif isinstance(prop.get("diffuse"), str):
-        diffuse = tex(prop["diffuse"], True)
-    elif isinstance(prop.get("diffuse"), (list, tuple, dict)):
-        diffuse = packer.add_color(prop["diffuse"])
-    else:
-        diffuse = packer.add_color([0.5, 0.5, 0.5])
-
-    if gm.get("map_pmr"):
-        rough = tex(base_path + "/" + gm["map_pmr"], False, swizzle=gm.get("pmr_swizzle"))
-    elif gm.get("pmr"):
-        rough = packer.add_color(gm["pmr"])
-    elif isinstance(prop.get("metallicRoughness"), str):
-        rough = tex(prop["metallicRoughness"], False, swizzle=prop.get("mrSwizzle"))
-    elif isinstance(prop.get("metallicRoughness"), (list, tuple, dict)):
-        rough = packer.add_color(prop["metallicRoughness"])
-    else:
-        rough = packer.add_color([0.0, 0.3, 0])
-
-    if gm.get("map_kem"):
-        spec = tex(base_path + "/" + gm["map_kem"])
-    elif gm.get("kem"):
-        spec = packer.add_color(gm["kem"])
-    elif isinstance(prop.get("emission"), str):
-        spec = tex(prop["emission"])
-    else:  # an array-valued `emission` is ignored by the reference (main.js:249-253)
-        spec = packer.add_color([0, 0, 0])
-
-    if gm.get("map_bump"):
-        normal = tex(base_path + "/" + gm["map_bump"])
-    elif prop.get("normal"):
-        normal = tex(prop["normal"])
-    else:
-        normal = packer.add_color([0.5, 0.5, 1])
-    ior = gm.get("ior") or prop.get("ior") or 1.4
-    dielectric = gm.get("dielectric") or prop.get("dielectric") or -1
-    return dict(diffuseIndex=diffuse, roughnessIndex=rough, specularIndex=spec, normalIndex=normal,
-                ior=float(ior), dielectric=float(dielectric), emittance=prop.get("emittance", [0, 0, 0]))
+    out = {}
+    for layer in MATERIAL_LAYERS:
+        pv = prop.get(layer["prop"])
+        if mtl.get(layer["map"]):
+            out[layer["id"]] = image(base_path + "/" + mtl[layer["map"]], layer, mtl.get(layer.get("map_swizzle")))
+        elif layer["colour"] and mtl.get(layer["colour"]):
+            out[layer["id"]] = packer.add_color(mtl[layer["colour"]])
+        elif isinstance(pv, str) or (layer.get("any_truthy_prop") and pv):
+            out[layer["id"]] = image(pv, layer, prop.get(layer.get("prop_swizzle")))
+        elif layer["prop_colour"] and isinstance(pv, (list, tuple, dict)):
+            out[layer["id"]] = packer.add_color(pv)
+        else:
+            out[layer["id"]] = packer.add_color(layer["default"])
+    out["ior"] = float(mtl.get("ior") or prop.get("ior") or 1.4)
+    out["dielectric"] = float(mtl.get("dielectric") or prop.get("dielectric") or -1)
+    out["emittance"] = prop.get("emittance", [0, 0, 0])
+    return out
 
 
 _NORMALS_MODE = {None: 0, "flat": 0, "smooth": 1, "mesh": 2}
