@@ -204,10 +204,24 @@ function renderToPng(scenePath, outPath, width, height, opts) {
   return fr;
 }
 
-module.exports = { decodePng, encodePng, mtllibUrls, loadSceneFile, renderFrame, renderToPng };
+/** frame=N sequencing (main.js:851-866, 966-969): for every N of `frames` load scenePattern with {frame} replaced (the
+ *  per-frame scene JSON the reference's server hands out for `?frame=N`), render it, write outPattern with {frame}
+ *  replaced (the reference POSTs the canvas PNG to /upload/<scene>/<N>), go on to N + 1.  Returns the files written. */
+function renderSequence(scenePattern, frames, outPattern, width, height, opts) {
+  const written = [];
+  for (const n of frames) {
+    const out = outPattern.replace('{frame}', String(n));
+    renderToPng(scenePattern.replace('{frame}', String(n)), out, width, height, opts);
+    written.push(out);
+  }
+  return written;
+}
+
+module.exports = { decodePng, encodePng, mtllibUrls, loadSceneFile, renderFrame, renderToPng, renderSequence };
 
 // node fspt_amd/js/scene_file.js scene/bunny.json out.png [--width W] [--height H] [--samples N] [--bounces B] [--seed S]
-//                                [--asset-root DIR] [--denoise]       (mirrors `python -m fspt_amd.render`)
+//                                [--asset-root DIR] [--denoise] [--frames A:B]   (mirrors `python -m fspt_amd.render`;
+//                                with --frames both paths contain {frame}: the reference's ?frame=N loop)
 if (require.main === module) {
   const argv = process.argv.slice(2), pos = [], o = { width: 960, height: 540 };
   for (let i = 0; i < argv.length; i++) {
@@ -219,7 +233,14 @@ if (require.main === module) {
   if (pos.length !== 2) { console.error('usage: node scene_file.js <scene.json> <out.png> [--width W] [--height H] [--samples N] [--bounces B] [--seed S] [--asset-root DIR] [--denoise]'); process.exit(2); }
   const num = (k) => (o[k] === undefined ? undefined : Number(o[k]));
   const t0 = Date.now();
-  const fr = renderToPng(pos[0], pos[1], Number(o.width), Number(o.height), { samples: num('samples'), bounces: num('bounces'), seed: num('seed'),
-    assetRoot: o.assetRoot, denoise: !!o.denoise });
-  console.log(JSON.stringify({ out: pos[1], width: fr.width, height: fr.height, seconds: (Date.now() - t0) / 1000 }));
+  const ro = { samples: num('samples'), bounces: num('bounces'), seed: num('seed'), assetRoot: o.assetRoot, denoise: !!o.denoise };
+  if (o.frames) {
+    const [a, b] = String(o.frames).split(':').map(Number), frames = [];
+    for (let n = a; n < b; n++) frames.push(n);
+    const written = renderSequence(pos[0], frames, pos[1], Number(o.width), Number(o.height), ro);
+    console.log(JSON.stringify({ out: written, seconds: (Date.now() - t0) / 1000 }));
+  } else {
+    const fr = renderToPng(pos[0], pos[1], Number(o.width), Number(o.height), ro);
+    console.log(JSON.stringify({ out: pos[1], width: fr.width, height: fr.height, seconds: (Date.now() - t0) / 1000 }));
+  }
 }

@@ -266,3 +266,41 @@ def test_js_render_scene_file_to_png(tmp_path):
     img = np.asarray(Image.open(png).convert("RGB"))
     assert img.shape == (H, W, 3)
     assert np.array_equal(img, O.draw(want, st["exposure"], 1.0, False, 3.0)[::-1, :, :3])
+
+
+@pytest.mark.gpu
+def test_js_cli_frame_sequence(tmp_path):
+    """`node scene_file.js 'scene/anim_{frame}.json' 'up/{frame}.png' --frames 0:2`: the reference's ?frame=N loop
+    (main.js:851-866, 966-969) from the command line of its own language; every PNG equals the Python host's render of
+    the same frame file - which test_frame_sequence_from_scene_files pins to the oracle - up to the one-step atlas
+    difference between the two hosts' sRGB pow()."""
+    import copy
+    from PIL import Image
+    from fspt_amd import scene_file as PF
+    from test_goldens import load_js, write_asset_tree
+    z, scene, texts, files = load_js("mtl")
+    scene = dict(scene, cameraPos=[0.2, 0.6, 2.4], cameraDir=[-0.05, -0.2, -1.0], samples=3, exposure=1.3, environmentTheta=0.7)
+    frames = {}
+    for n in range(2):
+        sc = copy.deepcopy(scene)
+        sc["animated_props"]["a"]["translate"] = [1.0 - 0.4 * n, 0.5, 0.1 * n]
+        frames[f"anim_{n}.json"] = sc
+    root = str(tmp_path)
+    write_asset_tree(root, z, scene, texts, files, frames)
+    W, H = 80, 48
+    p = subprocess.run(["node", os.path.join(ROOT, "fspt_amd", "js", "scene_file.js"), os.path.join(root, "scene", "anim_{frame}.json"),
+                        os.path.join(root, "up", "{frame}.png"), "--frames", "0:2", "--width", str(W), "--height", str(H), "--bounces", "4",
+                        "--seed", "9"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    outs = json.loads(p.stdout.strip().splitlines()[-1])["out"]
+    assert len(outs) == 2
+    imgs = []
+    for n, path in enumerate(outs):
+        arrays, st = PF.load_scene_file(os.path.join(root, "scene", f"anim_{n}.json"))
+        rgba, _ = PF.render_frame(arrays, st, W, H, bounces=4, seed=9)
+        got = np.asarray(Image.open(path).convert("RGB")).astype(int)
+        assert got.shape == (H, W, 3)
+        d = np.abs(got - rgba[..., :3].astype(int))
+        assert d.max() <= 2 and (d > 0).mean() < 0.02, (n, d.max(), (d > 0).mean())
+        imgs.append(got)
+    assert (imgs[0] != imgs[1]).mean() > 0.01  # the animated prop really moved
