@@ -178,6 +178,14 @@ def parse_args(argv=None):
     return args
 
 
+def _rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:  # noqa: BLE001 - a missing version query must not take a rank down
+        return f"unknown ({type(e).__name__})"
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -305,7 +313,10 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     from fspt_amd import distributed as D
-    dist = (D.init_process_group(backend="nccl", device=torch.device("cuda", local_rank), timeout_s=args.rendezvous_timeout)
+    # the process group's own timeout (what RCCL's watchdog applies to every collective) is generous - rank 0 checks the
+    # frame against the oracle and counts work while the others wait at the closing barrier; the tighter deadlines around
+    # the rendezvous, the barriers of the timed regions and the exchange are the Watchdogs below
+    dist = (D.init_process_group(backend="nccl", device=torch.device("cuda", local_rank), timeout_s=max(600.0, 2 * args.rendezvous_timeout))
             if n_gpus > 1 else None)
     world_seen = dist.get_world_size() if dist is not None else 1
     if world_seen != args.gpus:
@@ -316,7 +327,7 @@ def main():
         rank_info = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
                      "visible_devices": torch.cuda.device_count(),
                      "peer_access_to_rank0_device": bool(local_rank == 0 or torch.cuda.can_device_access_peer(local_rank, 0)),
-                     "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                     "rccl": _rccl_version(torch),
                      "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
         sys.stderr.write("[bench rank] " + json.dumps(rank_info) + "\n"); sys.stderr.flush()
 

@@ -61,7 +61,7 @@ def init_process_group(backend=None, device=None, timeout_s=None):
     if timeout_s:
         import datetime
         kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
-    with Watchdog((timeout_s or 0) + 30 if timeout_s else 0, f"init_process_group({backend}, world {world})", rank):
+    with Watchdog(min(timeout_s, 300.0) + 30 if timeout_s else 0, f"init_process_group({backend}, world {world})", rank):
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return dist
 
