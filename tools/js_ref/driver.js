@@ -2,18 +2,17 @@
 // (vector.js, bvh.js, obj_loader.js, env_sampler.js imported unmodified from a
 // temp copy of /root/reference beside a {"type":"module"} package.json) and
 // dumps what main.js would upload.  main.js itself cannot be imported (it
-// touches the DOM at import time, main.js:953-975), so its pure array-pushing
-// packing loops (main.js:360-392) and maskBVHBuffer (main.js:272-282) are
-// restated here.  getMaterial (main.js:206-270) and mergeSceneProps (main.js:869-871) are NOT restated:
-// js_ref.py cuts their source text out of main.js at run time into ref_functions.js (never committed),
-// and they run unmodified against the reference's own TexturePacker (texture_packer.js, imported).
+// touches the DOM at import time, main.js:953-975): js_ref.py cuts the source text of getMaterial (main.js:206-270),
+// mergeSceneProps (:869-871), maskBVHBuffer (:272-282), shootAutoFocusRay (:447-546), the scene.normalize block
+// (:337-348) and the packing loops (:358-392) out of main.js at run time into ref_functions.js (never committed), and
+// they run unmodified against the reference's own modules.  Nothing of main.js is restated here.
 import * as ObjLoader from './obj_loader.js';
 import { BVH } from './bvh.js';
 import { ProcessEnvRadiance } from './env_sampler.js';
 import { TexturePacker } from './texture_packer.js';
 import { BoundingBox } from './bvh.js';
 import { Vec3 } from './vector.js';
-import { getMaterial, mergeSceneProps, autoFocus } from './ref_functions.js';
+import { getMaterial, mergeSceneProps, autoFocus, normalizeScene, packScene, maskBVHBuffer } from './ref_functions.js';
 import fs from 'fs';
 
 (async () => {
@@ -59,17 +58,7 @@ import fs from 'fs';
           group.triangles.forEach((t) => { t.material = material; geometry.push(t); });
         });
       }
-      if (scene.normalize) {                                  // main.js:337-348
-        let diff = Vec3.sub(bounds.max, bounds.min);
-        let longest = Math.max(Math.max(diff[0], diff[1]), diff[2]);
-        let centroid = bounds.centroid;
-        let scale = 2 * scene.normalize / longest;
-        for (let i = 0; i < geometry.length; i++) {
-          for (let j = 0; j < geometry[i].verts.length; j++) {
-            geometry[i].verts[j] = Vec3.scale(Vec3.sub(geometry[i].verts[j], centroid), scale)
-          }
-        }
-      }
+      normalizeScene(Vec3, scene, bounds, geometry);          // main.js:337-348, cut from main.js
       out.image_set = texturePacker.imageSet.map((e) => Array.isArray(e) ? { color: e } :
         { src: e.currentSrc, corrected: !!e.corrected, swizzle: e.swizzle || null });
       out.n_props = props.length;
@@ -84,34 +73,11 @@ import fs from 'fs';
     const t0 = Date.now();
     const bvh = new BVH(geometry, job.leaf_size || 4);
     out.build_ms = Date.now() - t0;
-    console.log = realLog;
     // shootAutoFocusRay (main.js:447-546) needs the un-serialized tree: run it first
     out.autofocus = (job.autofocus || []).map(([eye, dir]) => autoFocus(Vec3, bvh, eye, dir));
-    const bvhArray = bvh.serializeTree();
-    let bvhBuffer = [], trianglesBuffer = [], materialBuffer = [], normalBuffer = [], uvBuffer = [];
-    for (let i = 0; i < bvhArray.length; i++) {           // main.js:360-392
-      let e = bvhArray[i];
-      let node = e.node;
-      let triIndex = node.leaf ? trianglesBuffer.length / 3 / 3 : -1;
-      let bufferNode = [e.left, e.right, triIndex].concat(node.boundingBox.min, node.boundingBox.max);
-      if (node.leaf) {
-        let tris = node.getTriangles();
-        for (let j = 0; j < tris.length; j++) {
-          trianglesBuffer.push(...tris[j].verts[0], ...tris[j].verts[1], ...tris[j].verts[2]);
-          let material = tris[j].material;
-          materialBuffer.push(material.diffuseIndex, material.specularIndex, material.normalIndex,
-            material.roughnessIndex, 0, 0, ...material.emittance, material.ior, material.dielectric, 0);
-          for (let k = 0; k < 3; k++) {
-            normalBuffer.push(...tris[j].normals[k], ...tris[j].tangents[k], ...tris[j].bitangents[k]);
-          }
-          uvBuffer.push(...tris[j].uvs[0], ...tris[j].uvs[1], ...tris[j].uvs[2]);
-        }
-      }
-      for (let j = 0; j < bufferNode.length; j++) bvhBuffer.push(bufferNode[j]);
-    }
-    // maskBVHBuffer (main.js:272-282)
-    let masked = new Float32Array(new Int32Array(bvhBuffer).buffer);
-    for (let i = 0; i < bvhBuffer.length; i += 9) for (let j = 3; j < 9; j++) masked[i + j] = bvhBuffer[i + j];
+    const { bvhBuffer, trianglesBuffer, materialBuffer, normalBuffer, uvBuffer } = packScene(bvh);   // main.js:358-392, cut from main.js
+    const masked = maskBVHBuffer(bvhBuffer);                                                        // main.js:272-282
+    console.log = realLog;
     const b64 = (f32) => Buffer.from(f32.buffer, f32.byteOffset, f32.byteLength).toString('base64');
     out.depth = bvh.depth;
     out.bvh = b64(masked);

@@ -32,6 +32,22 @@ def _cut_function(src, name):
         i += 1
 
 
+def _cut_block(src, head, start=0):
+    """The source text from `head` (e.g. 'if (scene.normalize) {', 'for (...) {') to its matching closing brace."""
+    a = src.index(head, start)
+    i = src.index("{", a + len(head) - 1)
+    depth = 0
+    while True:
+        c = src[i]
+        if c == "{":
+            depth += 1
+        elif c == "}":
+            depth -= 1
+            if depth == 0:
+                return src[a:i + 1], i + 1
+        i += 1
+
+
 def run(job, max_old_space_mb=6000):
     with tempfile.TemporaryDirectory() as td:
         for f in ("vector.js", "bvh.js", "obj_loader.js", "mtl_loader.js", "utility.js", "env_sampler.js",
@@ -46,6 +62,16 @@ def run(job, max_old_space_mb=6000):
             fh.write("export function autoFocus(Vec3, bvh, eye, dir) {\n  const maxT = 1e6;\n  let lensFeatures = [0, 0];\n"
                      "  let elements = { focalDepthElement: {} };\n" + _cut_function(main_src, "shootAutoFocusRay") +
                      "\n  shootAutoFocusRay();\n  return lensFeatures[0];\n}\n")
+            # initBVH's scene.normalize block (main.js:337-348) and its packing loops (main.js:358-392) are statements
+            # inside initBVH, not functions: their text is cut out the same way and given the names they use
+            init = main_src[main_src.index("async function initBVH("):]
+            norm, _ = _cut_block(init, "if (scene.normalize) {")
+            fh.write("export function normalizeScene(Vec3, scene, bounds, geometry) {\n" + norm + "\n}\n")
+            a = init.index("let bvhArray = bvh.serializeTree();")
+            loop, end = _cut_block(init, "for (let i = 0; i < bvhArray.length; i++) {", a)
+            fh.write("export function packScene(bvh) {\n  let time = 0;\n" + init[a:end] +
+                     "\n  return { bvhBuffer, trianglesBuffer, materialBuffer, normalBuffer, uvBuffer };\n}\n")
+            fh.write("export " + _cut_function(main_src, "maskBVHBuffer") + "\n")
         shutil.copy(os.path.join(HERE, "driver.js"), td)
         with open(os.path.join(td, "package.json"), "w") as fh:
             fh.write('{"type":"module"}')
