@@ -155,6 +155,7 @@ def parse_args(argv=None):
     ap.add_argument("--pool", type=int, default=0, help="stream scheduler: live paths per state set (0 = library default)")
     ap.add_argument("--drain", type=int, default=-1, help="stream scheduler: drain iterations before the tail kernel (-1 = default)")
     ap.add_argument("--tail", type=int, default=-1, help="batch scheduler: the tail kernel takes over after this round (-1 adaptive, 0 never)")
+    ap.add_argument("--primary-form", type=int, default=0, help="k_wf_primary's traversal phase: 1 one ray per lane, 2 per-lane refill, 0 = measured and chosen by the library")
     ap.add_argument("--trace-budget", type=int, default=-1, help="steps before a starved trace wave suspends its rays (0 = never, -1 = default)")
     ap.add_argument("--overlap", type=int, default=-1, help="stream scheduler: 1 = primary on a second HIP stream, 0 = one stream (-1 = default)")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
@@ -352,6 +353,8 @@ def main():
     # that, not for the 128-tick maximum (216 bytes per pixel and tick: 57 GB at 1920x1080 x 128, 9 GB x 20)
     args.batch = max(1, min(args.batch, max(args.steps, args.warmup)))
     pt.set_pipeline(args.pipeline, args.batch)
+    if args.primary_form:
+        pt.set_primary_form(args.primary_form)
     if args.trace_budget >= 0:
         pt.set_trace_budget(args.trace_budget)
     if args.tail >= 0:
@@ -489,6 +492,17 @@ def l1_request_peak():
     return L1_PEAK_FALLBACK, {"source": "fallback constant (tools/microbench/l1_peak not built)"}
 
 
+def _prof_key(prof, name):
+    """Key of a kernel class in the stamped profile: the symbol itself, or (k_wf_primary<false, true, R>: two forms of one
+    class) the entry with the most launches that starts with it."""
+    base = name.replace("fspt::", "")
+    if base in prof["kernels"]:
+        return base
+    stem = base[:-1] if base.endswith(">") else base
+    cand = [k for k in prof["kernels"] if k.startswith(stem)]
+    return max(cand, key=lambda k: prof["kernels"][k].get("launches", 0)) if cand else None
+
+
 def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed, times, kernel_ms, launches, stages, build_s):
     import fspt_amd
     ref = count_work(pt, 1)   # reference algorithm (SURVEY 8d's S, L, H, E)
@@ -534,13 +548,14 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
             kj = {"kernel": name, "launches": n, "ms_per_step": round(ms / steps, 4), "avg_launch_ms": round(ms / max(1, n), 4),
                   "alg_bytes_per_step": round(alg[k]), "alg_GBps": round(gbps, 1), "bound": bound,
                   "traffic_bytes_per_launch": None, "traffic_GBps": None}
-            if prof and name.replace("fspt::", "") in prof["kernels"]:
-                tps = prof["kernels"][name.replace("fspt::", "")]["hbm_bytes_per_sample"]
+            pkey = _prof_key(prof, name) if prof else None
+            if pkey:
+                tps = prof["kernels"][pkey]["hbm_bytes_per_sample"]
                 tb = tps * spt * steps
                 kj["traffic_bytes_per_launch"] = round(tb / max(1, n))
                 kj["traffic_GBps"] = round(tb / (ms / 1e3) / 1e9, 1) if ms > 0 else None
-            if prof and name.replace("fspt::", "") in prof["kernels"]:
-                pk = prof["kernels"][name.replace("fspt::", "")]
+            if pkey:
+                pk = prof["kernels"][pkey]
                 if "ta_busy" in pk:  # stamped SQ / TA / TD counters of the same code (tools/collect_r04.py)
                     kj["counters"] = {c: pk[c] for c in ("ta_busy", "td_busy", "valu_active_share", "valu_lane_utilisation", "wait_share", "l2_hit") if c in pk}
             if k == "trace":
@@ -648,6 +663,8 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
                    "sharding": f"32x32 tiles round-robin over {n_gpus}", "world_size_seen": world_seen,
                    "exchange": (args.exchange if n_gpus > 1 else "none"), "pipeline": args.pipeline,
                    "batch_ticks": args.batch, "path_state_bytes": pt.path_state_bytes()[0],
+                   "primary_form": (dict(zip(("form", "ms_per_Msample"), (lambda f, ms: (f, [round(m * 1e6, 4) if m >= 0 else None for m in ms]))(*pt.primary_form(min(args.batch, args.steps)))))
+                                    if args.pipeline == "wavefront" else None),
                    "scene_build_s": round(build_s, 2), "source_sha": sha},
         "roofline": roofline,
     }

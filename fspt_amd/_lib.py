@@ -109,6 +109,8 @@ SIGNATURES = {
     "fspt_math_eval": (C.c_int, [C.c_int, C.c_int, _F, _F, C.c_uint32, _F]),
     "fspt_last_kernel_ms": (C.c_int, [_VP, _F, _U32]),
     "fspt_target_set_pipeline": (C.c_int, [_VP, C.c_int, C.c_uint32]),
+    "fspt_target_set_primary_form": (C.c_int, [_VP, C.c_int]),
+    "fspt_target_get_primary_form": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "fspt_target_set_pool": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_uint32, C.c_int]),
     "fspt_target_set_trace_budget": (C.c_int, [_VP, C.c_uint32]),
     "fspt_last_stage_ms": (C.c_int, [_VP, _F, _U32]),

@@ -124,6 +124,20 @@ struct fspt_target {
   bool cam_recorded = false;     // last_cam is valid and newer than the ray buffers' contents
   bool rays_injected = false;    // the ray buffers hold caller-supplied rays (fspt_set_rays): trace them as they are
   bool defer = true;             // fspt_target_set_deferred
+  // Primary-form tuner (batch scheduler): k_wf_primary has two forms of its traversal phase with identical results
+  // (fspt_kernels.hip).  Which is faster depends on the scene and the batch size, so the target measures: HIP events
+  // around the primary launch of every batch, read back without waiting at the start of a later batch; per batch size the
+  // form not yet measured is tried next, then the faster one is kept.
+  int primary_form = 0;      // fspt_target_set_primary_form: 0 measure and choose, 1 / 2 forced
+  // batch ticks -> [form] {best ms per sample so far (< 0: none), measurements taken}.  Every form is timed
+  // PRIM_TUNE_RUNS times, alternating, and judged by its best run: the first batch of a size runs cold (first touch of
+  // the path state, cold caches) and must not decide.
+  struct PrimStat { double best[3] = {-1.0, -1.0, -1.0}; uint32_t runs[3] = {0, 0, 0}; };
+  std::map<uint32_t, PrimStat> prim_ms;
+  hipEvent_t prim_ev[2] = {nullptr, nullptr};
+  bool prim_pending = false;
+  uint32_t prim_pending_form = 0, prim_pending_ticks = 0;
+  double prim_pending_samples = 0.0;
   int tail_round = -1;       // fspt_target_set_tail: -1 adaptive, 0 never, r >= 1 after round r
   float live_frac[80] = {};  // live paths after round r / slots of the batch, from the most recent finished batch
   bool live_known = false;
@@ -601,6 +615,8 @@ int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **
   if (e == hipSuccess) e = hipEventCreate(&t->ev0);
   if (e == hipSuccess) e = hipEventCreate(&t->ev1);
   if (e == hipSuccess) e = hipEventCreate(&t->ev_start);
+  if (e == hipSuccess) e = hipEventCreate(&t->prim_ev[0]);
+  if (e == hipSuccess) e = hipEventCreate(&t->prim_ev[1]);
   {
     fspt_target::WfLane &ln = t->wf;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
@@ -653,6 +669,7 @@ int fspt_target_destroy(fspt_target *t) {
     if (ln.stream) hipStreamDestroy(ln.stream);
   }
   if (t->ev_start) hipEventDestroy(t->ev_start);
+  for (hipEvent_t ev : t->prim_ev) if (ev) hipEventDestroy(ev);
   for (hipEvent_t e : t->ev_pool) hipEventDestroy(e);
   if (t->ev0) hipEventDestroy(t->ev0);
   if (t->ev1) hipEventDestroy(t->ev1);
@@ -861,6 +878,32 @@ static int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ti
   }
 }
 
+// Primary-form tuner (fspt_target::prim_ms): fold a finished measurement in (wait = block until it has finished) ...
+static const uint32_t PRIM_TUNE_RUNS = 2;
+static void prim_collect(fspt_target *t, bool wait) {
+  if (!t->prim_pending) return;
+  if (wait) { if (hipEventSynchronize(t->prim_ev[1]) != hipSuccess) return; }
+  else if (hipEventQuery(t->prim_ev[1]) != hipSuccess) return;
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, t->prim_ev[0], t->prim_ev[1]) == hipSuccess && t->prim_pending_samples > 0.0) {
+    fspt_target::PrimStat &st = t->prim_ms[t->prim_pending_ticks];
+    const double v = (double)ms / t->prim_pending_samples;
+    const uint32_t f = t->prim_pending_form;
+    if (st.best[f] < 0.0 || v < st.best[f]) st.best[f] = v;
+    st.runs[f]++;
+  }
+  t->prim_pending = false;
+}
+// ... and the form for the next batch of `ticks` ticks: the one with fewer runs while either has fewer than
+// PRIM_TUNE_RUNS (form 1 first), then the one whose best run was faster
+static uint32_t prim_choose(const fspt_target *t, uint32_t ticks) {
+  const auto it = t->prim_ms.find(ticks);
+  if (it == t->prim_ms.end()) return 1u;
+  const fspt_target::PrimStat &st = it->second;
+  if (st.runs[1] < PRIM_TUNE_RUNS || st.runs[2] < PRIM_TUNE_RUNS) return st.runs[2] < st.runs[1] ? 2u : 1u;
+  return st.best[2] < st.best[1] ? 2u : 1u;
+}
+
 static int ev_begin(fspt_target *t, int kind, hipStream_t stream) {
   if (t->ev_used >= EV_PAIRS) { t->ev_overflow = true; return -1; }
   if (t->ev_pool.size() < (size_t)(t->ev_used + 1) * 2) {
@@ -984,11 +1027,24 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     uint32_t tail = wf_tail_round(t, (uint64_t)nbt * work_total, last);
     if ((t->scene->has_dielectric || susp_on) && tail > last) tail = last; // refraction / a suspended traversal: paths may outlive `last` rounds
     auto set_round = [&](uint32_t r) { p.round = r; p.cnt_in = r - 1; p.cnt_out = r; p.set_in = (r - 1) & 1u; p.set_out = r & 1u; };
+    // the primary launch's form: forced, or measured (see fspt_target::prim_ms)
+    prim_collect(t, false);
+    uint32_t form = 1;
+    if (t->primary_form == 1 || t->primary_form == 2) form = (uint32_t)t->primary_form;
+    else if (t->count == 0) form = prim_choose(t, nbt); // (the counting variants are not what is timed: form 1 unless forced)
+    p.primary_r = form;
+    const bool time_primary = t->count == 0 && !t->prim_pending;
     bool prev_trace_suspends = false; // (no carry launch behind a trace launch that cannot have suspended anything)
     for (uint32_t r = 1; r <= last && r <= tail; ++r) {
       set_round(r);
       if (r > 1 && susp_on && prev_trace_suspends) { if ((rc = launch(fspt::WF_K_CARRY))) return rc; } // the paths trace(r-1) suspended move on
+      if (r == 1 && time_primary) HIP_TRY(hipEventRecord(t->prim_ev[0], st));
       if ((rc = launch(r == 1 ? fspt::WF_K_PRIMARY : fspt::WF_K_LOGIC))) return rc;
+      if (r == 1 && time_primary) {
+        HIP_TRY(hipEventRecord(t->prim_ev[1], st));
+        t->prim_pending = true; t->prim_pending_form = form; t->prim_pending_ticks = nbt;
+        t->prim_pending_samples = (double)nbt * (double)work_total;
+      }
       if (r < last && r < tail) {
         // the last trace launch of a batch lets its long rays finish: what it suspended the tail kernel would have to
         // trace again from the start
@@ -1138,6 +1194,7 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
   base.shard = tp.shard; base.n_shards = tp.n_shards; base.tile = tp.tile; base.tiles_x = tp.tiles_x; base.tiles_y = tp.tiles_y;
   base.n_owned_tiles = tp.n_owned_tiles;
   base.gen_rays = rays_from_buffers ? 0u : 1u;
+  base.primary_r = 1u; // (iterations of varying size: the plain form)
 
   // everything already queued on the target's stream (clear, ray upload, earlier renders) comes first
   HIP_TRY(hipEventRecord(t->ev_start, t->stream));
@@ -1549,6 +1606,26 @@ int fspt_target_set_trace_budget(fspt_target *t, uint32_t steps) {
   if (!t) { fspt_set_error("fspt_target_set_trace_budget: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
   t->susp_budget = steps;
+  return FSPT_OK;
+}
+
+int fspt_target_set_primary_form(fspt_target *t, int form) {
+  if (!t) { fspt_set_error("fspt_target_set_primary_form: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
+  if (form < 0 || form > 2) { fspt_set_error("fspt_target_set_primary_form: form must be 0 (measure and choose), 1 or 2"); return FSPT_E_INVALID; }
+  t->primary_form = form;
+  return FSPT_OK;
+}
+
+int fspt_target_get_primary_form(fspt_target *t, uint32_t batch_ticks, int *form, double ms_per_sample[2]) {
+  if (!t || !form) { fspt_set_error("fspt_target_get_primary_form: NULL argument"); return FSPT_E_INVALID; }
+  HIP_TRY(hipSetDevice(t->scene->device));
+  prim_collect(t, true);
+  double m1 = -1.0, m2 = -1.0;
+  const auto it = t->prim_ms.find(batch_ticks);
+  if (it != t->prim_ms.end()) { m1 = it->second.best[1]; m2 = it->second.best[2]; }
+  *form = (t->primary_form == 1 || t->primary_form == 2) ? t->primary_form : (int)prim_choose(t, batch_ticks);
+  if (ms_per_sample) { ms_per_sample[0] = m1; ms_per_sample[1] = m2; }
   return FSPT_OK;
 }
 

@@ -234,6 +234,7 @@ struct WfP {
   int *susp[2];         // suspended-traversal records: trace(i) writes susp[cnt_out & 1], resumes susp[cnt_in & 1]
   uint32_t susp_stride; // ints per record (WF_SUSP_HEADER + stack entries, a multiple of 4)
   uint32_t susp_budget; // traversal steps a wave walks on after its last refill before it suspends (0: never)
+  uint32_t primary_r;   // k_wf_primary: 1 = one traversal per lane, 2 = per-lane refill over 2 x 64 samples per wave (same results)
   uint32_t W, H;
   uint32_t vw, vh; // viewport, as in TraceP
   uint32_t work_total; // work indices per tick (owned tiles * tile^2)

@@ -224,6 +224,55 @@ FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 d
   hitB = hit;
 }
 
+// intersectScene (tracer.fs:366-404) for ONE ray per lane, in SLICES: the traversal state (node reference, stack depth,
+// t, hit; the stack itself is the lane's LDS column) is the caller's and survives the call.  A lane walks on from
+// where it stands until its ray is finished (cur == REF_SENTINEL) or it has done `budget` loop iterations in this call;
+// the call returns when no lane has anything left to do within its budget.  `anyhit`: stop at the first hit (NEE
+// shadow rays, tracer.fs:502).  Same node sequence and arithmetic as trace_rays, whatever the slicing.
+template <bool COUNT>
+FM_DEV void trace_slice(const DScene &S, int *stack, V3 o, V3 d, V3 inv /* 1 / d */, bool anyhit, int &cur, int &sp, float &t, int &hit,
+                        uint32_t budget, uint32_t &n /* loop iterations this lane has used of the budget */, Counters &cnt) {
+  const float4 *__restrict__ nodes = S.nodes;
+  const float *__restrict__ leaves = S.leaves;
+  const uint32_t leaf_size = S.leaf_size;
+  while (cur != REF_SENTINEL && n < budget) {
+    while (cur >= 0 && n < budget) {
+      if (COUNT) cnt.steps++;
+      ++n;
+      const float4 *nd = nodes + (size_t)cur * NODE_F4;
+      float4 n0 = nd[0], n1 = nd[1], n2 = nd[2];
+      const int2 n3 = node_refs(nd);
+      float tl, tr;
+      node_test(n0, n1, n2, o, inv, tl, tr);
+      bool hl = tl < t, hr = tr < t;
+      bool swap = tl > tr; // tracer.fs:384: right first only when strictly nearer
+      int nearRef = swap ? n3.y : n3.x;
+      int farRef = swap ? n3.x : n3.y;
+      if (hl && hr) {
+        stack[sp * WAVE] = farRef;
+        sp++;
+        cur = nearRef;
+      } else if (hl) {
+        cur = n3.x;
+      } else if (hr) {
+        cur = n3.y;
+      } else if (sp > 0) {
+        sp--;
+        cur = stack[sp * WAVE];
+      } else {
+        cur = REF_SENTINEL;
+      }
+    }
+    if (cur >= 0 || cur == REF_SENTINEL) break; // out of budget on an interior node / finished
+    if (COUNT) { cnt.steps++; cnt.leaves++; }
+    ++n;
+    process_leaf(leaves, leaf_size, ~cur, o, d, t, hit);
+    if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
+    else cur = REF_SENTINEL;
+    if (anyhit && hit != -1) cur = REF_SENTINEL;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Texture fetches (sampler state: main.js:170-180, 548-559)
 // ---------------------------------------------------------------------------
@@ -1351,10 +1400,24 @@ FM_DEV void flush_counters(const Counters &cnt, unsigned long long *counters, in
 #ifndef WF_PRIMARY_THREADS
 #define WF_PRIMARY_THREADS 256
 #endif
-template <bool COUNT, bool LDSTAB>
+// Two forms of the traversal phase, chosen per launch (WfP::primary_r; same samples, same values):
+//   R = 1  one traversal per lane (trace_rays): the wave waits for the longest of its 64 rays;
+//   R = 2  per-lane refill over the wave's 2 x 64 samples (below).
+// Which one is faster depends on the scene and the batch: on the 70 k-triangle scene a wave's rays (ticks of three
+// neighbouring pixels) have similar lengths and the plain loop's tighter code wins (primary 0.128 vs 0.134 ms per tick at
+// 20-tick batches, 0.28 vs 0.35 for a single tick); on the 1 M-triangle scene - sub-pixel triangles, ray lengths all over
+// the place - the refill wins (0.215 -> 0.180).  The host measures both on the target's own batches and keeps the faster
+// (fspt_api.cpp: primary-form tuner; profiles/r04/ab_primary_refill*.log).
+#define WF_PRIMARY_R_MAX 2
+#ifndef WF_PRIMARY_SLICE
+#define WF_PRIMARY_SLICE 8u // traversal steps between two looks at the wave's sample counter
+#endif
+template <bool COUNT, bool LDSTAB, int R>
 __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_primary(const WfP p) {
-  extern __shared__ int lds_dyn[]; // the waves' traversal stacks
+  extern __shared__ int lds_dyn[]; // the waves' traversal stacks | [tables] | [camera rays and hits of the block iteration]
   constexpr int NW = WF_PRIMARY_THREADS / WAVE;
+  constexpr uint32_t SPAN = (uint32_t)R * WF_PRIMARY_THREADS; // samples of a block iteration
+  static_assert(R >= 1 && R <= WF_PRIMARY_R_MAX, "k_wf_primary: R");
   __shared__ uint32_t s_off[2], s_base[2];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
@@ -1375,8 +1438,9 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
     ring0 = (uint32_t)(((unsigned long long)u0 * unit_slots) % p.ring_slots);
   }
   if (threadIdx.x < 2) s_off[threadIdx.x] = 0u;
+  int *lds_tab = lds_dyn + (size_t)NW * S.stack_n * WAVE;
   if (LDSTAB) { // behind the stacks
-    const LdsTables tb = stage_tables(lds_dyn + (size_t)NW * S.stack_n * WAVE, p.scene, p.rb_trace, p.n_batch, WF_PRIMARY_THREADS);
+    const LdsTables tb = stage_tables(lds_tab, p.scene, p.rb_trace, p.n_batch, WF_PRIMARY_THREADS);
     S.tex_sets = tb.sets;
     S.bins = tb.bins;
     s_rb = tb.rb;
@@ -1384,34 +1448,117 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
   __syncthreads();
   Counters cnt = {0, 0, 0, 0, 0, 0};
   int *stack = lds_dyn + (size_t)wave * S.stack_n * WAVE + lane;
+  // R > 1: camera ray + hit of every sample of the block iteration: 8 floats each (o.xyz, t | d.xyz, hit), in a piece of
+  // LDS per wave that only this wave touches
+  float4 *s_ray = reinterpret_cast<float4 *>(lds_tab + (LDSTAB ? wf_table_bytes(S.n_tex_sets, S.n_bins, p.n_batch) / 4u : 0u));
 
   uint32_t par = 0;
-  for (uint32_t base = blockIdx.x * WF_PRIMARY_THREADS; base < n_in; base += gridDim.x * WF_PRIMARY_THREADS, par ^= 1u) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t g = first + i;
-    uint32_t fx = 0, fy = 0;
-    const bool valid = i < n_in && work_to_pixel(p, wf_work_index(p, g), fx, fy);
-    V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
-    float tB = MAX_T;
-    int hitB = -1;
-    if (valid) {
-      if (p.gen_rays) {
-        camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[g % p.n_batch], o, d);
-      } else {
-        float4 po = p.ray_pos[fy * p.W + fx], di = p.ray_dir[fy * p.W + fx];
-        o = v3(po.x, po.y, po.z);
-        d = v3(di.x, di.y, di.z);
+  for (uint32_t base = blockIdx.x * SPAN; base < n_in; base += gridDim.x * SPAN, par ^= 1u) {
+    unsigned long long m_surv[R];
+    // R == 1: this thread's one sample, in registers
+    V3 o1 = v3(0.0f, 0.0f, 0.0f), d1 = v3(0.0f, 0.0f, 1.0f);
+    float t1 = MAX_T;
+    int hit1 = -1;
+    bool valid1 = false;
+    if constexpr (R == 1) {
+      const uint32_t i = base + threadIdx.x;
+      const uint32_t g = first + i;
+      uint32_t fx = 0, fy = 0;
+      valid1 = i < n_in && work_to_pixel(p, wf_work_index(p, g), fx, fy);
+      if (valid1) {
+        if (p.gen_rays) {
+          camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[g % p.n_batch], o1, d1);
+        } else {
+          float4 po = p.ray_pos[fy * p.W + fx], di = p.ray_dir[fy * p.W + fx];
+          o1 = v3(po.x, po.y, po.z);
+          d1 = v3(di.x, di.y, di.z);
+        }
+        if (COUNT) cnt.samples++;
+        int hitA;
+        trace_rays<COUNT, false>(S, stack, o1, false, d1, d1, hitA, t1, hit1, cnt);
       }
-      if (COUNT) cnt.samples++;
-      int hitA;
-      trace_rays<COUNT, false>(S, stack, o, false, d, d, hitA, tB, hitB, cnt);
+    } else {
+      // ---- T: the wave's R x 64 samples of this block iteration, with per-lane refill ---------------------------------
+      // A lane whose ray is done writes t and hit to LDS and takes the wave's next sample, so the wave is through when
+      // the WORK is through, not when its longest ray is.  The wave then shades the same R x 64 samples (lane l: samples
+      // l, l + 64, ... of the wave's range, whoever traced them): ray and hit wait in a piece of LDS only this wave
+      // touches - no barrier between the two phases, and a sample's ray is read right before it is shaded.  Slot ids
+      // and every value are those of the plain form; only the ORDER of the survivors in the state set differs.
+      const uint32_t w_lo = base + (uint32_t)wave * (R * WAVE), w_hi = min(w_lo + (uint32_t)(R * WAVE), n_in);
+      // the wave's camera rays first, all lanes at work (camera.fs main: 150 instructions a lane should not run alone)
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const uint32_t loc = (uint32_t)wave * (R * WAVE) + (uint32_t)u * WAVE + (uint32_t)lane;
+        const uint32_t i = base + loc, g = first + i;
+        uint32_t fx = 0, fy = 0;
+        V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
+        int h = -2; // -2: the sample does not exist (outside the viewport / beyond the launch)
+        if (i < n_in && work_to_pixel(p, wf_work_index(p, g), fx, fy)) {
+          if (p.gen_rays) {
+            camera_ray(fx, fy, p.W, p.H, p.cam, p.rb_cam[g % p.n_batch], o, d);
+          } else {
+            const float4 po = p.ray_pos[fy * p.W + fx], di = p.ray_dir[fy * p.W + fx];
+            o = v3(po.x, po.y, po.z);
+            d = v3(di.x, di.y, di.z);
+          }
+          h = -1;
+          if (COUNT) { cnt.samples++; cnt.rays++; }
+        }
+        s_ray[2u * loc] = make_float4(o.x, o.y, o.z, MAX_T);
+        s_ray[2u * loc + 1u] = make_float4(d.x, d.y, d.z, __int_as_float(h));
+      }
+      uint32_t next = min(w_lo, w_hi); // (wave-uniform)
+      bool have = false;
+      uint32_t my_loc = 0;
+      V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f), inv = v3(0.0f, 0.0f, 0.0f);
+      int cur = REF_SENTINEL, sp = 0, hit = -1;
+      float t = MAX_T;
+      while (true) {
+        // finished rays -> LDS (t and hit: the ray is there already)
+        if (have && cur == REF_SENTINEL) {
+          s_ray[2u * my_loc].w = t;
+          s_ray[2u * my_loc + 1u].w = __int_as_float(hit);
+          have = false;
+        }
+        // refill: a free lane takes the wave's next sample
+        const unsigned long long need = __ballot(!have);
+        const uint32_t avail = w_hi - next;
+        if (avail != 0u && need != 0ull) {
+          const uint32_t rank = lane_rank(need), take = min((uint32_t)__popcll(need), avail);
+          if (!have && rank < take) {
+            my_loc = next + rank - base;
+            const float4 ra = s_ray[2u * my_loc], rb = s_ray[2u * my_loc + 1u];
+            if (__float_as_int(rb.w) != -2) { // (a sample that does not exist stays as it is)
+              o = v3(ra.x, ra.y, ra.z); d = v3(rb.x, rb.y, rb.z);
+              inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+              have = true;
+              t = MAX_T; hit = -1; cur = S.root_ref; sp = 0;
+            }
+          }
+          next += take;
+        }
+        if (__ballot(have) == 0ull) { if (next >= w_hi) break; else continue; }
+        uint32_t used = 0;
+        trace_slice<COUNT>(S, stack, o, d, inv, false, cur, sp, t, hit, WF_PRIMARY_SLICE, used, cnt);
+      }
     }
     // advance_path: a hit is shaded (and the path lives on) unless the bounce budget is already used up
-    const unsigned long long m_surv = __ballot(valid && hitB != -1 && p.num_bounces > 0u);
+    uint32_t n_mine = 0;
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if constexpr (R == 1) {
+        m_surv[u] = __ballot(valid1 && hit1 != -1 && p.num_bounces > 0u);
+      } else {
+        const uint32_t loc = (uint32_t)wave * (R * WAVE) + (uint32_t)u * WAVE + (uint32_t)lane;
+        const int h = base + loc < n_in ? __float_as_int(s_ray[2u * loc + 1u].w) : -2; // -2: no such sample
+        m_surv[u] = __ballot(h >= 0 && p.num_bounces > 0u);
+      }
+      n_mine += (uint32_t)__popcll(m_surv[u]);
+    }
     // block-aggregated reservation: the waves' offsets from an LDS counter, ONE global atomic per block iteration.
     // The two LDS words alternate between iterations (parity), so one barrier pair per iteration is enough.
     uint32_t my_off = 0;
-    if (lane == 0) my_off = atomicAdd(&s_off[par], (uint32_t)__popcll(m_surv));
+    if (lane == 0) my_off = atomicAdd(&s_off[par], n_mine);
     my_off = __builtin_amdgcn_readfirstlane(my_off);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1420,22 +1567,43 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
       s_off[par ^ 1u] = 0u;
     }
     __syncthreads();
-    if (valid) {
-      uint32_t slot = ring0 + i; // < 2 * ring_slots: a launch is shorter than the ring
-      if (slot >= p.ring_slots) slot -= p.ring_slots;
-      Path ps;
-      ps.ro = o; ps.rd = d;
-      ps.thr = v3(1.0f, 1.0f, 1.0f);
-      ps.color = v3(0.0f, 0.0f, 0.0f);
-      ps.envDir = v3(0.0f, 0.0f, 0.0f);
-      ps.pend = v3(0.0f, 0.0f, 0.0f);
-      ps.wx = ps.wy = 0.0f;
-      ps.bounce = 0; ps.iters = 0; ps.pix = 0; ps.lag = 0u;
-      ps.hasShadow = false; ps.primary = true;
-      const uint32_t j = (first + i) % p.n_batch;
-      const bool finished = advance_path<COUNT>(S, ps, -1, tB, hitB, s_rb[j], p.env_theta, p.num_bounces, cnt);
-      if (finished) st3(p.fin + 3 * (size_t)slot, ps.color);
-      else store_path(out, s_base[par] + my_off + lane_rank(m_surv), ps, slot);
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      uint32_t i;
+      bool valid;
+      V3 ro, rd;
+      float tB;
+      int hitB;
+      if constexpr (R == 1) {
+        i = base + threadIdx.x;
+        valid = valid1; ro = o1; rd = d1; tB = t1; hitB = hit1;
+      } else {
+        const uint32_t loc = (uint32_t)wave * (R * WAVE) + (uint32_t)u * WAVE + (uint32_t)lane;
+        i = base + loc;
+        const float4 ra = s_ray[2u * loc], rb = s_ray[2u * loc + 1u];
+        valid = i < n_in && __float_as_int(rb.w) != -2;
+        ro = v3(ra.x, ra.y, ra.z); rd = v3(rb.x, rb.y, rb.z);
+        tB = ra.w;
+        hitB = __float_as_int(rb.w);
+      }
+      if (valid) {
+        uint32_t slot = ring0 + i; // < 2 * ring_slots: a launch is shorter than the ring
+        if (slot >= p.ring_slots) slot -= p.ring_slots;
+        Path ps;
+        ps.ro = ro; ps.rd = rd;
+        ps.thr = v3(1.0f, 1.0f, 1.0f);
+        ps.color = v3(0.0f, 0.0f, 0.0f);
+        ps.envDir = v3(0.0f, 0.0f, 0.0f);
+        ps.pend = v3(0.0f, 0.0f, 0.0f);
+        ps.wx = ps.wy = 0.0f;
+        ps.bounce = 0; ps.iters = 0; ps.pix = 0; ps.lag = 0u;
+        ps.hasShadow = false; ps.primary = true;
+        const uint32_t j = (first + i) % p.n_batch;
+        const bool finished = advance_path<COUNT>(S, ps, -1, tB, hitB, s_rb[j], p.env_theta, p.num_bounces, cnt);
+        if (finished) st3(p.fin + 3 * (size_t)slot, ps.color);
+        else store_path(out, s_base[par] + my_off + lane_rank(m_surv[u]), ps, slot);
+      }
+      my_off += (uint32_t)__popcll(m_surv[u]);
     }
   }
   flush_counters<COUNT>(cnt, p.counters, 0, lane);
@@ -1538,56 +1706,6 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
     __syncthreads(); // s_list / s_total are rewritten by the next iteration
   }
   flush_counters<COUNT>(cnt, p.counters, 4, lane);
-}
-
-// intersectScene (tracer.fs:366-404) for ONE ray per lane, in SLICES: the traversal state (node reference, stack depth,
-// t, hit; the stack itself is the lane's LDS column) is the caller's and survives the call.  A lane walks on from
-// where it stands until its ray is finished (cur == REF_SENTINEL) or it has done `budget` loop iterations in this call;
-// the call returns when no lane has anything left to do within its budget.  `anyhit`: stop at the first hit (NEE
-// shadow rays, tracer.fs:502).  Same node sequence and arithmetic as trace_rays, whatever the slicing.
-template <bool COUNT>
-FM_DEV void trace_slice(const DScene &S, int *stack, V3 o, V3 d, bool anyhit, int &cur, int &sp, float &t, int &hit, uint32_t budget,
-                        uint32_t &n /* loop iterations this lane has used of the budget */, Counters &cnt) {
-  const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const float4 *__restrict__ nodes = S.nodes;
-  const float *__restrict__ leaves = S.leaves;
-  const uint32_t leaf_size = S.leaf_size;
-  while (cur != REF_SENTINEL && n < budget) {
-    while (cur >= 0 && n < budget) {
-      if (COUNT) cnt.steps++;
-      ++n;
-      const float4 *nd = nodes + (size_t)cur * NODE_F4;
-      float4 n0 = nd[0], n1 = nd[1], n2 = nd[2];
-      const int2 n3 = node_refs(nd);
-      float tl, tr;
-      node_test(n0, n1, n2, o, inv, tl, tr);
-      bool hl = tl < t, hr = tr < t;
-      bool swap = tl > tr; // tracer.fs:384: right first only when strictly nearer
-      int nearRef = swap ? n3.y : n3.x;
-      int farRef = swap ? n3.x : n3.y;
-      if (hl && hr) {
-        stack[sp * WAVE] = farRef;
-        sp++;
-        cur = nearRef;
-      } else if (hl) {
-        cur = n3.x;
-      } else if (hr) {
-        cur = n3.y;
-      } else if (sp > 0) {
-        sp--;
-        cur = stack[sp * WAVE];
-      } else {
-        cur = REF_SENTINEL;
-      }
-    }
-    if (cur >= 0 || cur == REF_SENTINEL) break; // out of budget on an interior node / finished
-    if (COUNT) { cnt.steps++; cnt.leaves++; }
-    ++n;
-    process_leaf(leaves, leaf_size, ~cur, o, d, t, hit);
-    if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
-    else cur = REF_SENTINEL;
-    if (anyhit && hit != -1) cur = REF_SENTINEL;
-  }
 }
 
 FM_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src, WAVE), __shfl(v.y, src, WAVE), __shfl(v.z, src, WAVE)); }
@@ -1757,7 +1875,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
     }
     if (r_state != RAY_GOING) r_cur = REF_SENTINEL;
     uint32_t used = 0;
-    trace_slice<COUNT>(S, stack, o, d, ANYHIT && !is_main, r_cur, r_sp, r_t, r_hit, WF_TAIL_SLICE, used, cnt);
+    trace_slice<COUNT>(S, stack, o, d, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), ANYHIT && !is_main, r_cur, r_sp, r_t, r_hit, WF_TAIL_SLICE,
+                       used, cnt);
     if (r_state == RAY_GOING && r_cur == REF_SENTINEL) r_state = RAY_DONE;
     // a pair is ready when its extension ray is done and its shadow ray is done or was never cast
     const int st_other = __shfl(r_state, lane | 1, WAVE);
@@ -2054,7 +2173,7 @@ hipError_t launch_trace(const TraceP &p, bool gen_rays, bool count, int num_cus,
 
 size_t wf_max_stack_entries() {
   // the largest LDS user per stack entry is the primary launch: 8 waves x 256 B per entry next to the staged tables
-  const size_t lds_cu = 160u * 1024u, tables = WF_LDS_TABLE_MAX;
+  const size_t lds_cu = 160u * 1024u, tables = WF_LDS_TABLE_MAX + (size_t)WF_PRIMARY_R_MAX * WF_PRIMARY_THREADS * 32u;
   return (lds_cu - tables) / ((WF_PRIMARY_THREADS / WAVE) * WAVE * sizeof(int));
 }
 
@@ -2121,18 +2240,23 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
     // resident blocks per CU at WF_LOGIC_WAVES waves per SIMD (4 SIMDs): 2 blocks of 512 threads at 4 waves; twice that many in flight
     const uint32_t threads = kernel == WF_K_PRIMARY ? (uint32_t)WF_PRIMARY_THREADS : (uint32_t)WF_LOGIC_THREADS;
     const uint32_t blocks_per_cu = 2u * ((uint32_t)WF_LOGIC_WAVES * 4u * WAVE / threads);
-    uint32_t grid = min((total + threads - 1) / threads, (uint32_t)num_cus * blocks_per_cu);
+    const uint32_t prim_r = p.primary_r >= 2u ? 2u : 1u;
+    const uint32_t per_block = kernel == WF_K_PRIMARY ? threads * prim_r : threads;
+    uint32_t grid = min((total + per_block - 1) / per_block, (uint32_t)num_cus * blocks_per_cu);
     const uint32_t tab_bytes = wf_table_bytes(p.scene.n_tex_sets, p.scene.n_bins, p.n_batch);
     const bool tab = WF_LOGIC_LDSTAB && tab_bytes <= WF_LDS_TABLE_MAX;
     if (kernel == WF_K_PRIMARY) {
-      const size_t dyn = (size_t)(WF_PRIMARY_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int) + (tab ? tab_bytes : 0u);
-#define FSPT_LAUNCH_PRIMARY(C, T)                                                                          \
+      const size_t dyn = (size_t)(WF_PRIMARY_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int) + (tab ? tab_bytes : 0u) +
+                         (prim_r > 1u ? (size_t)prim_r * WF_PRIMARY_THREADS * 32u : 0u); // + ray and hit of every sample of a block iteration
+#define FSPT_LAUNCH_PRIMARY(C, T, RR)                                                                      \
       do {                                                                                                   \
-        if ((e = allow_lds(k_wf_primary<C, T>, dyn)) != hipSuccess) return e;                                \
-        hipLaunchKernelGGL((k_wf_primary<C, T>), dim3(grid), dim3(WF_PRIMARY_THREADS), dyn, stream, p);      \
+        if ((e = allow_lds(k_wf_primary<C, T, RR>, dyn)) != hipSuccess) return e;                            \
+        hipLaunchKernelGGL((k_wf_primary<C, T, RR>), dim3(grid), dim3(WF_PRIMARY_THREADS), dyn, stream, p);  \
       } while (0)
-      if (count) { if (tab) FSPT_LAUNCH_PRIMARY(true, true); else FSPT_LAUNCH_PRIMARY(true, false); }
-      else { if (tab) FSPT_LAUNCH_PRIMARY(false, true); else FSPT_LAUNCH_PRIMARY(false, false); }
+#define FSPT_LAUNCH_PRIMARY_R(C, T) do { if (prim_r > 1u) FSPT_LAUNCH_PRIMARY(C, T, 2); else FSPT_LAUNCH_PRIMARY(C, T, 1); } while (0)
+      if (count) { if (tab) FSPT_LAUNCH_PRIMARY_R(true, true); else FSPT_LAUNCH_PRIMARY_R(true, false); }
+      else { if (tab) FSPT_LAUNCH_PRIMARY_R(false, true); else FSPT_LAUNCH_PRIMARY_R(false, false); }
+#undef FSPT_LAUNCH_PRIMARY_R
 #undef FSPT_LAUNCH_PRIMARY
     } else {
       const size_t dyn = tab ? tab_bytes : 0u;

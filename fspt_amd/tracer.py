@@ -125,6 +125,18 @@ class PathTracer:
         fspt_target_set_pool."""
         L.check(L.lib().fspt_target_set_pool(self._t, int(paths), int(drain), int(max_iterations), int(overlap)))
 
+    def set_primary_form(self, form=0):
+        """k_wf_primary's traversal phase: 1 one ray per lane, 2 per-lane refill, 0 (default) measured and chosen by the
+        library per batch size (include/fspt_tuning.h)."""
+        L.check(L.lib().fspt_target_set_primary_form(self._t, int(form)))
+
+    def primary_form(self, batch_ticks):
+        """(form the next batch of that size uses, [ms per sample of form 1, form 2] measured so far or -1)."""
+        f = C.c_int()
+        ms = (C.c_double * 2)()
+        L.check(L.lib().fspt_target_get_primary_form(self._t, int(batch_ticks), C.byref(f), ms))
+        return int(f.value), [float(ms[0]), float(ms[1])]
+
     def set_trace_budget(self, steps):
         """Traversal steps a starved trace wave walks on before it suspends its rays (0 = never; include/fspt_tuning.h)."""
         L.check(L.lib().fspt_target_set_trace_budget(self._t, int(steps)))

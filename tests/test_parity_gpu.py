@@ -888,6 +888,74 @@ def test_suspended_traversals_deep_stack_and_refraction(small_scene, pipeline):
         pt.close()
 
 
+@pytest.mark.parametrize("form", [1, 2, 0])
+def test_primary_launch_forms_bitwise(form, small_scene, camera):
+    """k_wf_primary's two forms of the traversal phase (include/fspt_tuning.h: fspt_target_set_primary_form) - one ray per
+    lane, or per-lane refill over 2 x 64 samples per wave with rays and hits parked in LDS - and the tuner that times both
+    and keeps the faster (0): same frame as the oracle, work counters included, on a ragged sharded frame with a viewport
+    (samples that do not exist), through both entry points, over several batches of two sizes, with injected rays, on a
+    63-deep tree and on the refractive scene."""
+    from test_goldens import scene_from_golden
+    W, H = 150, 91
+    want = np.zeros((H, W, 4), np.float32)
+    oc = O.OCounters()
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 6, 0, 11, 5, want,
+             counters=oc, shard=1, n_shards=3, tile=16)
+    for counting in (False, True):
+        pt = make_pt(small_scene, W, H, camera, 6, "wavefront", 4)
+        pt.set_primary_form(form)
+        pt.set_shard(1, 3, 16)
+        if counting:
+            pt.enable_counters(True)
+        pt.clear()
+        pt.seed(5)
+        pt.render(4); pt.sync(); pt.render(4)   # two batches of 4: the tuner times form 1, then form 2 ...
+        pt.tick(); pt.tick(); pt.tick()         # the two-call form: one more batch (of 3) at the read-out
+        assert np.array_equal(pt.readRadiance(), want), (form, counting)
+        if counting:
+            assert pt.counters() == oc.as_dict()
+        f, ms = pt.primary_form(4)
+        assert f == (form or f) and f in (1, 2)
+        if form == 0 and not counting:
+            assert ms[0] > 0 and ms[1] > 0 and f == 1   # ... both forms were timed once; each gets a second run (form 1 first)
+            pt.render(4); pt.sync(); pt.render(4); pt.sync()
+            f, ms2 = pt.primary_form(4)
+            assert ms2[0] <= ms[0] and ms2[1] <= ms[1] and f == (2 if ms2[1] < ms2[0] else 1)  # best runs decide
+        pt.close()
+    # a viewport: most samples of the launch do not exist
+    pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 2)
+    pt.set_primary_form(form)
+    pt.set_viewport(37, 22)
+    pt.seed(8)
+    pt.render(4)
+    got = pt.readRadiance()
+    pt.close()
+    full = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4, 0, 4, 8, full)
+    assert np.array_equal(got[:22, :37], full[:22, :37]) and not got[22:].any() and not got[:, 37:].any()
+    # injected rays (the ray buffers instead of camera.fs), a 63-deep chain, refraction
+    arrays = chain_scene(64, small_scene)
+    cam = dict(P=[64 + 2.5, 0.05, 0.1], I=[-1.0, -0.01, -0.02], fov_scale=0.5, env_theta=1.66, focal_depth=2.0, aperture=0.02, lens=[0.5, 0.02])
+    for arr, c, nb in ((arrays, cam, 3),
+                       (scene_from_golden("variant"), dict(P=[0.3, 1.2, 3.4], I=[-0.05, -0.3, -0.95], fov_scale=0.5, env_theta=1.66,
+                                                          focal_depth=2.0, aperture=0.02, lens=[0.5, 0.02]), 4)):
+        w2, h2 = 72, 40
+        want2 = np.zeros((h2, w2, 4), np.float32)
+        O.render(arr, w2, h2, c["P"], c["I"], c["fov_scale"], c["lens"], c["env_theta"], nb, 0, 4, 9, want2)
+        pt = make_pt(arr, w2, h2, c, nb, "wavefront", 2)
+        pt.set_primary_form(form)
+        pt.seed(9)
+        pt.render(4)
+        assert np.array_equal(pt.readRadiance(), want2), form
+        pos, d = O.camera(w2, h2, c["P"], c["I"], c["fov_scale"], c["lens"], 321.0)
+        acc = pt.readRadiance().copy()
+        O.trace(arr, w2, h2, pos, d, 4, 77.0, c["env_theta"], nb, acc)
+        pt.setRays(pos, d)
+        pt.drawTracer(4, 77.0)
+        assert np.array_equal(pt.readRadiance(), acc), form
+        pt.close()
+
+
 def test_bvh_deeper_than_the_reference_stack_is_rejected():
     """tracer.fs:368 `int stack[64]`: a (degenerate, chain-shaped) tree deeper than 63 levels is refused."""
     import ctypes as C
