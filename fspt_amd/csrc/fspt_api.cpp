@@ -129,9 +129,9 @@ struct fspt_target {
   // around the primary launch of every batch, read back without waiting at the start of a later batch; per batch size the
   // form not yet measured is tried next, then the faster one is kept.
   int primary_form = 0;      // fspt_target_set_primary_form: 0 measure and choose, 1 / 2 forced
-  // batch ticks -> [form] {best ms per sample so far (< 0: none), measurements taken}.  Every form is timed
-  // PRIM_TUNE_RUNS times, alternating, and judged by its best run: the first batch of a size runs cold (first touch of
-  // the path state, cold caches) and must not decide.
+  // batch ticks -> [form] {best ms per sample so far (< 0: none), measurements taken}.  Forms are judged by their best
+  // run, and the first batch of a size - always form 1 - runs cold (4-8 % slower: first use of that much path state, cold
+  // caches) and must not decide on its own: see prim_choose.
   struct PrimStat { double best[3] = {-1.0, -1.0, -1.0}; uint32_t runs[3] = {0, 0, 0}; };
   std::map<uint32_t, PrimStat> prim_ms;
   hipEvent_t prim_ev[2] = {nullptr, nullptr};
@@ -879,7 +879,6 @@ static int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ti
 }
 
 // Primary-form tuner (fspt_target::prim_ms): fold a finished measurement in (wait = block until it has finished) ...
-static const uint32_t PRIM_TUNE_RUNS = 2;
 static void prim_collect(fspt_target *t, bool wait) {
   if (!t->prim_pending) return;
   if (wait) { if (hipEventSynchronize(t->prim_ev[1]) != hipSuccess) return; }
@@ -894,14 +893,18 @@ static void prim_collect(fspt_target *t, bool wait) {
   }
   t->prim_pending = false;
 }
-// ... and the form for the next batch of `ticks` ticks: the one with fewer runs while either has fewer than
-// PRIM_TUNE_RUNS (form 1 first), then the one whose best run was faster
+// ... and the form for the next batch of `ticks` ticks.  Batches 1, 2 of a size: form 1 (cold), form 2.  If form 2 was
+// slower than even the cold run of form 1 the matter is settled; otherwise form 1 gets its warm run (batch 3) and the
+// better best-run wins.  At most three batches of a size are spent on this.
 static uint32_t prim_choose(const fspt_target *t, uint32_t ticks) {
   const auto it = t->prim_ms.find(ticks);
   if (it == t->prim_ms.end()) return 1u;
   const fspt_target::PrimStat &st = it->second;
-  if (st.runs[1] < PRIM_TUNE_RUNS || st.runs[2] < PRIM_TUNE_RUNS) return st.runs[2] < st.runs[1] ? 2u : 1u;
-  return st.best[2] < st.best[1] ? 2u : 1u;
+  if (st.runs[1] == 0) return 1u;
+  if (st.runs[2] == 0) return 2u;
+  if (st.best[2] >= st.best[1]) return 1u;
+  if (st.runs[1] < 2) return 1u;
+  return 2u;
 }
 
 static int ev_begin(fspt_target *t, int kind, hipStream_t stream) {

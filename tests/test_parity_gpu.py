@@ -917,10 +917,14 @@ def test_primary_launch_forms_bitwise(form, small_scene, camera):
         f, ms = pt.primary_form(4)
         assert f == (form or f) and f in (1, 2)
         if form == 0 and not counting:
-            assert ms[0] > 0 and ms[1] > 0 and f == 1   # ... both forms were timed once; each gets a second run (form 1 first)
-            pt.render(4); pt.sync(); pt.render(4); pt.sync()
-            f, ms2 = pt.primary_form(4)
-            assert ms2[0] <= ms[0] and ms2[1] <= ms[1] and f == (2 if ms2[1] < ms2[0] else 1)  # best runs decide
+            assert ms[0] > 0 and ms[1] > 0      # ... both forms were timed once (form 1 cold)
+            if ms[1] >= ms[0]:
+                assert f == 1                   # form 2 slower than even the cold form 1: settled
+            else:
+                assert f == 1                   # form 1 gets its warm run first
+                pt.render(4); pt.sync()
+                f, ms2 = pt.primary_form(4)
+                assert ms2[0] <= ms[0] and ms2[1] == ms[1] and f == (2 if ms2[1] < ms2[0] else 1)  # best runs decide
         pt.close()
     # a viewport: most samples of the launch do not exist
     pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 2)
