@@ -893,18 +893,19 @@ static void prim_collect(fspt_target *t, bool wait) {
   }
   t->prim_pending = false;
 }
-// ... and the form for the next batch of `ticks` ticks.  Batches 1, 2 of a size: form 1 (cold), form 2.  If form 2 was
-// slower than even the cold run of form 1 the matter is settled; otherwise form 1 gets its warm run (batch 3) and the
-// better best-run wins.  At most three batches of a size are spent on this.
+// ... and the form for the next batch of `ticks` ticks.  Batches 1-3 of a size: form 1 (cold), form 2, form 1 (warm).
+// Form 2 then gets a second run (batch 4) unless its first was more than 10 % behind - one disturbed measurement (a clock
+// ramp, another process on the host) must not decide - and the better best-run wins.  At most four batches of a size are
+// spent on this.
 static uint32_t prim_choose(const fspt_target *t, uint32_t ticks) {
   const auto it = t->prim_ms.find(ticks);
   if (it == t->prim_ms.end()) return 1u;
   const fspt_target::PrimStat &st = it->second;
   if (st.runs[1] == 0) return 1u;
   if (st.runs[2] == 0) return 2u;
-  if (st.best[2] >= st.best[1]) return 1u;
   if (st.runs[1] < 2) return 1u;
-  return 2u;
+  if (st.runs[2] < 2 && st.best[2] < st.best[1] * 1.10) return 2u;
+  return st.best[2] < st.best[1] ? 2u : 1u;
 }
 
 static int ev_begin(fspt_target *t, int kind, hipStream_t stream) {

@@ -924,7 +924,12 @@ def test_primary_launch_forms_bitwise(form, small_scene, camera):
                 assert f == 1                   # form 1 gets its warm run first
                 pt.render(4); pt.sync()
                 f, ms2 = pt.primary_form(4)
-                assert ms2[0] <= ms[0] and ms2[1] == ms[1] and f == (2 if ms2[1] < ms2[0] else 1)  # best runs decide
+                assert ms2[0] <= ms[0] and ms2[1] == ms[1]
+                if ms2[1] < ms2[0] * 1.10:
+                    assert f == 2               # close: form 2 gets a second run too
+                    pt.render(4); pt.sync()
+                    f, ms2 = pt.primary_form(4)
+                assert f == (2 if ms2[1] < ms2[0] else 1)  # best runs decide
         pt.close()
     # a viewport: most samples of the launch do not exist
     pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 2)
