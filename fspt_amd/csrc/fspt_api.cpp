@@ -126,12 +126,11 @@ struct fspt_target {
   bool defer = true;             // fspt_target_set_deferred
   // Primary-form tuner (batch scheduler): k_wf_primary has two forms of its traversal phase with identical results
   // (fspt_kernels.hip).  Which is faster depends on the scene and the batch size, so the target measures: HIP events
-  // around the primary launch of every batch, read back without waiting at the start of a later batch; per batch size the
-  // form not yet measured is tried next, then the faster one is kept.
+  // around the primary launch of a batch, read back without waiting at the start of a later batch.  Per batch size: the
+  // first batch runs the form the scene's size suggests (X), the second the other one (Y), and as a rule that settles it
+  // - see prim_choose for the one case that takes a third batch.
   int primary_form = 0;      // fspt_target_set_primary_form: 0 measure and choose, 1 / 2 forced
-  // batch ticks -> [form] {best ms per sample so far (< 0: none), measurements taken}.  Forms are judged by their best
-  // run, and the first batch of a size - always form 1 - runs cold (4-8 % slower: first use of that much path state, cold
-  // caches) and must not decide on its own: see prim_choose.
+  // batch ticks -> [form] {best ms per sample so far (< 0: none), measurements taken}
   struct PrimStat { double best[3] = {-1.0, -1.0, -1.0}; uint32_t runs[3] = {0, 0, 0}; };
   std::map<uint32_t, PrimStat> prim_ms;
   hipEvent_t prim_ev[2] = {nullptr, nullptr};
@@ -893,19 +892,25 @@ static void prim_collect(fspt_target *t, bool wait) {
   }
   t->prim_pending = false;
 }
-// ... and the form for the next batch of `ticks` ticks.  Batches 1-3 of a size: form 1 (cold), form 2, form 1 (warm).
-// Form 2 then gets a second run (batch 4) unless its first was more than 10 % behind - one disturbed measurement (a clock
-// ramp, another process on the host) must not decide - and the better best-run wins.  At most four batches of a size are
-// spent on this.
+// ... and the form for the next batch of `ticks` ticks.  X = the form the scene's size suggests (per-lane refill pays
+// where ray lengths scatter: sub-pixel triangles), Y the other one.  Batch 1 of a size runs X - cold: a size's first batch
+// is 4-8 % slower (first use of that much path state, clocks, caches) - batch 2 runs Y.  If X won although it ran cold,
+// or lost by more than a cold start explains (12 %), the matter is settled after those two batches; otherwise X gets a
+// warm run (batch 3) and the better best-run wins.  (Forms are measured on whole batches: timed on halves of a batch
+// the refill form - 512 samples per block iteration - looked 10-20 % worse than it is, profiles/r04/primary_form_tuner_split.log.)
 static uint32_t prim_choose(const fspt_target *t, uint32_t ticks) {
+  const uint32_t X = t->scene->n_tris >= (1u << 18) ? 2u : 1u, Y = 3u - X;
   const auto it = t->prim_ms.find(ticks);
-  if (it == t->prim_ms.end()) return 1u;
+  if (it == t->prim_ms.end()) return X;
   const fspt_target::PrimStat &st = it->second;
-  if (st.runs[1] == 0) return 1u;
-  if (st.runs[2] == 0) return 2u;
-  if (st.runs[1] < 2) return 1u;
-  if (st.runs[2] < 2 && st.best[2] < st.best[1] * 1.10) return 2u;
-  return st.best[2] < st.best[1] ? 2u : 1u;
+  if (st.runs[X] == 0) return X;
+  if (st.runs[Y] == 0) return Y;
+  if (st.runs[X] == 1) { // X has only its cold run
+    if (st.best[X] <= st.best[Y]) return X;
+    if (st.best[X] > 1.12 * st.best[Y]) return Y;
+    return X; // its warm run
+  }
+  return st.best[X] <= st.best[Y] ? X : Y;
 }
 
 static int ev_begin(fspt_target *t, int kind, hipStream_t stream) {

@@ -43,9 +43,10 @@ int fspt_target_set_trace_budget(fspt_target *target, uint32_t steps);
 int fspt_target_set_tail(fspt_target *target, int round);
 /* The primary launch (ray generation + the camera ray's traversal + its shading) has two forms of its traversal phase:
  * 1 = one traversal per lane (a wave waits for its longest ray), 2 = per-lane refill over 2 x 64 samples per wave.  0
- * (default): the batch scheduler times both on the target's own batches (HIP events, read back without waiting; at most
- * four batches of a size: form 1 cold, form 2, form 1 warm, form 2 again if close) and keeps the faster per batch size - form 1 on the
- * 70 k-triangle scene, form 2 on the 1 M-triangle one. */
+ * (default): the batch scheduler times both on the target's own batches (HIP events around the launch, read back
+ * without waiting): per batch size the first batch runs the form the scene's size suggests, the second the other one,
+ * a third batch is spent only when the first form lost by no more than its cold start explains; then the faster form
+ * runs - form 1 on the 70 k-triangle scene, form 2 on the 1 M-triangle one. */
 int fspt_target_set_primary_form(fspt_target *target, int form);
 /* The form the next batch of `batch_ticks` ticks will use and what has been measured for that batch size so far
  * (best ms per sample of form 1, form 2; < 0: not measured yet).  Blocking (waits for a measurement in flight). */
