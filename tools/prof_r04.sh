@@ -20,6 +20,13 @@ echo "l1_peak: $L1" > $O/${T}_l1_peak.txt
 set -- $L1ARG "$@"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -- python3 $R/bench.py --no-cpu-baseline ${KT_ARGS:---steps 20 --warmup 5} "$@" > $O/${T}_kt.log 2>&1
 find $O/${T}_kt -name "*kernel_trace.csv" -size +8M -delete
+# the counter passes run the primary launch in the form this (lightly profiled) run settled on: under --pmc the kernels'
+# timings are distorted and the library's form tuner would measure the profiler, not the kernels
+PF=$(python3 -c "import sys,json
+for l in open('$O/${T}_kt.log'):
+    if l.startswith('{'): print(json.loads(l)['config'].get('primary_form',{}).get('form',0))" | tail -1)
+[ -n "$PF" ] && [ "$PF" != "0" ] && set -- --primary-form $PF "$@"
+echo "primary form for the counter passes: ${PF:-tuner}" >> $O/${T}_l1_peak.txt
 # traffic passes: the timed configuration itself (TRAFFIC_ARGS, default: the driver's 20-step regions - one warm-up
 # region, whose first batch has no live-path statistics yet, and four timed ones; the counters sum all five)
 TA=${TRAFFIC_ARGS:---steps 20 --warmup 20 --reps 4}
