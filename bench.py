@@ -166,6 +166,10 @@ def parse_args(argv=None):
                          "outside this run, e.g. under a profiler where no child process may be started)")
     ap.add_argument("--no-l1-microbench", action="store_true", help="never start tools/microbench/l1_peak: use --l1-peak or the fallback constant")
     ap.add_argument("--rendezvous-timeout", type=float, default=180.0, help="seconds a rank waits for the process group / an exchange before it exits non-zero")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="plumbing check for a 1-GPU box: all N ranks render on device 0 and exchange over gloo through host "
+                         "memory (RCCL cannot put two ranks on one device); exercises the N-rank code path - sharding, the "
+                         "exchange's packing, max-over-ranks timing, the mandatory parity check - its Msamples/s says nothing about scaling")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / exchange plumbing only, on CPU over gloo (no GPU, no rendering)")
     args = ap.parse_args(argv)
@@ -310,6 +314,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libfspt has no CPU path)")
+    if args.share_gpu:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
@@ -317,7 +323,8 @@ def main():
     # the process group's own timeout (what RCCL's watchdog applies to every collective) is generous - rank 0 checks the
     # frame against the oracle and counts work while the others wait at the closing barrier; the tighter deadlines around
     # the rendezvous, the barriers of the timed regions and the exchange are the Watchdogs below
-    dist = (D.init_process_group(backend="nccl", device=torch.device("cuda", local_rank), timeout_s=max(600.0, 2 * args.rendezvous_timeout))
+    dist = (D.init_process_group(backend="gloo" if args.share_gpu else "nccl", device=torch.device("cuda", local_rank),
+                                 timeout_s=max(600.0, 2 * args.rendezvous_timeout))
             if n_gpus > 1 else None)
     world_seen = dist.get_world_size() if dist is not None else 1
     if world_seen != args.gpus:
@@ -391,18 +398,18 @@ def main():
         t_render = time.perf_counter()
         with D.Watchdog(args.rendezvous_timeout if n_gpus > 1 else 0, f"read-out exchange ({args.exchange}) of region {rep_i}", rank):
             if exch is not None:
-                exch.exchange(accum)  # RCCL over xGMI: rank 0 ends up with the whole frame
+                exch.exchange(accum, stage_host=args.share_gpu)  # RCCL over xGMI: rank 0 ends up with the whole frame
             elif n_gpus > 1:
                 # sum-reduce of the full frame; the other ranks' pixels rank 0 received in the previous region are zeroed
                 # first (foreign mask), or they would be added again
-                D.reduce_radiance(accum, dst=0, foreign_mask=foreign)
+                D.reduce_radiance(accum, dst=0, foreign_mask=foreign, stage_host=args.share_gpu)
             torch.cuda.synchronize()
         barrier(f"barrier after region {rep_i}")
         elapsed = time.perf_counter() - t_start
         exch_ms.append((time.perf_counter() - t_render) * 1e3)
         render_ms.append((t_render - t_start) * 1e3)
         if dist is not None:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else f"cuda:{local_rank}")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         times.append(elapsed)
@@ -661,7 +668,7 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
                    "scene_bytes": arrays.nbytes(), "bvh_nodes": arrays.n_nodes, "bvh_depth": arrays.depth,
                    "env_bins": int(arrays.bins.size // 4), "atlas": f"{arrays.atlas_res}^2 x {arrays.atlas_layers}",
                    "sharding": f"32x32 tiles round-robin over {n_gpus}", "world_size_seen": world_seen,
-                   "exchange": (args.exchange if n_gpus > 1 else "none"), "pipeline": args.pipeline,
+                   "exchange": ((args.exchange + (" (gloo through host memory: --share-gpu, all ranks on ONE device - a plumbing check, not a scaling figure)" if args.share_gpu else "")) if n_gpus > 1 else "none"), "pipeline": args.pipeline,
                    "batch_ticks": args.batch, "path_state_bytes": pt.path_state_bytes()[0],
                    "primary_form": (dict(zip(("form", "ms_per_Msample"), (lambda f, ms: (f, [round(m * 1e6, 4) if m >= 0 else None for m in ms]))(*pt.primary_form(min(args.batch, args.steps)))))
                                     if args.pipeline == "wavefront" else None),

@@ -173,18 +173,28 @@ class TileGather:
             flat[:, 3].index_fill_(0, self.all_idx, 1.0)
         return accum
 
-    def exchange(self, accum):
-        """accum: float32 [H, W, 4] on every rank (only own pixels non-zero); complete on `dst` afterwards."""
+    def exchange(self, accum, stage_host=False):
+        """accum: float32 [H, W, 4] on every rank (only own pixels non-zero); complete on `dst` afterwards.
+        stage_host: the packed pieces travel through host memory (a backend without device-tensor gather: gloo with the
+        ranks sharing one GPU, bench.py --share-gpu); packing and unpacking stay on the device."""
+        import torch
         import torch.distributed as dist
         self.pack(accum)
         if self.world > 1:
-            dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst)
+            if stage_host:
+                send = self.send.cpu()
+                recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == self.dst else None
+                dist.gather(send, recv, dst=self.dst)
+                if self.rank == self.dst:
+                    self.big.copy_(torch.cat(recv))
+            else:
+                dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst)
             if self.rank == self.dst:
                 self.unpack(accum)
         return accum
 
 
-def reduce_radiance(accum, dst=0, own_mask=None, foreign_mask=None):
+def reduce_radiance(accum, dst=0, own_mask=None, foreign_mask=None, stage_host=False):
     """The one exchange step as a sum-reduce (the RCCL reduce north_star names): the ranks' full-size buffers are summed
     onto `dst` in place.  Every rank's buffer must be zero outside its own tiles.  That holds for a fresh buffer, but
     after a reduce `dst` holds the other ranks' pixels too - a second reduce would add them again - so a caller that
@@ -197,5 +207,11 @@ def reduce_radiance(accum, dst=0, own_mask=None, foreign_mask=None):
             foreign_mask = ~own_mask
         if foreign_mask is not None:
             accum.masked_fill_(foreign_mask.unsqueeze(-1), 0.0)
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+        if stage_host:  # (a backend without device-tensor reduce: see TileGather.exchange)
+            h = accum.cpu()
+            dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM)
+            if dist.get_rank() == dst:
+                accum.copy_(h)
+        else:
+            dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum

@@ -1242,6 +1242,32 @@ def test_bound_torch_accumulator_and_tile_gather_on_gpu(small_scene, camera):
         assert np.array_equal(g0.unpack(accs[0]).cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("exchange", ["gather", "reduce"])
+def test_bench_two_ranks_share_the_gpu(exchange):
+    """bench.py's N-rank path end to end on the 1-GPU pool (`--share-gpu`: both ranks render on device 0, the exchange goes
+    over gloo through host memory - RCCL cannot put two ranks on one device): the launcher, the rendezvous, tile sharding
+    of the weak-scaled frame, the exchange's pack / unpack on the device, max-over-ranks timing and the parity check that
+    is mandatory for N > 1 - the frame rank 0 assembled from both ranks' tiles equals the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--exchange", exchange,
+                        "--steps", "3", "--warmup", "2", "--reps", "2", "--width", "640", "--height", "360", "--mesh-n", "24",
+                        "--no-l1-microbench", "--rendezvous-timeout", "120"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size_seen"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["parity_check"]["equal"] is True
+    assert "share-gpu" in d["config"]["exchange"] and d["config"]["exchange"].startswith(exchange)
+    ranks = [json.loads(l.split("[bench rank] ", 1)[1]) for l in r.stderr.splitlines() if l.startswith("[bench rank] ")]
+    assert sorted({x["rank"] for x in ranks}) == [0, 1]  # every rank reported itself on stderr
+
+
 def test_frame_sequence_from_scene_files(tmp_path):
     """`?frame=N` sequencing (main.js:851-866, 869-871, 966-969): per-frame scene JSONs whose animated_props
     move, loaded from an on-disk web root (OBJ + MTL + PNG maps + RGBE sky), auto-focused, rendered and
