@@ -1442,6 +1442,8 @@ def test_fuzz_random_scenes_bitwise(seed):
         pt = PathTracer(sc, W, H, num_bounces=bounces)
         pt.eye, pt.dir, pt.fovScale, pt.envTheta, pt.lensFeatures = cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["lens"]
         pt.set_pipeline(pipeline, 2)
+        if pipeline == "wavefront":
+            pt.set_primary_form((seed % 3 + 1) % 3)  # both forms of the primary launch and the tuner, by seed
         pt.enable_counters(True)
         pt.clear()
         pt.seed(rseed)
@@ -1457,6 +1459,8 @@ def test_fuzz_random_scenes_bitwise(seed):
         pt.eye, pt.dir, pt.fovScale, pt.envTheta, pt.lensFeatures = cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["lens"]
         pt.set_pipeline(pipeline, 2)
         pt.set_trace_budget(1 + seed % 5)
+        if pipeline == "wavefront":
+            pt.set_primary_form(2 - seed % 2)
         if pool:
             pt.set_pool(pool, seed % 4 - 1, 0, seed % 2)
         pt.seed(rseed)
