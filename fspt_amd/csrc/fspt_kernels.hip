@@ -682,21 +682,19 @@ FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randB
   float F = schlick(incident, microNormal, nsx, nsy);
   bool specular = fma_(1.0f, metallic, F * (1.0f - metallic)) > rnd(seed);
   bool refracted = false;
+  // bsdfThroughput = numB * clamp(n . rd) / bsdfPdf and envThroughput = numE * clamp(n . envDir) / envPdf in the reflect
+  // and the Lambert branch (tracer.fs:476-480, 490-495): the branches leave the numerators, the six divisions happen once
+  // behind them (a wave usually holds lanes of both branches and used to run both copies)
+  V3 numB = v3(1.0f, 1.0f, 1.0f), numE = v3(0.0f, 0.0f, 0.0f);
   if (specular) {
     V3 I = -incident;
     float k = 2.0f * dot(microNormal, I);
     rd = v3(fma_(-k, microNormal.x, I.x), fma_(-k, microNormal.y, I.y), fma_(-k, microNormal.z, I.z));
     bsdfPdf = gtr2_pdf(incident, macroNormal, rough, rd);
-    V3 es = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, rd);
-    float cl = clamp_(dot(macroNormal, rd), 0.0f, 1.0f);
-    bsdfThroughput = v3((es.x * cl) / bsdfPdf, (es.y * cl) / bsdfPdf, (es.z * cl) / bsdfPdf);
-    V3 ee = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, envDir);
-    float ce = clamp_(cosEnv, 0.0f, 1.0f);
-    envThroughput = v3((ee.x * ce) / envPdf, (ee.y * ce) / envPdf, (ee.z * ce) / envPdf);
+    numB = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, rd);
+    numE = eval_specular(incident, macroNormal, texDiffuse, metallic, rough, envDir);
   } else if (dielectric >= 0.0f) {
     bsdfPdf = 1.0f;
-    bsdfThroughput = v3(1.0f, 1.0f, 1.0f);
-    envThroughput = v3(0.0f, 0.0f, 0.0f);
     ro = origin - off;
     V3 I = -incident;
     float eta = nsx / nsy;
@@ -712,12 +710,15 @@ FM_DEV void shade_hit(const DScene &S, Path &ps, float tHit, int ti, float randB
   } else {
     rd = sample_lambert(macroNormal, seed);
     bsdfPdf = abs_(dot(rd, macroNormal)) * INV_PI_F;
-    float cl = clamp_(dot(macroNormal, rd), 0.0f, 1.0f);
-    bsdfThroughput = v3(((texDiffuse.x * INV_PI_F) * cl) / bsdfPdf, ((texDiffuse.y * INV_PI_F) * cl) / bsdfPdf,
-                        ((texDiffuse.z * INV_PI_F) * cl) / bsdfPdf);
-    float ce = clamp_(cosEnv, 0.0f, 1.0f);
-    envThroughput = v3(((texDiffuse.x * INV_PI_F) * ce) / envPdf, ((texDiffuse.y * INV_PI_F) * ce) / envPdf,
-                       ((texDiffuse.z * INV_PI_F) * ce) / envPdf);
+    numB = numE = v3(texDiffuse.x * INV_PI_F, texDiffuse.y * INV_PI_F, texDiffuse.z * INV_PI_F);
+  }
+  if (refracted) {
+    bsdfThroughput = v3(1.0f, 1.0f, 1.0f);
+    envThroughput = v3(0.0f, 0.0f, 0.0f);
+  } else {
+    const float cl = clamp_(dot(macroNormal, rd), 0.0f, 1.0f), ce = clamp_(cosEnv, 0.0f, 1.0f);
+    bsdfThroughput = v3((numB.x * cl) / bsdfPdf, (numB.y * cl) / bsdfPdf, (numB.z * cl) / bsdfPdf);
+    envThroughput = v3((numE.x * ce) / envPdf, (numE.y * ce) / envPdf, (numE.z * ce) / envPdf);
   }
   if (inside) { // tracer.fs:497
     bsdfThroughput = v3(max_(1.0f - (((1.0f - texDiffuse.x) * tHit) * dielectric), 0.0f),
