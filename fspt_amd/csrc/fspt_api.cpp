@@ -895,7 +895,8 @@ static void prim_collect(fspt_target *t, bool wait) {
 // ... and the form for the next batch of `ticks` ticks.  X = the form the scene's size suggests (per-lane refill pays
 // where ray lengths scatter: sub-pixel triangles), Y the other one.  Batch 1 of a size runs X - cold: a size's first batch
 // is 4-8 % slower (first use of that much path state, clocks, caches) - batch 2 runs Y.  If X won although it ran cold,
-// or lost by more than a cold start explains (12 %), the matter is settled after those two batches; otherwise X gets a
+// or lost by more than a cold start explains (25 %: the first 128-tick batch - 57 GB of path state used for the first
+// time - has been seen 23 % slow), the matter is settled after those two batches; otherwise X gets a
 // warm run (batch 3) and the better best-run wins.  (Forms are measured on whole batches: timed on halves of a batch
 // the refill form - 512 samples per block iteration - looked 10-20 % worse than it is, profiles/r04/primary_form_tuner_split.log.)
 static uint32_t prim_choose(const fspt_target *t, uint32_t ticks) {
@@ -907,7 +908,7 @@ static uint32_t prim_choose(const fspt_target *t, uint32_t ticks) {
   if (st.runs[Y] == 0) return Y;
   if (st.runs[X] == 1) { // X has only its cold run
     if (st.best[X] <= st.best[Y]) return X;
-    if (st.best[X] > 1.12 * st.best[Y]) return Y;
+    if (st.best[X] > 1.25 * st.best[Y]) return Y;
     return X; // its warm run
   }
   return st.best[X] <= st.best[Y] ? X : Y;

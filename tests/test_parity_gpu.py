@@ -920,7 +920,7 @@ def test_primary_launch_forms_bitwise(form, small_scene, camera):
             assert ms[0] > 0 and ms[1] > 0      # ... both forms were timed once
             if ms[0] <= ms[1]:
                 assert f == 1                   # form 1 won although it ran cold: settled
-            elif ms[0] > 1.12 * ms[1]:
+            elif ms[0] > 1.25 * ms[1]:
                 assert f == 2                   # it lost by more than a cold start explains: settled
             else:
                 assert f == 1                   # form 1 gets a warm run
