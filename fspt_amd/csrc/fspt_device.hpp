@@ -177,7 +177,7 @@ struct alignas(128) WfCounts { // one per round, zeroed before the batch
 struct WfSet { float4 *A, *B, *C, *E, *D, *P; };
 
 // ---------------------------------------------------------------------------
-// Streaming scheduler (fspt_target_set_pipeline code 3 / 4): a FIXED pool of path state that is kept full.
+// Streaming scheduler (fspt_target_set_pipeline code 2): a FIXED pool of path state that is kept full.
 //   The (work index, tick) samples of a run of n_batch ticks are numbered pixel-major exactly like a batch's slots
 //   (g = w * n_batch + j) and cut into UNITS of 64 work indices x n_batch ticks (one 8x8 pixel patch, all its ticks).
 //   Iteration i:   plan(i)    takes as many units from the device-side cursor as are GUARANTEED to fit the state set:

@@ -41,7 +41,7 @@ using namespace fm;
 #ifndef WF_TRACE_LDS_TOP
 #define WF_TRACE_LDS_TOP 31 // top-of-tree nodes (breadth-first) k_wf_trace keeps in LDS: measured best of {0, 31, 77} (profiles/r01)
 #endif
-#define WF_TRACE_BLOCKS_PER_CU 7u // resident 256-thread blocks per CU at 66 VGPRs
+#define WF_TRACE_BLOCKS_PER_CU 7u // most 256-thread blocks per CU the LDS split is computed for (the registers - 80 since the suspended traversals - allow 6)
 #define BLOCK_THREADS 256
 #define WAVES_PER_BLOCK (BLOCK_THREADS / WAVE)
 #define WORK_CHUNK 256u
