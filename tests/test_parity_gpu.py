@@ -1268,6 +1268,28 @@ def test_bench_two_ranks_share_the_gpu(exchange):
     assert sorted({x["rank"] for x in ranks}) == [0, 1]  # every rank reported itself on stderr
 
 
+@pytest.mark.parametrize("exchange", ["gather", "reduce"])
+def test_bench_two_ranks_over_rccl(exchange):
+    """Arms itself on a node with >= 2 GPUs (skips on the 1-GPU pool): bench.py's two-rank run as the driver starts it -
+    one process per GPU, RCCL gather / reduce of the tiles over xGMI - and the frame rank 0 assembled equals the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if L.lib().fspt_device_count() < 2:
+        pytest.skip("needs two physical GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "2", "--exchange", exchange,
+                        "--steps", "3", "--warmup", "2", "--reps", "2", "--width", "640", "--height", "360", "--mesh-n", "24",
+                        "--no-l1-microbench", "--rendezvous-timeout", "120"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["world_size_seen"] == 2 and d["parity_check"]["equal"] is True
+    assert d["config"]["exchange"] == exchange
+
+
 def test_frame_sequence_from_scene_files(tmp_path):
     """`?frame=N` sequencing (main.js:851-866, 869-871, 966-969): per-frame scene JSONs whose animated_props
     move, loaded from an on-disk web root (OBJ + MTL + PNG maps + RGBE sky), auto-focused, rendered and
