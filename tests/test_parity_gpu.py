@@ -1279,8 +1279,10 @@ def test_bench_two_ranks_over_rccl(exchange):
     if L.lib().fspt_device_count() < 2:
         pytest.skip("needs two physical GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "2", "--exchange", exchange,
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--exchange", exchange,
                         "--steps", "3", "--warmup", "2", "--reps", "2", "--width", "640", "--height", "360", "--mesh-n", "24",
                         "--no-l1-microbench", "--rendezvous-timeout", "120"],
                        capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
