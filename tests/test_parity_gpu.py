@@ -1268,6 +1268,27 @@ def test_bench_two_ranks_share_the_gpu(exchange):
     assert sorted({x["rank"] for x in ranks}) == [0, 1]  # every rank reported itself on stderr
 
 
+def test_bench_c4_eight_ranks_share_the_gpu():
+    """BASELINE configs[3] (3840x2160, depth 8, eight ranks, strong scaling) as bench.py runs it, with the eight rank
+    processes on the pool's one GPU (`--share-gpu`): every tile shard is rendered by its own process, the eight pieces are
+    gathered, and the frame rank 0 assembled equals the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--share-gpu", "--config", "c4",
+                        "--steps", "3", "--warmup", "1", "--reps", "1", "--no-l1-microbench", "--rendezvous-timeout", "300"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["config"]["world_size_seen"] == 8 and d["scaling"] == "strong"
+    assert "3840x2160" in d["metric"] and d["config"]["sharding"] == "32x32 tiles round-robin over 8"
+    assert d["parity_check"]["equal"] is True and d["parity_check"]["pixels"] > 1000000
+    ranks = [json.loads(l.split("[bench rank] ", 1)[1]) for l in r.stderr.splitlines() if l.startswith("[bench rank] ")]
+    assert sorted({x["rank"] for x in ranks}) == list(range(8))
+
+
 @pytest.mark.parametrize("exchange", ["gather", "reduce"])
 def test_bench_two_ranks_over_rccl(exchange):
     """Arms itself on a node with >= 2 GPUs (skips on the 1-GPU pool): bench.py's two-rank run as the driver starts it -
