@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/session_r04_prof.sh <tag>
+# usage (GPU box): bash tools/sessions/session_r04_prof.sh <tag>
 T=${1:-final}
 O=gpurun_out/r04; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q > $O/${T}_pytest.log 2>&1; tail -3 $O/${T}_pytest.log
