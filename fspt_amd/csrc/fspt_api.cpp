@@ -1056,13 +1056,13 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
         t->prim_pending_samples = (double)nbt * (double)work_total;
       }
       if (r < last && r < tail) {
-        // the last trace launch of a batch lets its long rays finish: what it suspended the tail kernel would have to
-        // trace again from the start
-        const uint32_t keep = p.susp_budget;
-        if (r + 1 == (last < tail ? last : tail)) p.susp_budget = 0;
+        // (the last trace launch in front of the tail kernel parks its long rays like every other: the carry launch
+        // moves those paths on and the tail kernel - a bundle of dependent chains with lanes to spare - traces their rays
+        // again from the root.  Letting them finish in the trace launch, as rounds 3 and early 4 did, kept the chip
+        // waiting for a handful of rays: 1 M-triangle scene trace 0.249 -> 0.215 ms per tick, a single tick of C2 0.27 ->
+        // 0.18, profiles/r04/ab_last_trace_suspends.log)
         if ((rc = launch(fspt::WF_K_TRACE))) return rc;
         prev_trace_suspends = p.susp_budget != 0;
-        p.susp_budget = keep;
       }
     }
     if (tail <= last && (tail < last || t->scene->has_dielectric || susp_on)) {
