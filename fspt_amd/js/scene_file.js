@@ -7,7 +7,8 @@
  * main.js:838-866 tick / uploadOutput), with the browser's pieces replaced by Node's own:
  *   XHR text loads            -> fs.readFileSync
  *   <img> decoding            -> decodePng below (zlib.inflateSync + the five PNG filters): straight-alpha RGBA8,
- *                                row 0 = top - what a browser hands to texImage2D.  JPEG is not decoded (convert to PNG).
+ *                                row 0 = top - what a browser hands to texImage2D; baseline JPEG -> jpeg.js (libjpeg's
+ *                                default decode, bit for bit: the bytes Pillow gives the Python host)
  *   canvas.toBlob('image/png')-> encodePng
  * The path tracing itself happens in libfspt through fspt.js.  Same semantics as fspt_amd/scene_file.py.
  */
@@ -15,6 +16,7 @@ const fs = require('fs');
 const path = require('path');
 const zlib = require('zlib');
 const F = require('./fspt.js');
+const { decodeJpeg } = require('./jpeg.js');
 
 const PNG_SIG = Buffer.from([137, 80, 78, 71, 13, 10, 26, 10]);
 
@@ -125,7 +127,8 @@ function readImage(root, rel) {
   const file = path.join(root, rel);
   const buf = fs.readFileSync(file);
   if (buf.length >= 8 && buf.slice(0, 8).equals(PNG_SIG)) return Object.assign(decodePng(buf), { currentSrc: rel });
-  throw new Error(file + ': only PNG images are decoded by the Node host (the browser decodes JPEG for the reference; convert it)');
+  if (buf.length >= 3 && buf[0] === 0xFF && buf[1] === 0xD8 && buf[2] === 0xFF) return Object.assign(decodeJpeg(buf), { currentSrc: rel });
+  throw new Error(file + ': only PNG and baseline JPEG images are decoded by the Node host');
 }
 
 /** the urls obj_loader.js:185-187 fetches while parsing: basePath + '/' + the rest of each `mtllib` line */
@@ -217,7 +220,7 @@ function renderSequence(scenePattern, frames, outPattern, width, height, opts) {
   return written;
 }
 
-module.exports = { decodePng, encodePng, mtllibUrls, loadSceneFile, renderFrame, renderToPng, renderSequence };
+module.exports = { decodePng, encodePng, decodeJpeg, mtllibUrls, loadSceneFile, renderFrame, renderToPng, renderSequence };
 
 // node fspt_amd/js/scene_file.js scene/bunny.json out.png [--width W] [--height H] [--samples N] [--bounces B] [--seed S]
 //                                [--asset-root DIR] [--denoise] [--frames A:B]   (mirrors `python -m fspt_amd.render`;

@@ -27,6 +27,13 @@ if (mode === 'scene_file') {
   let err = null;
   try { SF.decodePng(Buffer.from('GIF89a-not-a-png')); } catch (e) { err = String(e.message); }
   out.not_png = err;
+} else if (mode === 'jpeg') {
+  // decodeJpeg on files Pillow wrote; what it refuses to decode must say so
+  out.decoded = {}; out.errors = {};
+  for (const f of job.files) {
+    try { const im = SF.decodeJpeg(fs.readFileSync(f)); out.decoded[f] = { width: im.width, height: im.height, rgba: b64(im.data) }; }
+    catch (e) { out.errors[f] = String(e.message); }
+  }
 } else if (mode === 'render_scene_file') {
   const fr = SF.renderToPng(job.scene_path, job.out_png, job.W, job.H, { samples: job.samples, bounces: job.bounces, seed: job.seed, denoise: job.denoise });
   out.radiance = b64(fr.radiance); out.rgba = b64(fr.rgba);

@@ -218,6 +218,56 @@ def test_js_png_codec_matches_pil(tmp_path):
     assert "not a PNG" in out["not_png"]
 
 
+def test_js_jpeg_decoder_matches_libjpeg(tmp_path):
+    """decodeJpeg (fspt_amd/js/jpeg.js) against Pillow's libjpeg on files Pillow writes here: a JPEG's decoded bytes are
+    the decoder's choice (inverse DCT, chroma upsampling, colour conversion), and the Node host makes libjpeg's default
+    choices bit for bit - so a scene with .jpeg maps (asset_packs/dungeon in the reference) loads to the same atlas from
+    both hosts.  Baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, optimised Huffman tables, restart
+    intervals, quality 1-100, sizes from 1x1 that are not multiples of the MCU, noise (coefficients that leave the
+    inverse DCT's range); CMYK is refused with a message."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+
+    def picture(w, h, ch):
+        y, x = np.mgrid[0:h, 0:w]
+        a = np.stack([(np.sin(x / 7.0 + k) + np.cos(y / 5.0 - k)) * 60 + 128 + rng.normal(0, 12, (h, w)) for k in range(ch)], -1)
+        return np.clip(a, 0, 255).astype(np.uint8)
+    files = {}
+
+    def save(name, im, **kw):
+        f = str(tmp_path / (name + ".jpg"))
+        im.save(f, "JPEG", **kw)
+        files[f] = np.asarray(Image.open(f).convert("RGBA"), dtype=np.uint8)
+    i = 0
+    for w, h in [(64, 64), (37, 23), (1, 1), (2, 3), (3, 2), (5, 17), (130, 71), (16, 8)]:
+        for sub in (0, 1, 2):
+            for q, prog in [(30, False), (75, True), (95, False), (100, True)]:
+                if i % 3 and (w, h) not in [(37, 23), (5, 17)]:
+                    i += 1
+                    continue
+                save(f"rgb_{w}x{h}_s{sub}_q{q}_p{int(prog)}", Image.fromarray(picture(w, h, 3)), quality=q, subsampling=sub,
+                     optimize=bool(i % 2), progressive=prog)
+                i += 1
+    save("grey", Image.fromarray(picture(64, 48, 1)[..., 0]), quality=80)
+    save("grey_prog", Image.fromarray(picture(13, 9, 1)[..., 0]), quality=60, progressive=True)
+    save("s411", Image.fromarray(picture(67, 41, 3)), subsampling="4:1:1")
+    save("q1", Image.fromarray(picture(40, 40, 3)), quality=1)
+    noise = Image.fromarray(rng.integers(0, 256, (40, 56, 3), dtype=np.uint8))
+    for sub in (0, 1, 2):
+        save(f"noise_s{sub}", noise, quality=100, subsampling=sub)
+        save(f"rst_s{sub}", Image.fromarray(picture(100, 60, 3)), quality=85, subsampling=sub, restart_marker_blocks=3)
+    save("prog_noise_rst", noise, quality=100, subsampling=2, progressive=True, restart_marker_blocks=2)
+    cmyk = str(tmp_path / "cmyk.jpg")
+    Image.fromarray(picture(16, 16, 3)).convert("CMYK").save(cmyk, "JPEG")
+    out = run_node("jpeg", {"files": sorted(files) + [cmyk]})
+    assert list(out["errors"]) == [cmyk] and "CMYK" in out["errors"][cmyk]
+    assert len(files) > 40
+    for f, want in files.items():
+        d = out["decoded"][f]
+        assert (d["height"], d["width"]) == want.shape[:2], f
+        assert np.array_equal(dec(d["rgba"], np.uint8).reshape(want.shape), want), os.path.basename(f)
+
+
 def test_js_scene_file_loader_matches_reference_arrays(tmp_path):
     """VERDICT r3 'missing 1': loadSceneFile in the reference's own language.  The 'mtl' golden asset tree on disk
     (scene JSON + OBJ + MTL + PNG maps + RGBE-PNG sky) loaded by Node - Node's fs instead of XHR, decodePng instead of
@@ -239,6 +289,37 @@ def test_js_scene_file_loader_matches_reference_arrays(tmp_path):
     assert (out["atlasRes"], out["atlasLayers"]) == (nat.atlas_res, nat.atlas_layers)
     got = dec(out["atlas"], np.uint8).astype(np.int16)
     assert np.abs(got - nat.atlas.astype(np.int16)).max() <= 1 and (got != nat.atlas).mean() < 1e-3
+
+
+def test_js_scene_file_loader_with_jpeg_maps(tmp_path):
+    """The 'mtl' asset tree with its image maps saved as JPEG (baseline and progressive; the reference's asset_packs/dungeon
+    holds .jpeg maps): the Node host - jpeg.js - and the Python host - Pillow's libjpeg - decode them to the same texels,
+    so both build the same layer list and, to the resampler's one 8-bit step, the same atlas."""
+    from PIL import Image
+    from fspt_amd import scene_file as PF
+    from test_goldens import load_js, stand_in_images, write_asset_tree
+    z, scene, texts, files = load_js("mtl")
+    imgs = stand_in_images(z)
+    ren = {rel: rel[:-4] + ".jpg" for rel in imgs}
+
+    def patch(t):
+        for a, b in ren.items():
+            t = t.replace(os.path.basename(a), os.path.basename(b))
+        return t
+    write_asset_tree(str(tmp_path), z, json.loads(patch(json.dumps(scene))), {k: patch(v) for k, v in texts.items()},
+                     {k: patch(v) for k, v in files.items()})
+    for i, (rel, img) in enumerate(imgs.items()):
+        os.remove(os.path.join(str(tmp_path), rel))
+        Image.fromarray(img).convert("RGB").save(os.path.join(str(tmp_path), ren[rel]), "JPEG", quality=90, subsampling=i % 3, progressive=bool(i % 2))
+    sp = os.path.join(str(tmp_path), "scene", "test.json")
+    out = run_node("scene_file", {"scene_path": sp})
+    a, _ = PF.load_scene_file(sp)
+    assert out["layers"] == a.meta["layers"] and any(".jpg" in str(x) for x in out["layers"])
+    assert (out["atlasRes"], out["atlasLayers"]) == (a.atlas_res, a.atlas_layers)
+    for k in ("bvh", "tri", "mat", "norm", "uv"):
+        assert np.array_equal(dec(out[k], np.uint32), getattr(a, k).view(np.uint32)), k
+    got = dec(out["atlas"], np.uint8).astype(np.int16)
+    assert np.abs(got - a.atlas.astype(np.int16)).max() <= 1 and (got != a.atlas).mean() < 1e-3
 
 
 @pytest.mark.gpu
