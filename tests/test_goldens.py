@@ -205,11 +205,12 @@ def _env_decode_bias(a, env_theta):
     raise AssertionError("no stage golden with this environment map")
 
 
-@pytest.mark.parametrize("name", ["small", "small_d4", "variant", "textured"])
+@pytest.mark.parametrize("name", ["small", "small_d4", "variant", "textured", "small_dof"])
 def test_d5_converged_mean_matches_glsl(name):
     """Stage D5: 16 384 spp of the UNMODIFIED tracer.fs on SwiftShader (two randBase streams) against 16 384 spp of the
     oracle (its own stream): depth 8 (the BASELINE depth) on the flat-colour, the refractive / emissive and the
-    image-mapped scene, depth 4 (tracer.fs:9 as shipped) on the first.  After dividing out the deterministic RGBE-decode
+    image-mapped scene, depth 4 (tracer.fs:9 as shipped) on the first, and the first again through BASELINE configs[4]'s
+    lens (aperture 0.1: camera.fs getDOF moves every sample's origin over a 5x wider disc).  After dividing out the deterministic RGBE-decode
     factor of SwiftShader (see _env_decode_bias) the whole-image mean agrees within 0.5 %, and the per-pixel difference is
     the Monte-Carlo noise of the two renders: rel-L2 within 1.3x the GLSL-vs-GLSL floor (0.015 / 0.026 / 0.02)."""
     z = np.load(os.path.join(GOLD, f"glsl_converged_{name}.npz"))

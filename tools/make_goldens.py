@@ -482,7 +482,9 @@ def make_glsl(name="small"):
 CONVERGED = {"small": ("small", 48, 32, 16384, 8, None, None),
              "small_d4": ("small", 48, 32, 16384, 4, None, None),
              "variant": ("variant", 48, 32, 16384, 8, [0.3, 1.2, 3.4], [-0.05, -0.3, -0.95]),
-             "textured": ("textured", 48, 32, 16384, 8, None, None)}
+             "textured": ("textured", 48, 32, 16384, 8, None, None),
+             # BASELINE configs[4]'s lens (aperture 0.1 instead of 0.02): getDOF's disc is 5x wider, every sample's origin moves
+             "small_dof": ("small", 48, 32, 16384, 8, None, None, 0.1)}
 
 
 def converged_scene(scene_name):
@@ -496,8 +498,8 @@ def make_converged(name):
     import glsl_ref as G
     import oracle as O
     cam = dict(S.BUNNY_CAMERA)
-    lens = S.lens_features(cam["focal_depth"], cam["aperture"])
-    scene_name, Wc, Hc, spp, bounces, P, I = CONVERGED[name]
+    scene_name, Wc, Hc, spp, bounces, P, I = CONVERGED[name][:7]
+    lens = S.lens_features(cam["focal_depth"], CONVERGED[name][7] if len(CONVERGED[name]) > 7 else cam["aperture"])
     P = P or cam["P"]; I = I or cam["I"]
     arrays = converged_scene(scene_name)
     g = G.GlslRef()
