@@ -205,19 +205,21 @@ def _env_decode_bias(a, env_theta):
     raise AssertionError("no stage golden with this environment map")
 
 
-@pytest.mark.parametrize("name", ["small", "small_d4", "variant", "textured", "small_dof"])
+@pytest.mark.parametrize("name", ["small", "small_d4", "variant", "textured", "small_dof", "small_d1"])
 def test_d5_converged_mean_matches_glsl(name):
     """Stage D5: 16 384 spp of the UNMODIFIED tracer.fs on SwiftShader (two randBase streams) against 16 384 spp of the
     oracle (its own stream): depth 8 (the BASELINE depth) on the flat-colour, the refractive / emissive and the
     image-mapped scene, depth 4 (tracer.fs:9 as shipped) on the first, and the first again through BASELINE configs[4]'s
-    lens (aperture 0.1: camera.fs getDOF moves every sample's origin over a 5x wider disc).  After dividing out the deterministic RGBE-decode
+    lens (aperture 0.1: camera.fs getDOF moves every sample's origin over a 5x wider disc), and depth 1 on the first
+    scene (direct light only: one shading event's NEE sample and MIS-weighted extension ray, nothing averaged
+    over later bounces).  After dividing out the deterministic RGBE-decode
     factor of SwiftShader (see _env_decode_bias) the whole-image mean agrees within 0.5 %, and the per-pixel difference is
     the Monte-Carlo noise of the two renders: rel-L2 within 1.3x the GLSL-vs-GLSL floor (0.015 / 0.026 / 0.02)."""
     z = np.load(os.path.join(GOLD, f"glsl_converged_{name}.npz"))
     scene_name = str(z["scene"])
     a = S.textured_test_scene() if scene_name == "textured" else scene_from_golden(scene_name)
     W, H, spp, bounces = int(z["W"]), int(z["H"]), int(z["spp"]), int(z["bounces"])
-    assert spp >= 16384 and bounces == (4 if name == "small_d4" else 8)
+    assert spp >= 16384 and bounces == {"small_d4": 4, "small_d1": 1}.get(name, 8)
     ga, gb = z["a"][..., :3].astype(np.float64), z["b"][..., :3].astype(np.float64)
 
     def rel_l2(x, y):
@@ -232,11 +234,14 @@ def test_d5_converged_mean_matches_glsl(name):
     o = acc[..., :3].astype(np.float64)
     gm = 0.5 * (ga + gb)
     r = gm.mean() / o.mean()
-    if scene_name == "small":
+    if scene_name == "small" and name != "small_d1":
         assert abs(r / bias - 1.0) <= 0.005, (r, bias)   # every photon comes from the environment
     else:
         # emitted light (tracer.fs:467: an MTL Kem / an emissive map) does not pass through the RGBE decode: the
-        # GLSL's mean lies between the fully biased and the unbiased one
+        # GLSL's mean lies between the fully biased and the unbiased one.  (Depth 1: the decode factor depends on the
+        # exponent BYTE - 0.986-0.992 over the probe directions, which see sky; 1.009 on a map of one other exponent
+        #  - and at depth 1 half the light is the NEE's samples of the sun's texels, whose exponent the
+        # probe set does not weigh: 0.994 measured against the probe average 0.989.)
         assert bias - 0.005 <= r <= 1.005, (r, bias)
     o = o * r
     assert rel_l2(o, ga) <= 1.3 * floor and rel_l2(o, gb) <= 1.3 * floor, (rel_l2(o, ga), rel_l2(o, gb), floor)

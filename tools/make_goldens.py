@@ -484,7 +484,10 @@ CONVERGED = {"small": ("small", 48, 32, 16384, 8, None, None),
              "variant": ("variant", 48, 32, 16384, 8, [0.3, 1.2, 3.4], [-0.05, -0.3, -0.95]),
              "textured": ("textured", 48, 32, 16384, 8, None, None),
              # BASELINE configs[4]'s lens (aperture 0.1 instead of 0.02): getDOF's disc is 5x wider, every sample's origin moves
-             "small_dof": ("small", 48, 32, 16384, 8, None, None, 0.1)}
+             "small_dof": ("small", 48, 32, 16384, 8, None, None, 0.1),
+             # depth 1: direct light only - one shading event, its NEE sample and its MIS-weighted extension ray, nothing averaged over later bounces
+             # (on the flat-colour scene: with emitters in view a single RGBE-bias factor no longer fits every pixel at depth 1)
+             "small_d1": ("small", 48, 32, 16384, 1, None, None)}
 
 
 def converged_scene(scene_name):
