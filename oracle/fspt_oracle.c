@@ -582,12 +582,12 @@ static void trace_pixel(const oracle_scene *s, vec3 ro, vec3 rd, uint32_t tick, 
 
 /* ---- camera.fs main (37-46) for one pixel ------------------------------- */
 static void camera_pixel(uint32_t x, uint32_t y, uint32_t W, uint32_t H, const float P[3], const float I[3],
-                         float fovScale, const float lens[2], float randBase, float *pos, float *dir) {
+                         float fovScale, const float lens[2], float randBase, const float *rec, float *pos, float *dir) {
   float fx = (float)x + 0.5f, fy = (float)y + 0.5f; /* gl_FragCoord */
   float resx = (float)W, resy = (float)H;
   /* uv = interpolated clip-space corner (camera.vs:8, main.js:601-605) */
   float uvx = om_fma(fx / resx, 2.0f, -1.0f), uvy = om_fma(fy / resy, 2.0f, -1.0f);
-  float seed = om_fma(fx, resy, randBase) + fy;
+  rng_t g = {om_fma(fx, resy, randBase) + fy, rec, 0}; /* (rec: the four values the GLSL's rnd() returned, probes only) */
   vec3 Iv = v3(I[0], I[1], I[2]), Pv = v3(P[0], P[1], P[2]);
   vec3 basisX = v_normalize(v_cross(Iv, v3(0.0f, 1.0f, 0.0f)));
   vec3 basisY = v_normalize(v_cross(basisX, Iv));
@@ -598,17 +598,17 @@ static void camera_pixel(uint32_t x, uint32_t y, uint32_t W, uint32_t H, const f
   screen.y = (om_fma(icy * basisY.y, fovScale, (icx * basisX.y) * fovScale) + Iv.y) + Pv.y;
   screen.z = (om_fma(icy * basisY.z, fovScale, (icx * basisX.z) * fovScale) + Iv.z) + Pv.z;
   /* getAA (camera.fs:26-30) */
-  float theta = (rnd_seed(&seed) * M_PI_F) * 2.0f;
-  float r = sqrtf(rnd_seed(&seed)) * 1.414f;
+  float theta = (rnd(&g) * M_PI_F) * 2.0f;
+  float r = sqrtf(rnd(&g)) * 1.414f;
   float ct = om_cos(theta), st = om_sin(theta);
   vec3 aa;
   aa.x = (r * ((basisX.x * ct) / resx + (basisY.x * st) / resy)) * fovScale;
   aa.y = (r * ((basisX.y * ct) / resx + (basisY.y * st) / resy)) * fovScale;
   aa.z = (r * ((basisX.z * ct) / resx + (basisY.z * st) / resy)) * fovScale;
   /* getDOF (camera.fs:32-35) */
-  float theta2 = (rnd_seed(&seed) * M_PI_F) * 2.0f;
+  float theta2 = (rnd(&g) * M_PI_F) * 2.0f;
   float c2 = om_cos(theta2), s2 = om_sin(theta2);
-  float sq = sqrtf(rnd_seed(&seed));
+  float sq = sqrtf(rnd(&g));
   vec3 dof;
   dof.x = (om_fma(s2, basisY.x, c2 * basisX.x) * lens[1]) * sq;
   dof.y = (om_fma(s2, basisY.y, c2 * basisX.y) * lens[1]) * sq;
@@ -629,7 +629,19 @@ void oracle_camera(uint32_t W, uint32_t H, const float P[3], const float I[3], f
   for (int64_t y = 0; y < (int64_t)H; ++y)
     for (uint32_t x = 0; x < W; ++x) {
       size_t o = ((size_t)y * W + x) * 4;
-      camera_pixel(x, (uint32_t)y, W, H, P, I, fovScale, lens, randBase, pos + o, dir + o);
+      camera_pixel(x, (uint32_t)y, W, H, P, I, fovScale, lens, randBase, NULL, pos + o, dir + o);
+    }
+}
+
+/* camera.fs main with the four values the reference GLSL's own rnd() returned per pixel (rec: [H][W][4], call order)
+ * replayed: everything behind rnd() - getAA, getDOF, the ray - without the GLSL implementation's sin() of a large
+ * argument in between. */
+void oracle_camera_probe(uint32_t W, uint32_t H, const float P[3], const float I[3], float fovScale,
+                         const float lens[2], const float *rec, float *pos, float *dir) {
+  for (uint32_t y = 0; y < H; ++y)
+    for (uint32_t x = 0; x < W; ++x) {
+      size_t o = ((size_t)y * W + x) * 4;
+      camera_pixel(x, y, W, H, P, I, fovScale, lens, 0.0f, rec + o, pos + o, dir + o);
     }
 }
 

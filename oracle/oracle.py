@@ -90,6 +90,16 @@ def camera(W, H, P, I, fov_scale, lens, rand_base):
     return pos, d
 
 
+def camera_probe(W, H, P, I, fov_scale, lens, rec):
+    """camera.fs main with the GLSL's own rnd() values (rec: [H, W, 4], call order) replayed."""
+    rec = np.ascontiguousarray(rec, np.float32)
+    assert rec.shape == (H, W, 4)
+    pos = np.zeros((H, W, 4), np.float32); d = np.zeros((H, W, 4), np.float32)
+    lib().oracle_camera_probe(C.c_uint32(W), C.c_uint32(H), (C.c_float * 3)(*P), (C.c_float * 3)(*I), C.c_float(fov_scale),
+                              (C.c_float * 2)(*lens), _fp(rec), _fp(pos), _fp(d))
+    return pos, d
+
+
 def trace(arrays, W, H, pos, d, tick, rand_base, env_theta, num_bounces, accum, counters=None, first_hits=False,
           shard=0, n_shards=1, tile=32):
     s = oscene(arrays)

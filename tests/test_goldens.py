@@ -186,6 +186,31 @@ def test_d1_camera_rays_statistics(stages):
     assert abs(gd[..., :3].mean() - d[..., :3].mean()) < 2e-3
 
 
+def test_d1_camera_rays_with_replayed_rnd_match_glsl():
+    """camera.fs pinned deterministically: its main() run on SwiftShader with the four values its rnd() returned per pixel
+    recorded next to the ray (tools/make_goldens.py camera_replay patches the reference file when the goldens are made);
+    the oracle replays them (oracle_camera_probe) - the GLSL's sin() of a five-digit seed, which makes the two rnd() streams
+    differ (the statistics test above: rays up to 0.04-0.09 apart), drops out, and everything behind it - getScreen, getAA,
+    getDOF, the lens, the normalisation - agrees to float32 rounding: origins within 2 ulp, directions within 4 ulp of 1.
+    Four cameras: the bench's, the same through configs[4]'s aperture 0.1, the variant scene's, one looking straight down."""
+    z = np.load(os.path.join(GOLD, "glsl_camera_replay.npz"))
+    W, H = int(z["W"]), int(z["H"])
+    names = json.loads(str(z["names"]))
+    assert len(names) == 4
+    for n in names:
+        P, I, lens = ([float(x) for x in z[f"{n}_{k}"]] for k in ("P", "I", "lens"))
+        rec = z[f"{n}_rec"]
+        assert rec.shape == (H, W, 4) and 0.45 < rec.mean() < 0.55 and rec.std() > 0.25  # four uniform numbers per pixel
+        pos, d = O.camera_probe(W, H, P, I, float(z[f"{n}_fov"]), lens, rec)
+        assert np.abs(pos[..., :3] - z[f"{n}_pos"]).max() <= 2 * np.spacing(np.float32(np.abs(P).max())), n
+        assert np.abs(d[..., :3] - z[f"{n}_dir"]).max() <= 4 * np.spacing(np.float32(0.5)) * 2, n
+        # the lens really moves the origin: on the aperture's disc around P, and the replay matters
+        r = np.linalg.norm(pos[..., :3] - np.float32(P), axis=-1)
+        assert r.max() <= lens[1] * 1.0001 and r.max() > 0.9 * lens[1]
+        own, _ = O.camera(W, H, P, I, float(z[f"{n}_fov"]), lens, float(z[f"{n}_rand_base"]))
+        assert np.abs(own[..., :3] - z[f"{n}_pos"]).max() > 10 * np.spacing(np.float32(3.0))
+
+
 def _env_decode_bias(a, env_theta):
     """SwiftShader's RGBE decode relative to the exact one, on THIS environment map: its RGBA8 -> float conversion is
     ~6e-5 off, which envColor multiplies by 255 in the exponent (tracer.fs:412) - a deterministic factor (0.989 on the

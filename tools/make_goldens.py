@@ -479,6 +479,50 @@ def make_glsl(name="small"):
 
 # key -> (scene, W, H, spp, NUM_BOUNCES, P, I).  16 384 spp: GLSL-vs-GLSL noise floor ~0.015 (small) / ~0.026 (variant);
 # depth 8 is the BASELINE depth (tracer.fs:9 ships 4: kept for 'small_d4'); 'textured' has 16x16 image maps on every layer.
+def camera_probe_source(sel):
+    """The reference's camera.fs, cut and patched when the goldens are made (never stored): its rnd() renamed and wrapped
+    so that the four values it returns are kept, and main()'s two outputs carrying two of them (recv[2 sel], recv[2 sel + 1])
+    in their w components (the reference writes the constant 1 there)."""
+    import glsl_ref as G
+    src = G.read_shader("camera.fs")
+    assert src.count("float rnd()") == 1 and src.count("vec3 getScreen(") == 1
+    src = src.replace("float rnd()", "float rnd0()")
+    wrap = "float recv[4]; int reci = 0;\nfloat rnd() { float v = rnd0(); recv[reci] = v; reci++; return v; }\n\n"
+    src = src.replace("vec3 getScreen(", wrap + "vec3 getScreen(")
+    end = src.rstrip().rfind("}")
+    return src[:end] + f"  fragColor[0].w = recv[{2 * sel}]; fragColor[1].w = recv[{2 * sel + 1}];\n" + src[end:]
+
+
+def make_camera_replay():
+    """D1 with replay: camera.fs main() on SwiftShader with the values its rnd() returned recorded next to the rays
+    (two draws per case: the w components hold two values each), for the oracle to replay (oracle_camera_probe)."""
+    import glsl_ref as G
+    g = G.GlslRef()
+    W, H = 64, 40
+    g.target(W, H, replicate=False)
+    cam = dict(S.BUNNY_CAMERA)
+    cases = [("bunny", cam["P"], cam["I"], cam["aperture"], 1234.5), ("bunny_dof", cam["P"], cam["I"], 0.1, 977.25),
+             ("variant", [0.3, 1.2, 3.4], [-0.05, -0.3, -0.95], 0.02, 5000.75), ("down", [0.1, 3.0, 0.2], [0.02, -1.0, 0.05], 0.05, 0.5)]
+    out = dict(W=W, H=H, renderer=g.renderer, names=json.dumps([c[0] for c in cases]))
+    for name, P, I, ap, rb in cases:
+        lens = S.lens_features(cam["focal_depth"], ap)
+        rec = np.zeros((H, W, 4), np.float32)
+        rays = []
+        for sel in (0, 1):
+            g._ck(g.lib.gh_camera_program(G.read_shader("camera.vs").encode(), camera_probe_source(sel).encode()))
+            g.draw_camera(P, I, cam["fov_scale"], lens, rb)
+            pos, d = g.read_camera()
+            rec[..., 2 * sel], rec[..., 2 * sel + 1] = pos[..., 3], d[..., 3]
+            rays.append((pos[..., :3].copy(), d[..., :3].copy()))
+        assert np.array_equal(rays[0][0], rays[1][0]) and np.array_equal(rays[0][1], rays[1][1])  # the two draws are the same draw
+        assert (rec >= 0).all() and (rec < 1).all()
+        out.update({f"{name}_P": np.float32(P), f"{name}_I": np.float32(I), f"{name}_lens": np.float32(lens),
+                    f"{name}_fov": np.float32(cam["fov_scale"]), f"{name}_rand_base": np.float32(rb), f"{name}_rec": rec,
+                    f"{name}_pos": rays[0][0], f"{name}_dir": rays[0][1]})
+        print("camera replay", name, "rnd mean", rec.mean((0, 1)))
+    np.savez_compressed(os.path.join(GOLD, "glsl_camera_replay.npz"), **out)
+
+
 CONVERGED = {"small": ("small", 48, 32, 16384, 8, None, None),
              "small_d4": ("small", 48, 32, 16384, 4, None, None),
              "variant": ("variant", 48, 32, 16384, 8, [0.3, 1.2, 3.4], [-0.05, -0.3, -0.95]),
@@ -688,6 +732,8 @@ if __name__ == "__main__":
         elif w == "converged":
             for name in CONVERGED:
                 subprocess.check_call([sys.executable, "-u", os.path.abspath(__file__), "converged:" + name])
+        elif w == "camera_replay":
+            make_camera_replay()
         elif w == "textured":
             make_textured()
         elif w == "samplers":
