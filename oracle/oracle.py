@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+LIB_PATH = os.environ.get("FSPT_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # (FSPT_ORACLE_LIB: a sanitizer build, tools/sanitize_cpu.sh)
 _F = C.POINTER(C.c_float)
 
 
