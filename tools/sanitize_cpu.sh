@@ -32,3 +32,4 @@ FSPT_ORACLE_LIB=$D/liboracle_san.so python3 -m pytest tests/test_goldens.py -q -
   -k "d2 or d3 or sample or bounce or camera or bvh_test or rnd_replay"
 FSPT_LIB=$D/libfspt_san.so python3 -m pytest tests/test_goldens.py -q -p no:cacheprovider \
   -k "d0_native or mtl_parser or 70k_scene or scene_file_loader_matches"
+FSPT_LIB=$D/libfspt_san.so python3 tools/fuzz_builder.py
