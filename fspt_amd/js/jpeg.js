@@ -115,6 +115,7 @@ function decodeJpeg(buf) {
     if (buf[p] !== 8) throw new Error(buf[p] + '-bit JPEG is not decoded (8-bit only)');
     const h = u16(p + 1), w = u16(p + 3), n = buf[p + 5];
     if (!w || !h) throw new Error('JPEG with zero size');
+    if (w * h > (1 << 28)) throw new Error('JPEG of ' + w + ' x ' + h + ' pixels is not decoded (more than 2^28)');
     if (n !== 1 && n !== 3) throw new Error(n + '-component JPEG (CMYK / YCCK) is not decoded');
     if (len < 8 + 3 * n) throw new Error('truncated SOF segment');
     const comps = [];
