@@ -156,6 +156,9 @@ def parse_args(argv=None):
     ap.add_argument("--drain", type=int, default=-1, help="stream scheduler: drain iterations before the tail kernel (-1 = default)")
     ap.add_argument("--tail", type=int, default=-1, help="batch scheduler: the tail kernel takes over after this round (-1 adaptive, 0 never)")
     ap.add_argument("--primary-form", type=int, default=0, help="k_wf_primary's traversal phase: 1 one ray per lane, 2 per-lane refill, 0 = measured and chosen by the library")
+    ap.add_argument("--node-form", default=None,
+                    help="P,T,L[,below]: node form of the primary launch, the trace launches and the tail kernel (-1 library's choice, "
+                         "0 64-byte nodes, 1 two-level nodes); below = path count under which the library's choice for a trace launch is two-level")
     ap.add_argument("--trace-budget", type=int, default=-1, help="steps before a starved trace wave suspends its rays (0 = never, -1 = default)")
     ap.add_argument("--overlap", type=int, default=-1, help="stream scheduler: 1 = primary on a second HIP stream, 0 = one stream (-1 = default)")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
@@ -364,6 +367,9 @@ def main():
         pt.set_primary_form(args.primary_form)
     if args.trace_budget >= 0:
         pt.set_trace_budget(args.trace_budget)
+    if args.node_form:
+        nf = [int(x) for x in args.node_form.split(",")]
+        pt.set_node_form(nf[0], nf[1], nf[2], nf[3] if len(nf) > 3 else -1)
     if args.tail >= 0:
         pt.set_tail(args.tail)
     if args.pool or args.drain >= 0 or args.overlap >= 0:

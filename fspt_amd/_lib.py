@@ -102,6 +102,9 @@ SIGNATURES = {
     "fspt_draw": (C.c_int, [_VP, C.c_float, C.c_float, C.c_int, C.c_float, C.POINTER(C.c_uint8)]),
     "fspt_draw_scaled": (C.c_int, [_VP, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint8)]),
     "fspt_intersect": (C.c_int, [_VP, _F, C.c_uint32, _F, C.POINTER(C.c_int32), _U32, _U32]),
+    "fspt_intersect_form": (C.c_int, [_VP, C.c_int, _F, C.c_uint32, _F, C.POINTER(C.c_int32), _U32, _U32]),
+    "fspt_scene_two_level_nodes": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "fspt_target_set_node_form": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_int64]),
     "fspt_enable_counters": (C.c_int, [_VP, C.c_int]),
     "fspt_get_counters": (C.c_int, [_VP, C.POINTER(Counters)]),
     "fspt_counters_reset": (C.c_int, [_VP]),

@@ -48,7 +48,7 @@ struct fspt_scene {
   int device = 0;
   int num_cus = 256;
   fspt::DScene d{};
-  void *nodes = nullptr, *tris = nullptr /* leaf records */, *slot_tri = nullptr, *shade = nullptr, *atlas = nullptr, *atlas4 = nullptr, *tex_sets = nullptr, *env = nullptr, *bins = nullptr;
+  void *nodes = nullptr, *quads = nullptr /* two-level nodes, or NULL */, *tris = nullptr /* leaf records */, *slot_tri = nullptr, *shade = nullptr, *atlas = nullptr, *atlas4 = nullptr, *tex_sets = nullptr, *env = nullptr, *bins = nullptr;
   uint32_t depth = 0, n_nodes = 0, n_tris = 0, n_interior = 0;
   bool has_dielectric = false; // some triangle can refract (tracer.fs:481-488: unbounded path length)
 };
@@ -58,6 +58,16 @@ static const int WF_ARRAYS = 15;
 #define FSPT_SUSP_BUDGET 24 // profiles/r03/ab_trace_suspend_budget.log: 0 / 16 / 24 / 32 / 48 -> 3 883 / 3 938 / 3 940 / 3 935 / 3 921 Msamples/s in 20-step regions (same box, twice)
 #endif
 static const uint32_t ST_DEFAULT_SUSP_BUDGET = FSPT_SUSP_BUDGET;
+// Library's choice of the node form (fspt_target::node_form = -1), per kernel class; profiles/r05/ab_two_level_nodes*.log
+#ifndef FSPT_WIDE_PRIMARY
+#define FSPT_WIDE_PRIMARY 0
+#endif
+#ifndef FSPT_WIDE_TAIL
+#define FSPT_WIDE_TAIL 1
+#endif
+#ifndef FSPT_WIDE_TRACE_BELOW
+#define FSPT_WIDE_TRACE_BELOW 0u // paths
+#endif
 struct fspt_target {
   fspt_scene *scene = nullptr;
   uint32_t W = 0, H = 0;
@@ -137,6 +147,10 @@ struct fspt_target {
   bool prim_pending = false;
   uint32_t prim_pending_form = 0, prim_pending_ticks = 0;
   double prim_pending_samples = 0.0;
+  // Node form per kernel class (fspt_target_set_node_form): -1 the library's choice, 0 the 64-byte nodes, 1 the two-level
+  // nodes (fspt_device.hpp "quad"; only where the scene has them).  [0] primary launch, [1] trace launches, [2] tail kernel.
+  int node_form[3] = {-1, -1, -1};
+  uint32_t wide_trace_below = FSPT_WIDE_TRACE_BELOW; // library's choice for a trace launch: two-level nodes when it expects fewer paths than this
   int tail_round = -1;       // fspt_target_set_tail: -1 adaptive, 0 never, r >= 1 after round r
   float live_frac[80] = {};  // live paths after round r / slots of the batch, from the most recent finished batch
   bool live_known = false;
@@ -342,6 +356,48 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     int32_t lr[4] = {ref[l], ref[r], 0, 0};
     std::memcpy(n + 12, lr, 16);
   }
+  // ---- two-level nodes (fspt_device.hpp "quad"): the node records of both children side by side, one cache line ----
+  // Usable only when every interior node's box IS the union of its children's boxes, bit for bit (true for bvh.js trees:
+  // a node's box is built from its own triangles); checked here on the caller's arrays, no quads otherwise.
+  bool quad_ok = n_interior > 0;
+  std::vector<float> quads;
+  if (quad_ok) {
+    quads.assign((size_t)n_interior * 32, 0.0f);
+    auto bits = [](float x) { uint32_t u; std::memcpy(&u, &x, 4); return u; };
+    for (uint32_t i = 0; i < N && quad_ok; ++i) {
+      if (word(i, 2) > -1) continue;
+      const int32_t ch[2] = {word(i, 0), word(i, 1)};
+      float *q = &quads[(size_t)ref[i] * 32];
+      int32_t refs[8] = {fspt::REF_SENTINEL, fspt::REF_SENTINEL, ref[ch[0]], ref[ch[1]], fspt::REF_SENTINEL, fspt::REF_SENTINEL, 0, 0};
+      for (int k = 0; k < 2 && quad_ok; ++k) {
+        const int32_t c = ch[k];
+        float *part = q + 16 * k;
+        const float *cb = desc->bvh + (size_t)c * 9 + 3; // the child's own box: min.xyz max.xyz
+        if (word(c, 2) > -1) { // a leaf: its own box, twice
+          part[0] = part[4] = cb[0]; part[1] = part[5] = cb[1]; part[2] = part[6] = cb[3]; part[3] = part[7] = cb[4];
+          part[8] = part[10] = cb[2]; part[9] = part[11] = cb[5];
+        } else {
+          const float *cn = &nodes[(size_t)ref[c] * 16];
+          std::memcpy(part, cn, 48);
+          std::memcpy(&refs[4 * k], cn + 12, 8);
+        }
+        // box(c) == union of the two boxes of its part, exactly?  (the comparison the device's v_min / v_max make; a pair
+        // of candidates that compare equal must be the same bits: -0 / +0)
+        const float lo[3][2] = {{part[0], part[4]}, {part[1], part[5]}, {part[8], part[10]}};
+        const float hi[3][2] = {{part[2], part[6]}, {part[3], part[7]}, {part[9], part[11]}};
+        for (int a = 0; a < 3 && quad_ok; ++a) {
+          const float mn = lo[a][0] < lo[a][1] ? lo[a][0] : lo[a][1], mx = hi[a][0] > hi[a][1] ? hi[a][0] : hi[a][1];
+          if (std::isnan(lo[a][0]) || std::isnan(lo[a][1]) || std::isnan(hi[a][0]) || std::isnan(hi[a][1])) quad_ok = false;
+          if (lo[a][0] == lo[a][1] && bits(lo[a][0]) != bits(lo[a][1])) quad_ok = false;
+          if (hi[a][0] == hi[a][1] && bits(hi[a][0]) != bits(hi[a][1])) quad_ok = false;
+          if (bits(mn) != bits(cb[a]) || bits(mx) != bits(cb[3 + a])) quad_ok = false;
+        }
+      }
+      std::memcpy(q + 12, &refs[0], 16);
+      std::memcpy(q + 28, &refs[4], 16);
+    }
+    if (!quad_ok) quads.clear();
+  }
   if (max_depth + 1 > 64 || max_depth + 1 > fspt::wf_max_stack_entries()) {
     // the reference's stack is int[64] (tracer.fs:368); here one entry per level, in LDS (all 64 fit: 128 KB of the CU's
     // 160 KB under the 512-thread primary launch)
@@ -427,6 +483,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   };
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = upload(&s->nodes, nodes.data(), nodes.size() * 4);
+  if (e == hipSuccess && quad_ok) e = upload(&s->quads, quads.data(), quads.size() * 4);
   if (e == hipSuccess) e = upload(&s->tris, leaves.data(), leaves.size() * 4);
   if (e == hipSuccess) e = upload(&s->slot_tri, slot_tri.data(), slot_tri.size() * 4);
   if (e == hipSuccess) e = upload(&s->shade, shade.data(), shade.size() * 4);
@@ -544,6 +601,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
     return FSPT_E_HIP;
   }
   s->d.nodes = (const float4 *)s->nodes;
+  s->d.quads = (const float4 *)s->quads; // NULL when the boxes are not unions (see above)
   s->d.leaves = (const float *)s->tris;
   s->d.slot_tri = (const uint32_t *)s->slot_tri;
   s->d.hitrec = (const float4 *)s->shade;
@@ -574,7 +632,7 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
 int fspt_scene_destroy(fspt_scene *s) {
   if (!s) return FSPT_OK;
   hipSetDevice(s->device);
-  hipFree(s->nodes); hipFree(s->tris); hipFree(s->slot_tri); hipFree(s->shade); hipFree(s->atlas); hipFree(s->atlas4); hipFree(s->tex_sets); hipFree(s->env); hipFree(s->bins);
+  hipFree(s->nodes); hipFree(s->quads); hipFree(s->tris); hipFree(s->slot_tri); hipFree(s->shade); hipFree(s->atlas); hipFree(s->atlas4); hipFree(s->tex_sets); hipFree(s->env); hipFree(s->bins);
   delete s;
   return FSPT_OK;
 }
@@ -961,6 +1019,19 @@ static uint32_t wf_tail_round(const fspt_target *t, uint64_t slots, uint32_t las
   return last + 1;
 }
 
+// Which node form a launch of kernel class `kind` over (an expected) `paths` paths walks: WfP::wide's bit for it.
+static uint32_t wide_bit(const fspt_target *t, int kind, double paths) {
+  if (!t->scene->quads || t->count) return 0u;
+  const int slot = kind == fspt::WF_K_PRIMARY ? 0 : kind == fspt::WF_K_TRACE ? 1 : kind == fspt::WF_K_TAIL ? 2 : -1;
+  if (slot < 0) return 0u;
+  bool on;
+  if (t->node_form[slot] >= 0) on = t->node_form[slot] != 0;
+  else if (slot == 0) on = FSPT_WIDE_PRIMARY != 0;
+  else if (slot == 2) on = FSPT_WIDE_TAIL != 0;
+  else on = paths >= 0.0 && paths < (double)t->wide_trace_below;
+  return on ? 1u << kind : 0u;
+}
+
 // n_ticks ticks through the wavefront pipeline.  rays_from_buffers: two-call form (n_ticks == 1).
 static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
                             const float *rb_cam, const float *rb_trace, bool rays_from_buffers) {
@@ -1043,6 +1114,7 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     if (t->primary_form == 1 || t->primary_form == 2) form = (uint32_t)t->primary_form;
     else if (t->count == 0) form = prim_choose(t, nbt); // (the counting variants are not what is timed: form 1 unless forced)
     p.primary_r = form;
+    p.wide = wide_bit(t, fspt::WF_K_PRIMARY, -1.0) | wide_bit(t, fspt::WF_K_TAIL, -1.0);
     const bool time_primary = t->count == 0 && !t->prim_pending;
     bool prev_trace_suspends = false; // (no carry launch behind a trace launch that cannot have suspended anything)
     for (uint32_t r = 1; r <= last && r <= tail; ++r) {
@@ -1061,6 +1133,9 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
         // again from the root.  Letting them finish in the trace launch, as rounds 3 and early 4 did, kept the chip
         // waiting for a handful of rays: 1 M-triangle scene trace 0.249 -> 0.215 ms per tick, a single tick of C2 0.27 ->
         // 0.18, profiles/r04/ab_last_trace_suspends.log)
+        // a trace launch expected to be small (the previous batch's live-path counts) is a bundle of dependent chains
+        p.wide = (p.wide & ~(1u << fspt::WF_K_TRACE)) |
+                 wide_bit(t, fspt::WF_K_TRACE, t->live_known && r < 80 ? (double)t->live_frac[r] * (double)nbt * (double)work_total : -1.0);
         if ((rc = launch(fspt::WF_K_TRACE))) return rc;
         prev_trace_suspends = p.susp_budget != 0;
       }
@@ -1205,6 +1280,7 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
   base.n_owned_tiles = tp.n_owned_tiles;
   base.gen_rays = rays_from_buffers ? 0u : 1u;
   base.primary_r = 1u; // (iterations of varying size: the plain form)
+  base.wide = wide_bit(t, fspt::WF_K_PRIMARY, -1.0) | wide_bit(t, fspt::WF_K_TAIL, -1.0);
 
   // everything already queued on the target's stream (clear, ray upload, earlier renders) comes first
   HIP_TRY(hipEventRecord(t->ev_start, t->stream));
@@ -1247,6 +1323,7 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
       p.counts = ln.counts; p.heads = ln.heads; p.ctl = ln.ctl;
       p.work_total = units * 64u; p.n_batch = nbt; p.first_tick = first_tick + done;
       p.ring_slots = pl.ring_slots; p.cap = pl.cap; p.take_max = pl.take_max;
+      p.wide |= wide_bit(t, fspt::WF_K_TRACE, (double)pl.cap); // (every trace launch of a run is about pool-sized)
       if (susp_run && (rc = susp_ensure(t, ln, pl.cap, &susp_run))) return rc;
       p.susp[0] = susp_run ? ln.susp[0] : nullptr; p.susp[1] = susp_run ? ln.susp[1] : nullptr; p.susp_stride = ln.susp_stride; p.susp_budget = susp_run ? t->susp_budget : 0u;
       p.serial = overlap ? 0u : 1u;
@@ -1639,6 +1716,17 @@ int fspt_target_get_primary_form(fspt_target *t, uint32_t batch_ticks, int *form
   return FSPT_OK;
 }
 
+int fspt_target_set_node_form(fspt_target *t, int primary, int trace, int tail, int64_t trace_below) {
+  if (!t) { fspt_set_error("fspt_target_set_node_form: NULL target"); return FSPT_E_INVALID; }
+  const int v[3] = {primary, trace, tail};
+  for (int x : v) if (x < -1 || x > 1) { fspt_set_error("fspt_target_set_node_form: form %d (want -1, 0 or 1)", x); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
+  for (int k = 0; k < 3; ++k) t->node_form[k] = v[k];
+  if (trace_below >= 0) t->wide_trace_below = trace_below > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)trace_below;
+  t->prim_ms.clear(); // the primary-form measurements were taken with the other node form
+  return FSPT_OK;
+}
+
 int fspt_target_set_tail(fspt_target *t, int round) {
   if (!t) { fspt_set_error("fspt_target_set_tail: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
@@ -1928,7 +2016,20 @@ int fspt_multi_last_gather_bytes(fspt_multi *m, uint64_t *bytes) {
 // ---------------------------------------------------------------------------
 int fspt_intersect(fspt_scene *s, const float *rays, uint32_t n, float *t_out, int32_t *index_out, uint32_t *steps_out,
                    uint32_t *leaves_out) {
+  return fspt_intersect_form(s, 0, rays, n, t_out, index_out, steps_out, leaves_out);
+}
+
+int fspt_scene_two_level_nodes(const fspt_scene *s, int *present, uint64_t *bytes) {
+  if (!s) { fspt_set_error("fspt_scene_two_level_nodes: NULL argument"); return FSPT_E_INVALID; }
+  if (present) *present = s->quads != nullptr;
+  if (bytes) *bytes = s->quads ? (uint64_t)s->n_interior * fspt::QUAD_F4 * 16u : 0u;
+  return FSPT_OK;
+}
+
+int fspt_intersect_form(fspt_scene *s, int two_level, const float *rays, uint32_t n, float *t_out, int32_t *index_out, uint32_t *steps_out,
+                        uint32_t *leaves_out) {
   if (!s || (n && (!rays || !t_out || !index_out))) { fspt_set_error("fspt_intersect: NULL argument"); return FSPT_E_INVALID; }
+  if (two_level && !s->quads) { fspt_set_error("fspt_intersect_form: the scene has no two-level nodes (its boxes are not the unions of their children's)"); return FSPT_E_INVALID; }
   if (n == 0) return FSPT_OK;
   HIP_TRY(hipSetDevice(s->device));
   float *d_rays = nullptr, *d_t = nullptr;
@@ -1944,6 +2045,7 @@ int fspt_intersect(fspt_scene *s, const float *rays, uint32_t n, float *t_out, i
   if (e == hipSuccess) {
     fspt::IntersectP p{};
     p.scene = s->d; p.rays = d_rays; p.n = n; p.t_out = d_t; p.index_out = d_i; p.steps_out = d_s; p.leaves_out = d_l;
+    p.wide = two_level ? 1u : 0u;
     e = fspt::launch_intersect(p, nullptr);
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();

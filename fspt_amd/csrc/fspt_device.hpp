@@ -41,6 +41,7 @@ constexpr uint32_t TEXSET_SEPARATE = 1u; // image layers fetched from single-lay
 constexpr uint32_t TEXSET_QUAD = 2u;     // the four layers interleaved texel by texel: 4 x 2-texel tiles of 16-byte texels
 
 constexpr int NODE_F4 = 4;   // 64-byte two-child node = 4 x float4
+constexpr int QUAD_F4 = 8;   // 128-byte two-LEVEL node (below) = 8 x float4 = one cache line
 constexpr int TRI_FLOATS = 9;  // pre-edged triangle: v1, e1 = v2 - v1, e2 = v3 - v1 (tracer.fs:301-302 precomputed)
 constexpr int HITREC_F4 = 12; // 192-byte hit record (shading) = 12 x float4 = exactly 3 cache lines
 
@@ -49,6 +50,21 @@ constexpr int HITREC_F4 = 12; // 192-byte hit record (shading) = 12 x float4 = e
 //                f4[2] = lmin.z lmax.z rmin.z rmax.z   f4[3] = (int) left_ref right_ref 0 0
 //   (tracer.fs:374-378 fetches the header of `current` and then, dependently,
 //    the boxes of both children: 3 round trips; here one.)
+// Two-level node ("quad", 128 B = ONE cache line, one per interior node N with children L, R; DScene::quads): what a lane
+//   needs to take TWO of the reference's traversal steps (tracer.fs:372-392 at idx = N, then at idx = the child it
+//   descends into) on one memory round trip - for the launches that are bundles of DEPENDENT chains (tail kernel, small
+//   trace launches, the 1 M-triangle scene), where a step costs a cache-miss latency, not a request slot:
+//                f4[0..2] = the node record of L (the boxes of L's children LL, LR, in the layout above)
+//                f4[3]    = (int) LL_ref LR_ref L_ref R_ref
+//                f4[4..6] = the node record of R (boxes of RL, RR)      f4[7] = (int) RL_ref RR_ref 0 0
+//   The boxes of L and R themselves - what the step at N tests - are NOT stored: bvh.js builds every node's box from ITS
+//   triangles' vertices (BoundingBox.addNode, bvh.js:120-126), so box(L) = union(box(LL), box(LR)) exactly, in binary32
+//   (min / max are exact and rounding is monotone); the lane derives them with 12 v_min / v_max.  fspt_scene_create
+//   VERIFIES that identity bit for bit on every interior node of the arrays it is given and builds no quads otherwise
+//   (DScene::quads = NULL: every launch then uses the 64-byte nodes).  A child that is a leaf has no children: its part
+//   holds its own box twice (the union is the box).  Same nodes tested against the same t in the same order, the far
+//   child pushed as a child, the far grandchild as a grandchild: the node sequence, the counters and every result are
+//   those of the one-level walk.
 // Leaf record (LEAF_SIZE x 36 B = 144 B for LEAF_SIZE 4): the LEAF_SIZE consecutive triangles the reference's processLeaf
 //   reads from the leaf's first one (tracer.fs:355-364 - a leaf with fewer triangles reads on into its successors, the
 //   last leaves into the "-1" padding, main.js:150-152), pre-edged, COMPONENT-major: floats [c * LEAF_SIZE + i] =
@@ -62,6 +78,7 @@ constexpr int HITREC_F4 = 12; // 192-byte hit record (shading) = 12 x float4 = e
 //   layer ids (main.js:377-379); 46 ior; 47 dielectric.
 struct DScene {
   const float4 *nodes;
+  const float4 *quads;  // two-level nodes, indexed like `nodes` (NULL: the scene's boxes are not unions of their children's)
   const float *leaves;  // leaf records (see above)
   const uint32_t *slot_tri; // leaf slot -> triangle index
   const float4 *hitrec; // 12 x float4 per triangle
@@ -111,6 +128,7 @@ struct IntersectP {
   DScene scene;
   const float *rays; // 6 floats per ray
   uint32_t n;
+  uint32_t wide;     // walk the two-level nodes (scene.quads must exist)
   float *t_out;
   int *index_out;
   uint32_t *steps_out;
@@ -234,6 +252,7 @@ struct WfP {
   int *susp[2];         // suspended-traversal records: trace(i) writes susp[cnt_out & 1], resumes susp[cnt_in & 1]
   uint32_t susp_stride; // ints per record (WF_SUSP_HEADER + stack entries, a multiple of 4)
   uint32_t susp_budget; // traversal steps a wave walks on after its last refill before it suspends (0: never)
+  uint32_t wide;        // bit k: kernel class k (WF_K_PRIMARY / WF_K_TRACE / WF_K_TAIL) walks the two-level nodes (scene.quads; same results)
   uint32_t primary_r;   // k_wf_primary: 1 = one traversal per lane, 2 = per-lane refill over 2 x 64 samples per wave (same results)
   uint32_t W, H;
   uint32_t vw, vh; // viewport, as in TraceP

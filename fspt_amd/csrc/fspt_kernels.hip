@@ -78,6 +78,53 @@ FM_DEV int2 node_refs(const float4 *n) {
   return make_int2((int)(rr & 0xffffffffll), (int)(rr >> 32));
 }
 
+// One step of intersectScene at an interior node (tracer.fs:382-401) once the two entry distances are known: descend
+// into the nearer child that is hit (the other one, if hit too, goes on the stack), or pop.  Returns which child the
+// walk descends into: 0 left, 1 right, -1 neither (cur then holds the popped reference).
+FM_DEV int node_decide(float tl, float tr, int refL, int refR, float t, int *stack, int &sp, int &cur) {
+  const bool hl = tl < t, hr = tr < t;
+  const bool swap = tl > tr; // tracer.fs:384: right first only when strictly nearer
+  if (hl && hr) {
+    stack[sp * WAVE] = swap ? refL : refR;
+    sp++;
+    cur = swap ? refR : refL;
+    return swap ? 1 : 0;
+  }
+  if (hl) { cur = refL; return 0; }
+  if (hr) { cur = refR; return 1; }
+  if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
+  else cur = REF_SENTINEL;
+  return -1;
+}
+// TWO steps on one two-level node (fspt_device.hpp "quad"; the eight loads are the caller's: global or LDS): the step at
+// the node itself - its children's boxes are the unions of the stored grandchildren's, derived exactly - and, when the
+// walk descends into a child that is an interior node, that child's step right away: result.t has not changed in
+// between (no leaf was visited), so it is the test the one-level walk makes after its next fetch.  `steps` counts the
+// reference's loop iterations exactly as the one-level walk does.
+template <bool COUNT>
+FM_DEV void quad_step(float4 a0, float4 a1, float4 a2, int4 ar, float4 b0, float4 b1, float4 b2, int2 br, V3 o, V3 inv, float t,
+                      int *stack, int &sp, int &cur, uint32_t &steps) {
+  const float4 n0 = make_float4(min_(a0.x, a1.x), min_(a0.y, a1.y), max_(a0.z, a1.z), max_(a0.w, a1.w)); // box(L) = box(LL) U box(LR)
+  const float4 n1 = make_float4(min_(b0.x, b1.x), min_(b0.y, b1.y), max_(b0.z, b1.z), max_(b0.w, b1.w)); // box(R)
+  const float4 n2 = make_float4(min_(a2.x, a2.z), max_(a2.y, a2.w), min_(b2.x, b2.z), max_(b2.y, b2.w));
+  float tl, tr;
+  node_test(n0, n1, n2, o, inv, tl, tr);
+  const int side = node_decide(tl, tr, ar.z, ar.w, t, stack, sp, cur);
+  if (side < 0 || cur < 0) return; // popped, or the child is a leaf (its record is the next fetch)
+  if (COUNT) steps++;
+  const bool right = side != 0;
+  const float4 c0 = right ? b0 : a0, c1 = right ? b1 : a1, c2 = right ? b2 : a2;
+  node_test(c0, c1, c2, o, inv, tl, tr);
+  node_decide(tl, tr, right ? br.x : ar.x, right ? br.y : ar.y, t, stack, sp, cur);
+}
+FM_DEV void quad_load(const float4 *q, float4 &a0, float4 &a1, float4 &a2, int4 &ar, float4 &b0, float4 &b1, float4 &b2, int2 &br) {
+  a0 = q[0]; a1 = q[1]; a2 = q[2];
+  const float4 r = q[3];
+  ar = make_int4(__float_as_int(r.x), __float_as_int(r.y), __float_as_int(r.z), __float_as_int(r.w));
+  b0 = q[4]; b1 = q[5]; b2 = q[6];
+  br = node_refs(q + 4);
+}
+
 // rayTriangleIntersect (tracer.fs:300-315) on a pre-edged triangle; the early
 // returns become one predicate with the same NaN behaviour.
 FM_DEV float ray_tri(V3 o, V3 d, V3 v1, V3 e1, V3 e2) {
@@ -153,7 +200,8 @@ struct Counters {
 // the wave's LDS stack (entry k at stack[k*64]).
 // ---------------------------------------------------------------------------
 // ANYHIT: ray A stops at its first hit (only `shadow.index == -1` is consumed, tracer.fs:502).
-template <bool COUNT, bool ANYHIT>
+// WIDE: walk the two-level nodes (S.quads, must be non-NULL): two steps per memory round trip, same walk.
+template <bool COUNT, bool ANYHIT, bool WIDE = false>
 FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 dB, int &hitA, float &tB, int &hitB,
                        Counters &cnt) {
   int slot = hasA ? 0 : 1;
@@ -165,13 +213,19 @@ FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 d
   int sp = 0;
   hitA = -1;
   if (COUNT) cnt.rays++;
-  const float4 *__restrict__ nodes = S.nodes;
+  const float4 *__restrict__ nodes = WIDE ? S.quads : S.nodes;
   const float *__restrict__ leaves = S.leaves;
   const uint32_t leaf_size = S.leaf_size;
   while (true) {
     // ---- interior nodes ----------------------------------------------------
     while (cur >= 0) {
       if (COUNT) cnt.steps++;
+      if constexpr (WIDE) {
+        float4 a0, a1, a2, b0, b1, b2; int4 ar; int2 br;
+        quad_load(nodes + (size_t)cur * QUAD_F4, a0, a1, a2, ar, b0, b1, b2, br);
+        quad_step<COUNT>(a0, a1, a2, ar, b0, b1, b2, br, o, inv, t, stack, sp, cur, cnt.steps);
+        continue;
+      }
       const float4 *n = nodes + (size_t)cur * NODE_F4;
       float4 n0 = n[0], n1 = n[1], n2 = n[2];
       const int2 n3 = node_refs(n);
@@ -229,16 +283,22 @@ FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 d
 // where it stands until its ray is finished (cur == REF_SENTINEL) or it has done `budget` loop iterations in this call;
 // the call returns when no lane has anything left to do within its budget.  `anyhit`: stop at the first hit (NEE
 // shadow rays, tracer.fs:502).  Same node sequence and arithmetic as trace_rays, whatever the slicing.
-template <bool COUNT>
+template <bool COUNT, bool WIDE = false>
 FM_DEV void trace_slice(const DScene &S, int *stack, V3 o, V3 d, V3 inv /* 1 / d */, bool anyhit, int &cur, int &sp, float &t, int &hit,
-                        uint32_t budget, uint32_t &n /* loop iterations this lane has used of the budget */, Counters &cnt) {
-  const float4 *__restrict__ nodes = S.nodes;
+                        uint32_t budget, uint32_t &n /* loop iterations (memory round trips) this lane has used of the budget */, Counters &cnt) {
+  const float4 *__restrict__ nodes = WIDE ? S.quads : S.nodes;
   const float *__restrict__ leaves = S.leaves;
   const uint32_t leaf_size = S.leaf_size;
   while (cur != REF_SENTINEL && n < budget) {
     while (cur >= 0 && n < budget) {
       if (COUNT) cnt.steps++;
       ++n;
+      if constexpr (WIDE) {
+        float4 a0, a1, a2, b0, b1, b2; int4 ar; int2 br;
+        quad_load(nodes + (size_t)cur * QUAD_F4, a0, a1, a2, ar, b0, b1, b2, br);
+        quad_step<COUNT>(a0, a1, a2, ar, b0, b1, b2, br, o, inv, t, stack, sp, cur, cnt.steps);
+        continue;
+      }
       const float4 *nd = nodes + (size_t)cur * NODE_F4;
       float4 n0 = nd[0], n1 = nd[1], n2 = nd[2];
       const int2 n3 = node_refs(nd);
@@ -1069,7 +1129,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_carry(const WfP p) {
 #ifndef WF_TRACE_FINE
 #define WF_TRACE_FINE 8u // the last 1/8 of a launch's paths are dealt out in 64-path chunks
 #endif
-template <bool COUNT, bool ANYHIT>
+// WIDE: the interior loop walks the two-level nodes (fspt_device.hpp "quad"): two of the reference's steps per memory
+// round trip at twice the lane-requests per fetch - for the launches that are bound by the LATENCY of their rays' dependent
+// chains (few paths; a scene that does not fit the L2), not by the request rate of the vector-memory pipeline.
+template <bool COUNT, bool ANYHIT, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(const WfP p) {
   extern __shared__ int lds_stack[];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -1079,7 +1142,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   // (a suspended traversal's record carries it along)
   const uint32_t sn = S.stack_n + 4u; // + 3: the extension ray's direction while the shadow ray is traced
   int *stack = lds_stack + (size_t)wave * sn * WAVE + lane;
-  const float4 *__restrict__ nodes = S.nodes;
+  constexpr int REC_F4 = WIDE ? QUAD_F4 : NODE_F4;
+  const float4 *__restrict__ nodes = WIDE ? S.quads : S.nodes;
   const float *__restrict__ leaves = S.leaves;
   const uint32_t leaf_size = S.leaf_size;
   const WfSet st = p.set[p.set_out];
@@ -1098,7 +1162,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
   const int n_top = (int)p.lds_top;
   float4 *top = reinterpret_cast<float4 *>(lds_stack + (size_t)WAVES_PER_BLOCK * sn * WAVE);
   if (n_top > 0) {
-    for (int i = threadIdx.x; i < n_top * NODE_F4; i += BLOCK_THREADS) top[i] = nodes[i];
+    for (int i = threadIdx.x; i < n_top * REC_F4; i += BLOCK_THREADS) top[i] = nodes[i];
     __syncthreads();
   }
 
@@ -1247,6 +1311,26 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
 #endif
       if (cur >= 0) {
       if (COUNT) c_steps++;
+      if constexpr (WIDE) {
+        float4 a0, a1, a2, b0, b1, b2; int4 ar; int2 br;
+        if (cur < n_top) {
+          if (COUNT) c_lds++;
+          typedef float lds_f4 __attribute__((ext_vector_type(4)));
+          typedef int lds_i4 __attribute__((ext_vector_type(4)));
+          typedef int lds_i2 __attribute__((ext_vector_type(2)));
+          const __attribute__((address_space(3))) lds_f4 *n =
+              (const __attribute__((address_space(3))) lds_f4 *)(top + cur * QUAD_F4);
+          const lds_f4 x0 = n[0], x1 = n[1], x2 = n[2], y0 = n[4], y1 = n[5], y2 = n[6];
+          const lds_i4 xr = *(const __attribute__((address_space(3))) lds_i4 *)(n + 3);
+          const lds_i2 yr = *(const __attribute__((address_space(3))) lds_i2 *)(n + 7);
+          a0 = make_float4(x0.x, x0.y, x0.z, x0.w); a1 = make_float4(x1.x, x1.y, x1.z, x1.w); a2 = make_float4(x2.x, x2.y, x2.z, x2.w);
+          b0 = make_float4(y0.x, y0.y, y0.z, y0.w); b1 = make_float4(y1.x, y1.y, y1.z, y1.w); b2 = make_float4(y2.x, y2.y, y2.z, y2.w);
+          ar = make_int4(xr.x, xr.y, xr.z, xr.w); br = make_int2(yr.x, yr.y);
+        } else {
+          quad_load(nodes + (size_t)cur * QUAD_F4, a0, a1, a2, ar, b0, b1, b2, br);
+        }
+        quad_step<COUNT>(a0, a1, a2, ar, b0, b1, b2, br, o, inv, t, stack, sp, cur, c_steps);
+      } else {
       float4 n0, n1, n2;
       int2 n3;
       if (cur < n_top) {
@@ -1285,6 +1369,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(cons
       } else {
         cur = REF_SENTINEL;
       }
+      } // !WIDE
       }
       // (checked AFTER the step: every pass of the outer loop moves its rays on, also the ones that may not be parked)
       if (starved && ++starve >= p.susp_budget) break;
@@ -1413,7 +1498,7 @@ FM_DEV void flush_counters(const Counters &cnt, unsigned long long *counters, in
 #ifndef WF_PRIMARY_SLICE
 #define WF_PRIMARY_SLICE 8u // traversal steps between two looks at the wave's sample counter
 #endif
-template <bool COUNT, bool LDSTAB, int R>
+template <bool COUNT, bool LDSTAB, int R, bool WIDE = false>
 __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_primary(const WfP p) {
   extern __shared__ int lds_dyn[]; // the waves' traversal stacks | [tables] | [camera rays and hits of the block iteration]
   constexpr int NW = WF_PRIMARY_THREADS / WAVE;
@@ -1476,7 +1561,7 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
         }
         if (COUNT) cnt.samples++;
         int hitA;
-        trace_rays<COUNT, false>(S, stack, o1, false, d1, d1, hitA, t1, hit1, cnt);
+        trace_rays<COUNT, false, WIDE>(S, stack, o1, false, d1, d1, hitA, t1, hit1, cnt);
       }
     } else {
       // ---- T: the wave's R x 64 samples of this block iteration, with per-lane refill ---------------------------------
@@ -1540,7 +1625,7 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
         }
         if (__ballot(have) == 0ull) { if (next >= w_hi) break; else continue; }
         uint32_t used = 0;
-        trace_slice<COUNT>(S, stack, o, d, inv, false, cur, sp, t, hit, WF_PRIMARY_SLICE, used, cnt);
+        trace_slice<COUNT, WIDE>(S, stack, o, d, inv, false, cur, sp, t, hit, WF_PRIMARY_SLICE, used, cnt);
       }
     }
     // advance_path: a hit is shaded (and the path lives on) unless the bounce budget is already used up
@@ -1738,7 +1823,7 @@ FM_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src, WAVE), __shfl(v.y, s
 // sample into the pixel's accumulator value in its registers, in tick order (tracer.fs:515-517 is order-dependent) -
 // nothing of such a unit goes through the fin ring, and the run's last resolve ends where this launch began
 // (WfStreamCtl::hist of the last plan).
-template <bool COUNT, bool ANYHIT, bool GEN>
+template <bool COUNT, bool ANYHIT, bool GEN, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const WfP p) {
   extern __shared__ int lds_stack[];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -1876,8 +1961,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
     }
     if (r_state != RAY_GOING) r_cur = REF_SENTINEL;
     uint32_t used = 0;
-    trace_slice<COUNT>(S, stack, o, d, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), ANYHIT && !is_main, r_cur, r_sp, r_t, r_hit, WF_TAIL_SLICE,
-                       used, cnt);
+    trace_slice<COUNT, WIDE>(S, stack, o, d, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), ANYHIT && !is_main, r_cur, r_sp, r_t, r_hit, WF_TAIL_SLICE,
+                             used, cnt);
     if (r_state == RAY_GOING && r_cur == REF_SENTINEL) r_state = RAY_DONE;
     // a pair is ready when its extension ray is done and its shadow ray is done or was never cast
     const int st_other = __shfl(r_state, lane | 1, WAVE);
@@ -2083,7 +2168,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_intersect(const IntersectP p)
   Counters cnt = {0, 0, 0, 0, 0, 0};
   int hitA, hitB;
   float tB;
-  trace_rays<true, false>(p.scene, stack, o, false, d, d, hitA, tB, hitB, cnt);
+  if (p.wide) trace_rays<true, false, true>(p.scene, stack, o, false, d, d, hitA, tB, hitB, cnt);
+  else trace_rays<true, false>(p.scene, stack, o, false, d, d, hitA, tB, hitB, cnt);
   p.t_out[i] = tB;
   p.index_out[i] = slot_to_tri(p.scene, hitB); // the reference's triangle index (tracer.fs:360)
   if (p.steps_out) p.steps_out[i] = cnt.steps;
@@ -2195,6 +2281,8 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
     hipLaunchKernelGGL(k_wf_carry, dim3(64), dim3(BLOCK_THREADS), 0, stream, p);
     return hipGetLastError();
   }
+  // two-level nodes (WfP::wide, one bit per kernel class): production kernels only, and only when the scene has them
+  const bool wide = count == 0 && p.scene.quads != nullptr && kernel < WF_K_KINDS && ((p.wide >> kernel) & 1u) != 0u;
   if (kernel == WF_K_TRACE) {
     // persistent: the grid only has to fill the machine; the pool heads balance the work
     uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
@@ -2207,35 +2295,38 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
       if (blocks > WF_TRACE_BLOCKS_PER_CU) blocks = WF_TRACE_BLOCKS_PER_CU;
       if (blocks < 1) blocks = 1;
       size_t spare = (LDS_CU / blocks - lds) & ~(size_t)255; // allocation granularity
-      uint32_t fit = (uint32_t)(spare / (NODE_F4 * sizeof(float4)));
+      const size_t rec = (size_t)(wide ? QUAD_F4 : NODE_F4) * sizeof(float4);
+      uint32_t fit = (uint32_t)(spare / rec);
       q.lds_top = WF_TRACE_LDS_TOP ? min(min(fit, p.scene.n_top), (uint32_t)WF_TRACE_LDS_TOP) : 0u;
-      lds += (size_t)q.lds_top * NODE_F4 * sizeof(float4);
+      lds += (size_t)q.lds_top * rec;
     }
-#define FSPT_LAUNCH_TRACE(C, A)                                                                            \
+#define FSPT_LAUNCH_TRACE(C, A, Wd)                                                                        \
     do {                                                                                                     \
-      if ((e = allow_lds(k_wf_trace<C, A>, lds)) != hipSuccess) return e;                                    \
-      hipLaunchKernelGGL((k_wf_trace<C, A>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, q);               \
+      if ((e = allow_lds(k_wf_trace<C, A, Wd>, lds)) != hipSuccess) return e;                                \
+      hipLaunchKernelGGL((k_wf_trace<C, A, Wd>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, q);           \
     } while (0)
-    if (count == 1) FSPT_LAUNCH_TRACE(true, false);
-    else if (count == 2) FSPT_LAUNCH_TRACE(true, true);
-    else FSPT_LAUNCH_TRACE(false, true);
+    if (count == 1) FSPT_LAUNCH_TRACE(true, false, false);
+    else if (count == 2) FSPT_LAUNCH_TRACE(true, true, false);
+    else if (wide) FSPT_LAUNCH_TRACE(false, true, true);
+    else FSPT_LAUNCH_TRACE(false, true, false);
 #undef FSPT_LAUNCH_TRACE
   } else if (kernel == WF_K_TAIL) {
     uint32_t grid = min((2u * total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * (WF_TAIL_WAVES > 4 ? WF_TAIL_WAVES : 4)); // two lanes per path
     size_t lds = stack_bytes(p.scene);
-#define FSPT_LAUNCH_TAIL(C, A)                                                                             \
+#define FSPT_LAUNCH_TAIL(C, A, Wd)                                                                         \
     do {                                                                                                     \
       if (p.ctl && p.finish) {                                                                               \
-        if ((e = allow_lds(k_wf_tail<C, A, true>, lds)) != hipSuccess) return e;                             \
-        hipLaunchKernelGGL((k_wf_tail<C, A, true>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);        \
+        if ((e = allow_lds(k_wf_tail<C, A, true, Wd>, lds)) != hipSuccess) return e;                         \
+        hipLaunchKernelGGL((k_wf_tail<C, A, true, Wd>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);    \
       } else {                                                                                               \
-        if ((e = allow_lds(k_wf_tail<C, A, false>, lds)) != hipSuccess) return e;                            \
-        hipLaunchKernelGGL((k_wf_tail<C, A, false>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);       \
+        if ((e = allow_lds(k_wf_tail<C, A, false, Wd>, lds)) != hipSuccess) return e;                        \
+        hipLaunchKernelGGL((k_wf_tail<C, A, false, Wd>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);   \
       }                                                                                                      \
     } while (0)
-    if (count == 1) FSPT_LAUNCH_TAIL(true, false);
-    else if (count == 2) FSPT_LAUNCH_TAIL(true, true);
-    else FSPT_LAUNCH_TAIL(false, true);
+    if (count == 1) FSPT_LAUNCH_TAIL(true, false, false);
+    else if (count == 2) FSPT_LAUNCH_TAIL(true, true, false);
+    else if (wide) FSPT_LAUNCH_TAIL(false, true, true);
+    else FSPT_LAUNCH_TAIL(false, true, false);
 #undef FSPT_LAUNCH_TAIL
   } else if (kernel == WF_K_LOGIC || kernel == WF_K_PRIMARY) {
     // resident blocks per CU at WF_LOGIC_WAVES waves per SIMD (4 SIMDs): 2 blocks of 512 threads at 4 waves; twice that many in flight
@@ -2249,14 +2340,15 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
     if (kernel == WF_K_PRIMARY) {
       const size_t dyn = (size_t)(WF_PRIMARY_THREADS / WAVE) * p.scene.stack_n * WAVE * sizeof(int) + (tab ? tab_bytes : 0u) +
                          (prim_r > 1u ? (size_t)prim_r * WF_PRIMARY_THREADS * 32u : 0u); // + ray and hit of every sample of a block iteration
-#define FSPT_LAUNCH_PRIMARY(C, T, RR)                                                                      \
-      do {                                                                                                   \
-        if ((e = allow_lds(k_wf_primary<C, T, RR>, dyn)) != hipSuccess) return e;                            \
-        hipLaunchKernelGGL((k_wf_primary<C, T, RR>), dim3(grid), dim3(WF_PRIMARY_THREADS), dyn, stream, p);  \
+#define FSPT_LAUNCH_PRIMARY(C, T, RR, Wd)                                                                      \
+      do {                                                                                                       \
+        if ((e = allow_lds(k_wf_primary<C, T, RR, Wd>, dyn)) != hipSuccess) return e;                            \
+        hipLaunchKernelGGL((k_wf_primary<C, T, RR, Wd>), dim3(grid), dim3(WF_PRIMARY_THREADS), dyn, stream, p);  \
       } while (0)
-#define FSPT_LAUNCH_PRIMARY_R(C, T) do { if (prim_r > 1u) FSPT_LAUNCH_PRIMARY(C, T, 2); else FSPT_LAUNCH_PRIMARY(C, T, 1); } while (0)
-      if (count) { if (tab) FSPT_LAUNCH_PRIMARY_R(true, true); else FSPT_LAUNCH_PRIMARY_R(true, false); }
-      else { if (tab) FSPT_LAUNCH_PRIMARY_R(false, true); else FSPT_LAUNCH_PRIMARY_R(false, false); }
+#define FSPT_LAUNCH_PRIMARY_R(C, T, Wd) do { if (prim_r > 1u) FSPT_LAUNCH_PRIMARY(C, T, 2, Wd); else FSPT_LAUNCH_PRIMARY(C, T, 1, Wd); } while (0)
+      if (count) { if (tab) FSPT_LAUNCH_PRIMARY_R(true, true, false); else FSPT_LAUNCH_PRIMARY_R(true, false, false); }
+      else if (wide) { if (tab) FSPT_LAUNCH_PRIMARY_R(false, true, true); else FSPT_LAUNCH_PRIMARY_R(false, false, true); }
+      else { if (tab) FSPT_LAUNCH_PRIMARY_R(false, true, false); else FSPT_LAUNCH_PRIMARY_R(false, false, false); }
 #undef FSPT_LAUNCH_PRIMARY_R
 #undef FSPT_LAUNCH_PRIMARY
     } else {

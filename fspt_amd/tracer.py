@@ -41,15 +41,23 @@ class Scene:
         L.check(L.lib().fspt_scene_depth(self._h, C.byref(d)))
         return d.value
 
-    def intersect(self, rays):
-        """intersectScene (tracer.fs:366-404) for rays float32 [n, 6] -> t, index, steps, leaves."""
+    def intersect(self, rays, two_level=False):
+        """intersectScene (tracer.fs:366-404) for rays float32 [n, 6] -> t, index, steps, leaves.  two_level: walk the
+        128-byte two-level nodes (include/fspt_tuning.h: fspt_target_set_node_form) - same results, same counts."""
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         n = rays.shape[0]
         t = np.zeros(n, np.float32); idx = np.zeros(n, np.int32)
         steps = np.zeros(n, np.uint32); leaves = np.zeros(n, np.uint32)
-        L.check(L.lib().fspt_intersect(self._h, L.fptr(rays), n, L.fptr(t),
-                                       idx.ctypes.data_as(C.POINTER(C.c_int32)), L.u32ptr(steps), L.u32ptr(leaves)))
+        L.check(L.lib().fspt_intersect_form(self._h, 1 if two_level else 0, L.fptr(rays), n, L.fptr(t),
+                                            idx.ctypes.data_as(C.POINTER(C.c_int32)), L.u32ptr(steps), L.u32ptr(leaves)))
         return t, idx, steps, leaves
+
+    def two_level_nodes(self):
+        """(the scene has two-level nodes, their bytes): fspt_scene_create builds them when every box of the tree is the
+        exact union of its children's boxes (every tree bvh.js builds)."""
+        yes = C.c_int(); b = C.c_uint64()
+        L.check(L.lib().fspt_scene_two_level_nodes(self._h, C.byref(yes), C.byref(b)))
+        return bool(yes.value), int(b.value)
 
     def close(self):
         if self._h:
@@ -136,6 +144,12 @@ class PathTracer:
         ms = (C.c_double * 2)()
         L.check(L.lib().fspt_target_get_primary_form(self._t, int(batch_ticks), C.byref(f), ms))
         return int(f.value), [float(ms[0]), float(ms[1])]
+
+    def set_node_form(self, primary=-1, trace=-1, tail=-1, trace_below=-1):
+        """Node form per kernel class: -1 the library's choice, 0 the 64-byte nodes, 1 the two-level nodes (two traversal
+        steps per memory round trip; bit-identical results).  trace_below: the library's choice for a trace launch is
+        two-level when it expects fewer paths than this (include/fspt_tuning.h)."""
+        L.check(L.lib().fspt_target_set_node_form(self._t, int(primary), int(trace), int(tail), int(trace_below)))
 
     def set_trace_budget(self, steps):
         """Traversal steps a starved trace wave walks on before it suspends its rays (0 = never; include/fspt_tuning.h)."""
@@ -259,9 +273,14 @@ class PathTracer:
         return ms.value, n.value
 
     def close(self):
+        """Destroy the target.  Recorded (deferred) ticks are executed first: fspt_target_destroy itself drops them - it
+        never writes to a caller-owned accumulator, which may be gone by then - but here `_keep` still holds the bound
+        buffer, so a host that binds a tensor, ticks and closes finds every tick in its tensor."""
         if self._t:
+            L.lib().fspt_sync(self._t)  # (an error here must not keep the target alive: destroy follows regardless)
             L.lib().fspt_target_destroy(self._t)
             self._t = C.c_void_p()
+            self._keep = None
 
     def __del__(self):
         try:

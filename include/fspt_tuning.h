@@ -41,6 +41,24 @@ int fspt_target_set_trace_budget(fspt_target *target, uint32_t steps);
  * launch times, 0 never (except for paths that refraction keeps alive beyond NUM_BOUNCES rounds, tracer.fs:488),
  * r >= 1 after round r. */
 int fspt_target_set_tail(fspt_target *target, int round);
+/* Node form of the traversal, per kernel class.  Every interior node has a 64-byte record (the boxes of its two
+ * children: one of the reference's traversal steps, tracer.fs:372-392, per memory round trip) and - when
+ * fspt_scene_create found every box of the tree to be the exact union of its children's boxes, which holds for every
+ * tree bvh.js builds (bvh.js:120-126) - a 128-byte two-LEVEL record (the boxes of the four grandchildren, from which the
+ * children's are derived exactly): two steps per round trip at twice the requests per fetch, the same nodes visited in
+ * the same order.  The first is faster where the vector-memory request rate binds (large trace launches on a
+ * cache-resident scene), the second where a launch is a bundle of dependent chains (tail kernel, small trace launches,
+ * scenes beyond the L2).  primary / trace / tail: -1 the library's choice, 0 the 64-byte nodes, 1 the two-level nodes;
+ * trace_below >= 0: the library's choice for a trace launch is "two-level when it expects fewer paths than this" (from
+ * the previous batch's live-path counts); < 0 keeps the current threshold.  Ignored on a scene without two-level nodes
+ * and by the counting kernel variants. */
+int fspt_target_set_node_form(fspt_target *target, int primary, int trace, int tail, int64_t trace_below);
+/* Whether the scene has two-level nodes, and their size in bytes (either pointer may be NULL). */
+int fspt_scene_two_level_nodes(const fspt_scene *scene, int *present, uint64_t *bytes);
+/* fspt_intersect (fspt.h) walking the two-level nodes (two_level != 0; FSPT_E_INVALID when the scene has none): t, index
+ * and the per-ray step / leaf counts must equal the one-level walk's (tests). */
+int fspt_intersect_form(fspt_scene *scene, int two_level, const float *rays, uint32_t n, float *t_out, int32_t *index_out,
+                        uint32_t *steps_out, uint32_t *leaves_out);
 /* The primary launch (ray generation + the camera ray's traversal + its shading) has two forms of its traversal phase:
  * 1 = one traversal per lane (a wave waits for its longest ray), 2 = per-lane refill over 2 x 64 samples per wave.  0
  * (default): the batch scheduler times both on the target's own batches (HIP events around the launch, read back

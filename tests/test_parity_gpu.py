@@ -106,6 +106,78 @@ def test_intersect_bitwise(which, small_scene, medium_scene):
     assert (idx >= 0).mean() > 0.2
 
 
+@pytest.mark.parametrize("which", ["small", "medium"])
+def test_two_level_nodes_intersect_bitwise(which, small_scene, medium_scene):
+    """The 128-byte two-level nodes (two of the reference's traversal steps per memory round trip, the children's boxes
+    derived from the grandchildren's): t, hit index AND the per-ray step / leaf counts equal the oracle's - the walk
+    visits node sequences of exactly the reference's lengths (tracer.fs:366-404)."""
+    arrays = small_scene if which == "small" else medium_scene
+    rays = random_rays(arrays, 20000, seed=12)
+    sc = Scene(arrays)
+    present, nbytes = sc.two_level_nodes()
+    assert present and nbytes > 0 and nbytes % 128 == 0  # a bvh.js-shaped tree: every box is the union of its children's
+    t, idx, steps, leaves = sc.intersect(rays, two_level=True)
+    rt, ridx, rsteps, rleaves = O.intersect(arrays, rays)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+    assert np.array_equal(steps, rsteps) and np.array_equal(leaves, rleaves)
+    t1, idx1, steps1, leaves1 = sc.intersect(rays)
+    assert np.array_equal(t1, t) and np.array_equal(idx1, idx) and np.array_equal(steps1, steps)
+
+
+@pytest.mark.parametrize("forms", [(1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1), (-1, -1, -1)])
+@pytest.mark.parametrize("pipeline,tail,prim", [("wavefront", 0, 1), ("wavefront", 2, 2), ("wavefront", -1, 0), ("stream", 0, 1)])
+def test_two_level_nodes_render_bitwise(medium_scene, camera, forms, pipeline, tail, prim):
+    """fspt_target_set_node_form: the primary launch (both forms of its traversal phase), the trace launches (with
+    suspended traversals: a record written by one node form may be resumed by the other) and the tail kernel on the
+    two-level nodes, each alone and together, on both schedulers: the oracle's radiance, bit for bit."""
+    W, H, nb = 120, 72, 6
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], nb, 0, 7, 21, want)
+    pt = make_pt(medium_scene, W, H, camera, nb, pipeline, 3, tail=tail)
+    pt.set_node_form(*forms, trace_below=(1 << 30) if forms[1] < 0 else -1)
+    pt.set_primary_form(prim)
+    pt.set_trace_budget(3)
+    pt.seed(21)
+    pt.render(2); pt.render(5)
+    got = pt.readRadiance()
+    assert np.array_equal(got, want), f"{(got != want).any(-1).sum()} of {W * H} pixels differ"
+    pt.close()
+
+
+def test_scene_whose_boxes_are_not_unions_has_no_two_level_nodes(small_scene, camera):
+    """The two-level record derives a child's box from its grandchildren's, which is only right when the box IS their
+    union (true for every tree bvh.js builds).  fspt_scene_create checks that on the arrays it is given: a tree with one
+    box grown by an ulp is still a valid input (the reference would traverse it), gets no two-level nodes, every launch
+    walks the 64-byte nodes whatever the setting, and the result is the oracle's for THAT tree."""
+    import copy
+    arrays = copy.copy(small_scene)
+    bvh = np.array(small_scene.bvh, np.float32).reshape(-1, 9).copy()
+    iv = bvh.view(np.int32)
+    interior = np.nonzero(iv[:, 2] < 0)[0]
+    victim = int(interior[len(interior) // 2])
+    bvh[victim, 6] = np.nextafter(bvh[victim, 6], np.float32(np.inf))  # max.x one ulp larger than the union
+    arrays.bvh = bvh.reshape(-1)
+    sc = Scene(arrays)
+    assert sc.two_level_nodes() == (False, 0)
+    rays = random_rays(arrays, 4096, seed=5)
+    with pytest.raises(L.FsptError):
+        sc.intersect(rays, two_level=True)
+    t, idx, steps, leaves = sc.intersect(rays)
+    rt, ridx, rsteps, rleaves = O.intersect(arrays, rays)
+    assert np.array_equal(idx, ridx) and np.array_equal(t, rt) and np.array_equal(steps, rsteps)
+    W, H = 96, 64
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(arrays, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4, 0, 3, 5, want)
+    pt = PathTracer(sc, W, H, num_bounces=4)
+    pt.set_camera(camera["P"], camera["I"], camera["fov_scale"], camera["env_theta"], camera["focal_depth"], camera["aperture"])
+    pt.set_node_form(1, 1, 1)
+    pt.seed(5)
+    pt.render(3)
+    assert np.array_equal(pt.readRadiance(), want)
+    pt.close()
+
+
 @pytest.mark.parametrize("pipeline", PIPELINES)
 @pytest.mark.parametrize("bounces", [1, 4, 8])
 def test_trace_two_call_bitwise(small_scene, camera, bounces, pipeline):
@@ -1055,6 +1127,9 @@ def test_deep_chain_bvh_bitwise(small_scene, n_leaves):
     t, idx, steps, leaves = sc.intersect(rays)
     ot, oidx, osteps, oleaves = O.intersect(arrays, rays)
     assert np.array_equal(t, ot) and np.array_equal(idx, oidx) and np.array_equal(steps, osteps) and np.array_equal(leaves, oleaves)
+    assert sc.two_level_nodes()[0]  # (every interior node has a leaf child: the one-level part of the two-level walk)
+    t2, idx2, steps2, leaves2 = sc.intersect(rays, two_level=True)
+    assert np.array_equal(t2, ot) and np.array_equal(idx2, oidx) and np.array_equal(steps2, osteps) and np.array_equal(leaves2, oleaves)
     assert (idx >= 0).mean() > 0.3 and leaves.max() >= n_leaves // 2  # rays down the chain stack one entry per level: > 32 deep for 64
     W, H = 72, 40
     cam = dict(P=[n_leaves + 2.5, 0.05, 0.1], I=[-1.0, -0.01, -0.02], fov_scale=0.5, env_theta=1.66, focal_depth=2.0,
@@ -1074,6 +1149,13 @@ def test_deep_chain_bvh_bitwise(small_scene, n_leaves):
         pt.render(2)
         assert np.array_equal(pt.readRadiance(), want), (pipeline, tail)
         assert pt.counters() == oc.as_dict(), (pipeline, tail)
+        if pipeline == "wavefront":  # and the production kernels on the two-level nodes (the counting variants walk the 64-byte ones)
+            pt.enable_counters(0)
+            pt.set_node_form(1, 1, 1)
+            pt.clear()
+            pt.seed(9)
+            pt.render(2)
+            assert np.array_equal(pt.readRadiance(), want), (pipeline, tail, "two-level")
         if pipeline == "wavefront" and tail == 0:  # bvh_test.fs through the same stacks
             pt.clear()
             pt.drawCamera(12.5)
@@ -1483,6 +1565,11 @@ def test_fuzz_random_scenes_bitwise(seed):
     rt, ridx, rsteps, rleaves = O.intersect(arrays, rays)
     assert np.array_equal(idx, ridx) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
     assert np.array_equal(steps, rsteps) and np.array_equal(leaves, rleaves)
+    two_level = sc.two_level_nodes()[0]  # (the builder's trees have them unless the tree is a single leaf)
+    if two_level:
+        t, idx, steps, leaves = sc.intersect(rays, two_level=True)
+        assert np.array_equal(idx, ridx) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+        assert np.array_equal(steps, rsteps) and np.array_equal(leaves, rleaves)
     for pipeline in PIPELINES:
         pt = PathTracer(sc, W, H, num_bounces=bounces)
         pt.eye, pt.dir, pt.fovScale, pt.envTheta, pt.lensFeatures = cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["lens"]
@@ -1504,6 +1591,7 @@ def test_fuzz_random_scenes_bitwise(seed):
         pt.eye, pt.dir, pt.fovScale, pt.envTheta, pt.lensFeatures = cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["lens"]
         pt.set_pipeline(pipeline, 2)
         pt.set_trace_budget(1 + seed % 5)
+        pt.set_node_form((seed >> 0) & 1, (seed >> 1) & 1, (seed >> 2) & 1)  # every mix of node forms, by seed
         if pipeline == "wavefront":
             pt.set_primary_form(2 - seed % 2)
         if pool:
