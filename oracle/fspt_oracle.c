@@ -101,9 +101,12 @@ static inline float rnd_seed(float *seed) {
 /* The tracer's `seed` global.  `rec` (probes only): the values the reference GLSL's own rnd()
  * returned for the same calls, replayed in call order - takes the GLSL implementation's sin()
  * out of a comparison of everything downstream of rnd(). */
-typedef struct { float seed; const float *rec; uint32_t used; } rng_t;
+typedef struct { float seed; const float *rec; uint32_t used; uint32_t limit; /* values in rec (0: unbounded) */ } rng_t;
 static inline float rnd(rng_t *g) {
-  if (g->rec) return g->rec[g->used++];
+  if (g->rec) {
+    if (g->limit && g->used >= g->limit) { g->used++; return 0.5f; } /* past the recording: the caller sees used > limit */
+    return g->rec[g->used++];
+  }
   return rnd_seed(&g->seed);
 }
 
@@ -519,8 +522,26 @@ static inline void bounce_body(const oracle_scene *s, vec3 ro, vec3 rd, hit_t re
 
 /* ---- the rest of the iteration, tracer.fs:467 and 500-512: emission, NEE shadow ray, extension ray ------
  * Returns 1 when the extension ray left the scene (`break`). */
+/* Whole-path replay only (NULL otherwise): sig[0] a hash of the hit indices every intersectScene call of the path
+ * returned, in call order (h = h * 31 + index + 2, uint32 wrap-around), sig[1] the number of calls; `env` (optional):
+ * the rgb the reference GLSL's envSample returned for the path's environment lookups, in call order (env_limit of
+ * them), replayed in place of the oracle's own lookup - takes the GLSL implementation's RGBA8 / RGBE decode out. */
+typedef struct { uint32_t sig[2]; const float *env; uint32_t env_used, env_limit;
+                 /* `tex` (optional): the four texture() results of the path's k-th loop iteration (12 floats, bounce_body's layout) */
+                 const float *tex; uint32_t tex_limit; } replay_t;
+static inline void sig_add(replay_t *rp, int index) {
+  if (rp) { rp->sig[0] = rp->sig[0] * 31u + (uint32_t)(index + 2); rp->sig[1]++; }
+}
+static inline vec3 env_sample_rp(const oracle_scene *s, vec3 dir, float envTheta, oracle_counters *c, replay_t *rp) {
+  vec3 own = env_sample(s, dir, envTheta, c);
+  if (rp) {
+    const uint32_t k = rp->env_used++; /* (counted whether or not the lookups are replayed) */
+    if (rp->env && k < rp->env_limit) return v3(rp->env[k * 3], rp->env[k * 3 + 1], rp->env[k * 3 + 2]);
+  }
+  return own;
+}
 static inline int bounce_tail(const oracle_scene *s, const bounce_t *b, float envTheta, oracle_counters *c,
-                              vec3 *thr_io, vec3 *color_io, hit_t *result) {
+                              vec3 *thr_io, vec3 *color_io, hit_t *result, replay_t *sig) {
   vec3 thr = *thr_io, color = *color_io;
   /* tracer.fs:467 */
   color = v3(om_fma((thr.x * b->texEmissive.x) * b->texDiffuse.x, 30.0f, color.x),
@@ -528,18 +549,20 @@ static inline int bounce_tail(const oracle_scene *s, const bounce_t *b, float en
              om_fma((thr.z * b->texEmissive.z) * b->texDiffuse.z, 30.0f, color.z));
   if (b->dielectric < 0.0f && b->cosEnv > 0.0f) {
     hit_t shadow = intersect_scene(s, b->ro, b->envDir, c, NULL, NULL);
+    sig_add(sig, shadow.index);
     if (shadow.index == -1) {
-      vec3 es = env_sample(s, b->envDir, envTheta, c);
+      vec3 es = env_sample_rp(s, b->envDir, envTheta, c, sig);
       color = v3(om_fma((thr.x * b->envThroughput.x) * es.x, b->weights.x, color.x),
                  om_fma((thr.y * b->envThroughput.y) * es.y, b->weights.x, color.y),
                  om_fma((thr.z * b->envThroughput.z) * es.z, b->weights.x, color.z));
     }
   }
   *result = intersect_scene(s, b->ro, b->rd, c, NULL, NULL);
+  sig_add(sig, result->index);
   thr = v_mul(thr, b->bsdfThroughput);
   int left = 0;
   if (result->index == -1) {
-    vec3 es = env_sample(s, b->rd, envTheta, c);
+    vec3 es = env_sample_rp(s, b->rd, envTheta, c, sig);
     color = v3(om_fma(thr.x * es.x, b->weights.y, color.x), om_fma(thr.y * es.y, b->weights.y, color.y),
                om_fma(thr.z * es.z, b->weights.y, color.z));
     left = 1;
@@ -549,28 +572,39 @@ static inline int bounce_tail(const oracle_scene *s, const bounce_t *b, float en
 }
 
 /* ---- tracer.fs main (436-518) for one pixel ----------------------------- */
-static void trace_pixel(const oracle_scene *s, vec3 ro, vec3 rd, uint32_t tick, float randBase,
-                        float envTheta, uint32_t numBounces, float *accum /*rgba*/,
-                        oracle_counters *c, oracle_first_hit *fh) {
-  rng_t g = {0.0f, NULL, 0};
-  if (c) c->samples++;
+/* ... the path itself (tracer.fs:439-514): the sample's colour before the clamp of tracer.fs:515.  `g`: the tracer's
+ * random numbers - its own sin-hash, or (whole-path replay) the values the reference GLSL's rnd() returned. */
+static vec3 trace_path(const oracle_scene *s, vec3 ro, vec3 rd, float randBase, float envTheta, uint32_t numBounces,
+                       rng_t *gp, oracle_counters *c, oracle_first_hit *fh, replay_t *sig) {
+  rng_t g = *gp;
   hit_t result = intersect_scene(s, ro, rd, c, NULL, NULL);
+  sig_add(sig, result.index);
   vec3 color = v3(0.0f, 0.0f, 0.0f);
   if (fh) { memset(fh, 0, sizeof(*fh)); fh->t = result.t; fh->index = result.index; }
   if (result.index < 0) {
-    color = v_add(color, env_sample(s, rd, envTheta, c));
+    color = v_add(color, env_sample_rp(s, rd, envTheta, c, sig));
   } else {
     vec3 thr = v3(1.0f, 1.0f, 1.0f);
     int iters = 0;
     for (int i = 0; i < (int)numBounces && iters < ORACLE_MAX_PATH_ITERS; ++i, ++iters) {
       if (c) c->shades++;
       bounce_t b;
-      bounce_body(s, ro, rd, result, randBase, envTheta, &g, (fh && iters == 0) ? fh : NULL, NULL, &b);
+      bounce_body(s, ro, rd, result, randBase, envTheta, &g, (fh && iters == 0) ? fh : NULL,
+                  (sig && sig->tex && (uint32_t)iters < sig->tex_limit) ? sig->tex + (size_t)iters * 12 : NULL, &b);
       ro = b.ro; rd = b.rd;
       if (b.refracted) i--; /* tracer.fs:488 */
-      if (bounce_tail(s, &b, envTheta, c, &thr, &color, &result)) break;
+      if (bounce_tail(s, &b, envTheta, c, &thr, &color, &result, sig)) break;
     }
   }
+  *gp = g;
+  return color;
+}
+static void trace_pixel(const oracle_scene *s, vec3 ro, vec3 rd, uint32_t tick, float randBase,
+                        float envTheta, uint32_t numBounces, float *accum /*rgba*/,
+                        oracle_counters *c, oracle_first_hit *fh) {
+  rng_t g = {0.0f, NULL, 0, 0};
+  if (c) c->samples++;
+  vec3 color = trace_path(s, ro, rd, randBase, envTheta, numBounces, &g, c, fh, NULL);
   color = v3(om_clamp(color.x, 0.0f, 1024.0f), om_clamp(color.y, 0.0f, 1024.0f), om_clamp(color.z, 0.0f, 1024.0f));
   float ft = (float)tick;
   float den = ft + 1.0f;
@@ -587,7 +621,7 @@ static void camera_pixel(uint32_t x, uint32_t y, uint32_t W, uint32_t H, const f
   float resx = (float)W, resy = (float)H;
   /* uv = interpolated clip-space corner (camera.vs:8, main.js:601-605) */
   float uvx = om_fma(fx / resx, 2.0f, -1.0f), uvy = om_fma(fy / resy, 2.0f, -1.0f);
-  rng_t g = {om_fma(fx, resy, randBase) + fy, rec, 0}; /* (rec: the four values the GLSL's rnd() returned, probes only) */
+  rng_t g = {om_fma(fx, resy, randBase) + fy, rec, 0, 0}; /* (rec: the four values the GLSL's rnd() returned, probes only) */
   vec3 Iv = v3(I[0], I[1], I[2]), Pv = v3(P[0], P[1], P[2]);
   vec3 basisX = v_normalize(v_cross(Iv, v3(0.0f, 1.0f, 0.0f)));
   vec3 basisY = v_normalize(v_cross(basisX, Iv));
@@ -830,7 +864,7 @@ void oracle_sampler_probe(const oracle_scene *s, int which, const float *in, con
                           uint32_t rec_stride, float envTheta, uint32_t n, float *out) {
   for (uint32_t i = 0; i < n; ++i) {
     const float *p = in + (size_t)i * 4;
-    rng_t g = {0.0f, rec + (size_t)i * rec_stride, 0};
+    rng_t g = {0.0f, rec + (size_t)i * rec_stride, 0, 0};
     vec3 nrm = v3(p[0], p[1], p[2]);
     float *o = out + (size_t)i * 4;
     vec3 r = v3(0.0f, 0.0f, 0.0f);
@@ -865,7 +899,7 @@ void oracle_bounce_probe(const oracle_scene *s, const float *rays, const float *
     vec3 ro = v3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
     vec3 rd = v3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
     hit_t h = {t_in[i], index_in[i]};
-    rng_t g = {0.0f, rec ? rec + (size_t)i * 8 : NULL, 0};
+    rng_t g = {0.0f, rec ? rec + (size_t)i * 8 : NULL, 0, 0};
     bounce_t b;
     bounce_body(s, ro, rd, h, randBase, envTheta, &g, NULL, tex ? tex + (size_t)i * 12 : NULL, &b);
     o[0] = b.seed0; o[1] = (float)b.inside; o[2] = (float)b.specular; o[3] = b.bsdfPdf;
@@ -880,9 +914,41 @@ void oracle_bounce_probe(const oracle_scene *s, const float *rays, const float *
     o[32] = b.macroNormal.x; o[33] = b.macroNormal.y; o[34] = b.macroNormal.z; o[35] = b.dielectric;
     vec3 thr = v3(1.0f, 1.0f, 1.0f), color = v3(0.0f, 0.0f, 0.0f);
     hit_t next;
-    (void)bounce_tail(s, &b, envTheta, NULL, &thr, &color, &next);
+    (void)bounce_tail(s, &b, envTheta, NULL, &thr, &color, &next, NULL);
     o[36] = color.x; o[37] = color.y; o[38] = color.z; o[39] = (float)next.index;
     o[40] = thr.x; o[41] = thr.y; o[42] = thr.z; o[43] = next.t;
+  }
+}
+
+/* Stage D6 - the WHOLE path with the reference GLSL's random numbers replayed.  tools/make_goldens.py path_replay runs
+ * the reference's tracer.fs main() (436-518) unmodified at depth `numBounces` on SwiftShader and records, per pixel,
+ * every value its rnd() returned (in call order: `rec`, rec_stride floats per pixel of which rec_count[i] are valid),
+ * the number of rnd() calls, and a hash + count of the hit indices its intersectScene calls returned.  Here the same
+ * rays walk trace_path with those values in place of the sin-hash: out_color = the sample's colour after the clamp of
+ * tracer.fs:515 (what tick 0 writes), out_used = rnd() calls made (> rec_count[i]: the path asked for more values than
+ * were recorded - it took another branch somewhere), out_sig = {hash, calls} as sig_add defines them.  env_rec: also
+ * replay what the GLSL's envSample returned for the path's k-th environment lookup, tex_rec: the four texture() results
+ * of its k-th loop iteration (replay_t) - with all three the comparison is of the path LOGIC and its arithmetic alone. */
+void oracle_path_replay(const oracle_scene *s, const float *pos /* n x 4 */, const float *dir /* n x 4 */, uint32_t n,
+                        const float *rec, uint32_t rec_stride, const uint32_t *rec_count, float randBase, float envTheta,
+                        uint32_t numBounces, const float *env_rec /* n x env_stride x 3, or NULL */, uint32_t env_stride,
+                        const float *tex_rec /* n x tex_stride x 12, or NULL */, uint32_t tex_stride,
+                        float *out_color /* n x 3 */, uint32_t *out_used, uint32_t *out_sig /* n x 2 */, uint32_t *out_env_used) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    rng_t g = {0.0f, rec + (size_t)i * rec_stride, 0, rec_count[i] < rec_stride ? rec_count[i] : rec_stride};
+    if (g.limit == 0) g.limit = 0xFFFFFFFFu; /* (no values recorded: every draw is past the recording; 0 means unbounded) */
+    replay_t rp = {{0u, 0u}, env_rec ? env_rec + (size_t)i * env_stride * 3 : NULL, 0u, env_stride,
+                   tex_rec ? tex_rec + (size_t)i * tex_stride * 12 : NULL, tex_stride};
+    vec3 color = trace_path(s, v3(pos[i * 4], pos[i * 4 + 1], pos[i * 4 + 2]), v3(dir[i * 4], dir[i * 4 + 1], dir[i * 4 + 2]),
+                            randBase, envTheta, numBounces, &g, NULL, NULL, &rp);
+    if (rec_count[i] == 0 && g.used) g.used = 0xFFFFFFFFu;
+    out_color[i * 3] = om_clamp(color.x, 0.0f, 1024.0f);
+    out_color[i * 3 + 1] = om_clamp(color.y, 0.0f, 1024.0f);
+    out_color[i * 3 + 2] = om_clamp(color.z, 0.0f, 1024.0f);
+    out_used[i] = g.used;
+    out_sig[i * 2] = rp.sig[0]; out_sig[i * 2 + 1] = rp.sig[1];
+    if (out_env_used) out_env_used[i] = rp.env_used;
   }
 }
 

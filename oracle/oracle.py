@@ -198,6 +198,33 @@ def bounce_probe(arrays, rays, t, index, rand_base, env_theta, rec=None, tex=Non
     return out
 
 
+def path_replay(arrays, pos, d, rec, rec_count, rand_base, env_theta, num_bounces, env_rec=None, tex_rec=None):
+    """Stage D6: the whole path (tracer.fs main, 436-518) for rays pos / d ([n, 4] each) with the recorded rnd() values
+    of the reference GLSL replayed (rec [n, stride], rec_count [n] of them valid) and, optionally, what its envSample
+    returned for the path's k-th environment lookup (env_rec [n, k, 3]) and the four texture() results of its k-th loop
+    iteration (tex_rec [n, k, 12]: diffuse.rgb, emissive.rgb, mr.rg, normal.rgb, pad).  Returns (clamped colour [n, 3], rnd() calls made
+    [n], hash of the intersectScene hit indices [n], intersectScene calls [n], environment lookups made [n])."""
+    s = oscene(arrays)
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 4)
+    d = np.ascontiguousarray(d, np.float32).reshape(-1, 4)
+    n = pos.shape[0]
+    rec = np.ascontiguousarray(rec, np.float32).reshape(n, -1)
+    cnt = np.ascontiguousarray(rec_count, np.uint32).reshape(n)
+    if env_rec is not None:
+        env_rec = np.ascontiguousarray(env_rec, np.float32).reshape(n, -1, 3)
+    if tex_rec is not None:
+        tex_rec = np.ascontiguousarray(tex_rec, np.float32).reshape(n, -1, 12)
+    col = np.zeros((n, 3), np.float32); used = np.zeros(n, np.uint32); sig = np.zeros((n, 2), np.uint32)
+    env_used = np.zeros(n, np.uint32)
+    u32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+    lib().oracle_path_replay(C.byref(s), _fp(pos), _fp(d), C.c_uint32(n), _fp(rec), C.c_uint32(rec.shape[1]), u32(cnt),
+                             C.c_float(rand_base), C.c_float(env_theta), C.c_uint32(num_bounces),
+                             _fp(env_rec) if env_rec is not None else None, C.c_uint32(env_rec.shape[1] if env_rec is not None else 0),
+                             _fp(tex_rec) if tex_rec is not None else None, C.c_uint32(tex_rec.shape[1] if tex_rec is not None else 0),
+                             _fp(col), u32(used), u32(sig), u32(env_used))
+    return col, used, sig[:, 0], sig[:, 1], env_used
+
+
 def rnd_sequence(seeds, k):
     seeds = np.ascontiguousarray(seeds, np.float32).reshape(-1)
     out = np.zeros((seeds.size, k), np.float32)

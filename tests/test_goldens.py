@@ -738,3 +738,73 @@ def test_bounce_body_with_own_texture_fetch(name):
     assert np.abs(o[same, 24:27] - G[408][same, :3]).max() <= 2e-2            # emitted colour (x30)
     d = np.abs(o[same, 4:7] - G[403][same, :3]).max(1)
     assert np.percentile(d, 99) <= 2e-3                                        # ray.dir
+
+
+def _ragged(vals, cnt, k=1):
+    """[n] counts + flat values -> zero-padded [n, max(count)(, k)]."""
+    n, width = cnt.size, max(1, int(cnt.max()))
+    out = np.zeros((n, width, k) if k > 1 else (n, width), np.float32)
+    off = np.concatenate([[0], np.cumsum(cnt.astype(np.int64))])
+    for i in range(n):
+        v = vals[off[i] * k:off[i + 1] * k]
+        out[i, :cnt[i]] = v.reshape(-1, k) if k > 1 else v
+    return out
+
+
+@pytest.mark.parametrize("name", ["small", "variant", "textured"])
+def test_d6_whole_path_replay_matches_glsl(name):
+    """Stage D6, the whole path: ONE tick of the reference's UNMODIFIED tracer.fs main() (436-518) at depth 8 on
+    SwiftShader - rnd(), intersectScene(), envSample(), main() and (by #define) main()'s four texture() calls keep their
+    bodies and are wrapped from outside by recorders (tools/make_goldens.py path_replay) - against the oracle's
+    trace_path (the function trace_pixel runs) on the same injected camera rays, with what the GLSL's implementation
+    -defined parts returned replayed in three steps:
+      rnd            every value rnd() returned (SwiftShader's sin() of a five-digit seed is unrelated to anybody's,
+                     SURVEY 0.2), nothing else: the radiance then differs by SwiftShader's RGBE decode (0.989, D5);
+      rnd + env      + what envSample() returned per lookup: <= 1e-3 relative L2 (north_star's bar) on the flat-colour and
+                     the refractive / emissive scene; the image-mapped scene keeps the sampler's 3e-4 in its roughness;
+      rnd + env + tex  + the four texture() results of every iteration (its RGBA8 conversion is 6e-5 off even on flat
+                     colours): what is left is the path logic and its float32 arithmetic - 2e-6 / 6e-6 / 1.4e-6.
+    'Identical branch sequence' = the same number of rnd() calls (Lambert draws two more than the other branches, every
+    iteration six or eight), the same number of intersectScene calls and the same hash over the hit indices they returned
+    (primary, shadow and extension rays in call order), the same number of environment lookups: >= 99 % of the pixels."""
+    z = np.load(os.path.join(GOLD, f"glsl_path_replay_{name}.npz"))
+    a = S.textured_test_scene() if name == "textured" else scene_from_golden(name)
+    W, H = int(z["W"]), int(z["H"])
+    n = W * H
+    assert int(z["bounces"]) == 8
+    cnt, cap = z["rnd_count"].reshape(n), int(z["cap"])
+    assert cnt.max() <= cap  # nothing was cut off
+    rec = _ragged(z["rnd_values"], cnt)
+    ec, ti = z["env_count"].reshape(n), z["tex_iters"].reshape(n)
+    env, tex = _ragged(z["env_values"], ec, 3), _ragged(z["tex_values"], ti, 12)
+    g = z["color"].reshape(n, 3).astype(np.float64)
+    assert (cnt > 0).mean() > 0.4 and cnt.max() >= 48 and ti.max() >= 6  # paths of 6+ iterations are in the set
+
+    def rel_l2(x, y):
+        return float(np.linalg.norm(x - y) / np.linalg.norm(y))
+
+    def replay(use_env, use_tex):
+        col, used, sig, calls, eu = O.path_replay(a, z["rays_pos"], z["rays_dir"], rec, cnt, float(z["rand_base"]),
+                                                  float(z["env_theta"]), 8, env if use_env else None, tex if use_tex else None)
+        same = (used == cnt) & (sig == z["hit_sig"].reshape(n)) & (calls == z["hit_calls"].reshape(n)) & (eu == ec)
+        return col.astype(np.float64), same
+
+    # everything replayed: the path logic and its arithmetic
+    o, same = replay(True, True)
+    assert same.mean() >= 0.995, same.mean()
+    full = rel_l2(g[same], o[same])
+    assert full <= 2e-5, full
+    assert np.percentile(np.abs(g[same] - o[same]).max(1) / np.maximum(np.abs(o[same]).max(1), 1e-3), 99) <= 1e-4
+    # random numbers + environment lookups: north_star's 1e-3 on the HDR buffer
+    o, same = replay(True, False)
+    assert same.mean() >= 0.99, same.mean()
+    env_only = rel_l2(g[same], o[same])
+    assert env_only <= (1.2e-2 if name == "textured" else 1.0e-3), env_only
+    # random numbers only: SwiftShader's RGBE decode is all that is left
+    o, same = replay(False, False)
+    assert same.mean() >= 0.99, same.mean()
+    r = g[same].sum() / o[same].sum()
+    assert 0.985 <= r <= 0.995, r
+    if name == "small":  # every photon of this scene comes from the environment
+        assert abs(r / _env_decode_bias(a, float(z["env_theta"])) - 1.0) <= 0.002
+        assert rel_l2(g[same], o[same] * r) <= 2.5e-3

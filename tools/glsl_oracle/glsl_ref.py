@@ -61,7 +61,7 @@ def read_shader(name):
     return open(os.path.join(REF, "shader", name)).read()
 
 
-def tracer_source(n_bins, leaf_size=4, replicate=True, num_bounces=None, main_override=None):
+def tracer_source(n_bins, leaf_size=4, replicate=True, num_bounces=None, main_override=None, post=None):
     """tracer.fs with the preprocessor lines of main.js:293/299,403-405,895 spliced after
     line 1; optionally NUM_BOUNCES changed (tracer.fs:9 is a compile-time constant), the
     quad-replication substitutions, or a replacement main() for instrumented probes."""
@@ -87,6 +87,8 @@ def tracer_source(n_bins, leaf_size=4, replicate=True, num_bounces=None, main_ov
         for a, b in subs:
             assert src.count(a) == 1, a
             src = src.replace(a, b)
+    if post is not None:
+        src = post(src)  # instrumentation wrapped AROUND the reference's functions (tools/make_goldens.py path_replay)
     return src
 
 
@@ -147,8 +149,8 @@ class GlslRef:
         self._ck(self.lib.gh_target(W, H, self.rep))
         self._ck(self.lib.gh_clear())
 
-    def tracer(self, num_bounces=None, main_override=None, leaf_size=4):
-        src = tracer_source(self.n_bins, leaf_size, self.rep == 2, num_bounces, main_override)
+    def tracer(self, num_bounces=None, main_override=None, leaf_size=4, post=None):
+        src = tracer_source(self.n_bins, leaf_size, self.rep == 2, num_bounces, main_override, post)
         self._ck(self.lib.gh_tracer_program(read_shader("tracer.vs").encode(), src.encode()))
 
     def tracer_test(self, leaf_size=4):

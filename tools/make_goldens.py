@@ -418,6 +418,176 @@ def make_samplers(name):
 
 
 
+# ---- stage D6: the WHOLE path, tracer.fs main() unmodified, with every random number it drew recorded -------------------
+# The reference's rnd(), intersectScene() and main() keep their bodies and get new names; wrappers with the old names
+# count / record what goes through them (the only way to see inside a fragment shader is its one vec4 output, so the
+# program is run once per group of four rnd() values: probeSel 2, probeBase = 0, 4, 8, ...; every run of the same
+# (rays, randBase) is the same computation).  probeSel 0 leaves main()'s own output (tick 0: the clamped sample colour,
+# tracer.fs:515-517); 1 = (rnd() calls, hash of the hit indices intersectScene returned - low / high 16 bits -, calls).
+PATH_WRAP_RND = """
+uniform int probeSel;
+uniform int probeBase;
+int probeCount = 0;
+vec4 probeRec = vec4(0.0);
+float rnd() {
+  float r = rndRef();
+  int k = probeCount - probeBase;
+  if (k == 0) probeRec.x = r;
+  if (k == 1) probeRec.y = r;
+  if (k == 2) probeRec.z = r;
+  if (k == 3) probeRec.w = r;
+  probeCount++;
+  return r;
+}
+"""
+PATH_WRAP_HIT = """
+uint probeSig = 0u;
+int probeCalls = 0;
+Hit intersectScene(Ray ray) {
+  Hit h = intersectSceneRef(ray);
+  probeSig = probeSig * 31u + uint(h.index + 2);
+  probeCalls++;
+  return h;
+}
+"""
+PATH_WRAP_ENV = """
+uniform int probeEnvIdx;
+int probeEnvCount = 0;
+vec3 probeEnv = vec3(0.0);
+vec3 envSample(vec3 dir) {
+  vec3 e = envSampleRef(dir);
+  if (probeEnvCount == probeEnvIdx) probeEnv = e;
+  probeEnvCount++;
+  return e;
+}
+"""
+# texture() is a built-in: main()'s four atlas fetches per iteration (tracer.fs:453-456; envColor's fetch sits above this
+# point of the file and keeps the built-in) are routed through a counting wrapper by the preprocessor
+PATH_WRAP_TEX = """
+uniform int probeTexIdx;
+int probeTexCount = 0;
+vec4 probeTex = vec4(0.0);
+vec4 probeTexture(sampler2DArray s, vec3 c) {
+  vec4 v = texture(s, c);
+  if (probeTexCount == probeTexIdx) probeTex = v;
+  probeTexCount++;
+  return v;
+}
+#define texture probeTexture
+"""
+PATH_WRAP_MAIN = """
+#undef texture
+void main(void) {
+  mainRef();
+  if (probeSel == 1) fragColor = vec4(float(probeCount), float(probeSig & 0xFFFFu), float(probeSig >> 16u), float(probeCalls));
+  if (probeSel == 2) fragColor = probeRec;
+  if (probeSel == 3) fragColor = vec4(probeEnv, float(probeEnvCount));
+  if (probeSel == 4) fragColor = probeTex;
+  if (probeSel == 5) fragColor = vec4(float(probeTexCount), 0.0, 0.0, 0.0);
+}
+"""
+
+
+def path_wrap(src):
+    """tracer.fs (as tracer_source made it: #defines, NUM_BOUNCES, the quad-replication substitutions) with the three
+    wrappers spliced in behind the functions they wrap."""
+    def after_function(src, head, new_head, wrapper):
+        assert src.count(head) == 1, head
+        i = src.index(head)
+        depth, j = 0, src.index("{", i)
+        while True:  # the function's closing brace
+            depth += {"{": 1, "}": -1}.get(src[j], 0)
+            j += 1
+            if depth == 0:
+                break
+        return src[:i] + new_head + src[i + len(head):j] + "\n" + wrapper + src[j:]
+    src = after_function(src, "float rnd() {", "float rndRef() {", PATH_WRAP_RND)
+    src = after_function(src, "Hit intersectScene(Ray ray){", "Hit intersectSceneRef(Ray ray){", PATH_WRAP_HIT)
+    src = after_function(src, "vec3 envSample(vec3 dir){", "vec3 envSampleRef(vec3 dir){", PATH_WRAP_ENV)
+    assert src.count("texture(") == 5 and src.index("texture(envTex") < src.index("void main(void) {") < src.index("texture(texArray")
+    i = src.index("void main(void) {")
+    src = src[:i] + PATH_WRAP_TEX + src[i:]
+    src = after_function(src, "void main(void) {", "void mainRef(void) {", PATH_WRAP_MAIN)
+    return src
+
+
+PATH_REPLAY_CAP = 192  # rnd() values recorded per pixel at most (8 bounces x 8 values; refraction adds iterations)
+
+
+def make_path_replay(name):
+    """D6 golden: camera rays of the oracle (injected), ONE tick of the unmodified main() at depth 8."""
+    import glsl_ref as G
+    import oracle as O
+    scene_name = name
+    arrays = converged_scene(scene_name)
+    cam = dict(S.BUNNY_CAMERA)
+    if name in CONVERGED and CONVERGED[name][5] is not None:
+        cam["P"], cam["I"] = CONVERGED[name][5], CONVERGED[name][6]
+    lens = S.lens_features(cam["focal_depth"], cam["aperture"])
+    W, H, bounces = 64, 40, 8
+    env_theta, rand_base = cam["env_theta"], 3217.25
+    pos, d = O.camera(W, H, cam["P"], cam["I"], cam["fov_scale"], lens, 911.5)
+    g = G.GlslRef()
+    g.scene(arrays)
+    g.target(W, H, replicate=True)
+    g.tracer(num_bounces=bounces, post=path_wrap)
+    g.set_camera(pos, d)
+
+    def run(sel, base=0, env_idx=0, tex_idx=0):
+        g.set_int("probeSel", sel)
+        g.set_int("probeBase", base)
+        g.set_int("probeEnvIdx", env_idx)
+        g.set_int("probeTexIdx", tex_idx)
+        g.clear()
+        g.draw_tracer(0, rand_base, env_theta)
+        img, mism = g.read_screen(0)
+        assert mism == 0, f"{mism} replica mismatches"
+        return img
+
+    t0 = time.time()
+    color = run(0)
+    info = run(1)
+    count = info[..., 0].astype(np.uint32)
+    sig = (info[..., 1].astype(np.uint32) | (info[..., 2].astype(np.uint32) << 16))
+    calls = info[..., 3].astype(np.uint32)
+    n_rec = int(min(count.max(), PATH_REPLAY_CAP))
+    n_rec = (n_rec + 3) // 4 * 4
+    rec = np.zeros((H, W, max(n_rec, 4)), np.float32)
+    for base in range(0, n_rec, 4):
+        rec[..., base:base + 4] = run(2, base)
+    # what envSample returned for the path's k-th environment lookup (primary miss / NEE / the ray that leaves the scene)
+    e0 = run(3, 0, 0)
+    env_count = e0[..., 3].astype(np.uint32)
+    env = np.zeros((H, W, max(1, int(env_count.max())), 3), np.float32)
+    env[..., 0, :] = e0[..., :3]
+    for k in range(1, env.shape[2]):
+        env[..., k, :] = run(3, 0, k)[..., :3]
+    env_flat = np.concatenate([env[y, x, :env_count[y, x]].reshape(-1) for y in range(H) for x in range(W)])
+    # the four texture() results of every loop iteration (12 floats per iteration: diffuse.rgb, emissive.rgb, mr.rg, normal.rgb, 0)
+    tex_count = run(5)[..., 0].astype(np.uint32)
+    assert (tex_count % 4 == 0).all()
+    iters = tex_count // 4
+    tex = np.zeros((H, W, max(1, int(iters.max())), 12), np.float32)
+    for k in range(int(tex_count.max())):
+        v = run(4, 0, 0, k)
+        it, which = k // 4, k % 4
+        if which == 0: tex[..., it, 0:3] = v[..., :3]
+        elif which == 1: tex[..., it, 3:6] = v[..., :3]
+        elif which == 2: tex[..., it, 6:8] = v[..., :2]
+        else: tex[..., it, 8:11] = v[..., :3]
+    tex_flat = np.concatenate([tex[y, x, :iters[y, x]].reshape(-1) for y in range(H) for x in range(W)])
+    # ragged: only the values a pixel really drew
+    keep = np.minimum(count, rec.shape[-1])
+    flat = np.concatenate([rec[y, x, :keep[y, x]] for y in range(H) for x in range(W)]) if keep.sum() else np.zeros(0, np.float32)
+    print("path_replay", name, "rnd calls mean %.1f max %d" % (count.mean(), count.max()), "intersect calls max", int(calls.max()),
+          "hit pixels %.2f" % float((count > 0).mean()), "colour mean", color[..., :3].mean((0, 1)), round(time.time() - t0, 1), "s", flush=True)
+    np.savez_compressed(os.path.join(GOLD, f"glsl_path_replay_{name}.npz"), W=W, H=H, bounces=bounces, scene=scene_name,
+                        renderer=g.renderer, env_theta=np.float32(env_theta), rand_base=np.float32(rand_base),
+                        rays_pos=pos, rays_dir=d, color=color[..., :3].copy(), rnd_count=count, hit_sig=sig, hit_calls=calls,
+                        rnd_values=flat.astype(np.float32), cap=np.int32(rec.shape[-1]), env_count=env_count,
+                        env_values=env_flat.astype(np.float32), tex_iters=iters, tex_values=tex_flat.astype(np.float32))
+
+
 def probe(g, sel):
     if not getattr(g, "_probe_ready", False):
         g.tracer(main_override=PROBE_MAIN.replace("FCOORD", FC_REP if g.rep == 2 else "gl_FragCoord.xy"))
@@ -741,6 +911,11 @@ if __name__ == "__main__":
                 subprocess.check_call([sys.executable, "-u", os.path.abspath(__file__), "samplers:" + name])
         elif w.startswith("samplers:"):
             make_samplers(w.split(":", 1)[1])
+        elif w == "path_replay":
+            for name in ("small", "variant", "textured"):
+                subprocess.check_call([sys.executable, "-u", os.path.abspath(__file__), "path_replay:" + name])
+        elif w.startswith("path_replay:"):
+            make_path_replay(w.split(":", 1)[1])
         elif w == "atlas":
             make_atlas()
         elif w == "bvhtest":
