@@ -298,6 +298,13 @@ function loadBlob(path) {
 
 const PIPELINE_CODES = { megakernel: 0, wavefront: 1, stream: 2 };
 
+// a pipeline name (or a code of include/fspt_tuning.h's fspt_target_set_pipeline); anything else is an error, as in the Python host
+function pipelineCode(name) {
+  if (PIPELINE_CODES[name] !== undefined) return PIPELINE_CODES[name];
+  if (Number.isInteger(name) && name >= 0 && name <= 2) return name;
+  throw new Error("unknown pipeline '" + name + "' (want " + Object.keys(PIPELINE_CODES).join(', ') + ')');
+}
+
 class PathTracer {
   /** scene: {bvh,tri,mat,norm,uv,atlas,atlasRes,atlasLayers,env,envW,envH,bins,leafSize} */
   constructor(scene, width, height, device) {
@@ -349,7 +356,7 @@ class PathTracer {
   setViewport(w, h) { addon.setViewport(this._target, w || 0, h || 0); }
   setShard(shard, nShards, tile) { addon.setShard(this._target, shard, nShards, tile || 32); }
   /** 'wavefront' (batches of ticks), 'stream' (fixed pool of live paths), 'megakernel' (include/fspt_tuning.h) */
-  setPipeline(name, batch) { addon.setPipeline(this._target, PIPELINE_CODES[name] === undefined ? 1 : PIPELINE_CODES[name], batch || 0); }
+  setPipeline(name, batch) { addon.setPipeline(this._target, pipelineCode(name), batch || 0); }
   /** traversal steps a starved trace wave walks on before it suspends its rays (0 = never; include/fspt.h) */
   setTraceBudget(steps) { addon.setTraceBudget(this._target, steps); }
   /** stream scheduler: live paths per state set (0 = default), drain iterations (-1 = default), iteration cap (0 = none) */
@@ -365,7 +372,9 @@ class PathTracer {
   prepare() { addon.prepare(this._target); }
   enableCounters(on) { addon.enableCounters(this._target, !!on); }
   counters() { return addon.counters(this._target); }
-  close() { if (this._target) { addon.targetDestroy(this._target); addon.sceneDestroy(this._scene); this._target = null; } }
+  /** Recorded (deferred) ticks are executed first: fspt_target_destroy itself drops them (it never writes to a
+   *  caller-owned accumulator, include/fspt.h). */
+  close() { if (this._target) { try { addon.sync(this._target); } finally { addon.targetDestroy(this._target); addon.sceneDestroy(this._scene); this._target = null; } } }
 }
 
 /** The same frame driver over several GPUs of the node from this one JS thread (include/fspt.h: fspt_multi_*):
@@ -405,7 +414,7 @@ class MultiPathTracer {
       !!denoise, maxSigma === undefined ? 3 : maxSigma, out);
   }
   setPipeline(name, batch) {
-    const code = PIPELINE_CODES[name] === undefined ? 1 : PIPELINE_CODES[name];
+    const code = pipelineCode(name);
     for (let i = 0; i < this.devices.length; i++) addon.setPipeline(addon.multiTarget(this._multi, i), code, batch || 0);
   }
   close() { if (this._multi) { addon.multiDestroy(this._multi); this._multi = null; } }

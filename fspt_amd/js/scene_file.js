@@ -128,7 +128,7 @@ function readImage(root, rel) {
   const buf = fs.readFileSync(file);
   if (buf.length >= 8 && buf.slice(0, 8).equals(PNG_SIG)) return Object.assign(decodePng(buf), { currentSrc: rel });
   if (buf.length >= 3 && buf[0] === 0xFF && buf[1] === 0xD8 && buf[2] === 0xFF) return Object.assign(decodeJpeg(buf), { currentSrc: rel });
-  throw new Error(file + ': only PNG and baseline JPEG images are decoded by the Node host');
+  throw new Error(file + ': only PNG and JPEG (baseline / progressive) images are decoded by the Node host');
 }
 
 /** the urls obj_loader.js:185-187 fetches while parsing: basePath + '/' + the rest of each `mtllib` line */

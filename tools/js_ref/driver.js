@@ -78,13 +78,20 @@ import fs from 'fs';
     const { bvhBuffer, trianglesBuffer, materialBuffer, normalBuffer, uvBuffer } = packScene(bvh);   // main.js:358-392, cut from main.js
     const masked = maskBVHBuffer(bvhBuffer);                                                        // main.js:272-282
     console.log = realLog;
-    const b64 = (f32) => Buffer.from(f32.buffer, f32.byteOffset, f32.byteLength).toString('base64');
+    // large scenes (job.raw_dir): the arrays go to binary files, the JSON carries only their names (a 1 M-triangle
+    // scene's normals alone are 108 MB: as base64 inside one JSON string they pass V8's string limits)
+    const b64 = (f32, name) => {
+      const buf = Buffer.from(f32.buffer, f32.byteOffset, f32.byteLength);
+      if (!job.raw_dir) return buf.toString('base64');
+      fs.writeFileSync(job.raw_dir + '/' + name + '.f32', buf);
+      return { file: name + '.f32' };
+    };
     out.depth = bvh.depth;
-    out.bvh = b64(masked);
-    out.tri = b64(new Float32Array(trianglesBuffer));
-    out.mat = b64(new Float32Array(materialBuffer));
-    out.norm = b64(new Float32Array(normalBuffer));
-    out.uv = b64(new Float32Array(uvBuffer));
+    out.bvh = b64(masked, 'bvh');
+    out.tri = b64(new Float32Array(trianglesBuffer), 'tri');
+    out.mat = b64(new Float32Array(materialBuffer), 'mat');
+    out.norm = b64(new Float32Array(normalBuffer), 'norm');
+    out.uv = b64(new Float32Array(uvBuffer), 'uv');
   }
   fs.writeFileSync(process.argv[3], JSON.stringify(out));
 })().catch((e) => { console.error(e); process.exit(1); });

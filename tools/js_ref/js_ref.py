@@ -48,8 +48,11 @@ def _cut_block(src, head, start=0):
         i += 1
 
 
-def run(job, max_old_space_mb=6000):
+def run(job, max_old_space_mb=6000, raw=False):
+    """raw: the packed arrays come back through binary files instead of base64 in the JSON (large scenes)."""
     with tempfile.TemporaryDirectory() as td:
+        if raw:
+            job = dict(job, raw_dir=td)
         for f in ("vector.js", "bvh.js", "obj_loader.js", "mtl_loader.js", "utility.js", "env_sampler.js",
                   "texture_packer.js"):
             shutil.copy(os.path.join(REF, f), td)
@@ -81,8 +84,11 @@ def run(job, max_old_space_mb=6000):
                                "driver.js", "job.json", "out.json"], cwd=td,
                               stderr=None if os.environ.get("JS_REF_DEBUG") else subprocess.DEVNULL)
         out = json.load(open(os.path.join(td, "out.json")))
+        for k in ("bvh", "tri", "mat", "norm", "uv"):
+            if isinstance(out.get(k), dict):
+                out[k] = np.fromfile(os.path.join(td, out[k]["file"]), dtype=np.float32)
     for k in ("bvh", "tri", "mat", "norm", "uv"):
-        if k in out:
+        if k in out and not isinstance(out[k], np.ndarray):
             out[k] = np.frombuffer(base64.b64decode(out[k]), dtype=np.float32).copy()
     if "bins" in out:
         out["bins"] = np.array(out["bins"], dtype=np.uint32)

@@ -177,6 +177,33 @@ def make_js():
     print("js 70k", dig)
 
 
+def make_js_1m():
+    """BASELINE configs[2]'s input (1 002 256 triangles, bench.py --config c3) through the REFERENCE's own obj_loader.js +
+    bvh.js under Node (~2.5 min, ~4 GB): digests of its packed arrays, and where the native pipeline differs
+    (glibc vs V8 fdlibm atan2 / asin in the tangents' spherical-UV fallback, obj_loader.js:64-71)."""
+    import js_ref as J
+    props = S.bunny_props()
+    texts = {"synthetic/cube_sphere.obj": S.cube_sphere_obj(289), "synthetic/quad.obj": S.QUAD_OBJ}
+    t0 = time.time()
+    out = J.run(J.full_scene_job({"props": props}, texts), max_old_space_mb=24000, raw=True)
+    js_s = time.time() - t0
+    dig = {k: sha(out[k]) for k in ("bvh", "tri", "mat", "norm", "uv")}
+    dig.update(depth=int(out["depth"]), n_nodes=int(out["bvh"].size // 9), n_tris=int(out["tri"].size // 9),
+               js_seconds=round(js_s, 1), js_build_ms=out["build_ms"])
+    t0 = time.time()
+    nat = S.build_scene(props, texts)
+    dig["native_seconds"] = round(time.time() - t0, 1)
+    exc = {}
+    for k in ("bvh", "tri", "mat", "norm", "uv"):
+        d = np.where(getattr(nat, k).view(np.uint32) != out[k].view(np.uint32))[0]
+        if d.size:
+            ulp = np.abs(getattr(nat, k).view(np.int32)[d].astype(np.int64) - out[k].view(np.int32)[d].astype(np.int64))
+            exc[k] = {"index": d.tolist(), "js_bits": out[k].view(np.uint32)[d].tolist(), "max_ulp": int(ulp.max())}
+    dig["libm_exceptions"] = exc
+    json.dump(dig, open(os.path.join(GOLD, "js_scene_1M_digest.json"), "w"), indent=1)
+    print("js 1M", {k: v for k, v in dig.items() if k != "libm_exceptions"}, {k: (len(v["index"]), v["max_ulp"]) for k, v in exc.items()})
+
+
 def load_scene(name):
     """The reference JS pipeline's arrays + the atlas of the same scene."""
     z = np.load(os.path.join(GOLD, f"js_scene_{name}.npz"))
@@ -895,6 +922,8 @@ if __name__ == "__main__":
     for w in what:
         if w == "js":
             make_js()
+        elif w == "js1m":
+            make_js_1m()
         elif w == "glsl":
             make_glsl()
         elif w.startswith("glsl:"):
