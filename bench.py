@@ -37,13 +37,18 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2  # 1 228.8 G wave64 VALU instructions per second: CDNA4's SIMDs are 32 lanes wide, a
                                       # wave64 instruction issues over 2 cycles (MI355X_MICROARCH.md 'Wave scheduling')
 L2_GATHER_GUIDE_TBPS = (16.8, 18.8)  # MI355X_MICROARCH.md 'Indexed rows: gather into LDS': rows shared by every workgroup (the XCD's L2)
+# the same table's other rows, by the size of what is gathered from (here: the interior-node and leaf records the
+# traversal kernels read): chip-wide TB/s (low, high) and where the rows are served from
+GATHER_GUIDE_ROWS = [(8 << 20, (16.8, 18.8), "2,048 rows shared by every workgroup (the XCD's L2)"),
+                     (96 << 20, (8.6, 8.6), "38 MB table, uniformly random rows (Infinity Cache)"),
+                     (1 << 62, (7.4, 7.9), "151 MB table, uniformly random rows")]
 L1_PEAK_FALLBACK = 8.6e11     # 16-byte lane-requests/s of divergent 64-byte record gathers, all CUs (profiles/r03/l1_peak.json);
                               # bench.py measures it on the box it runs on (tools/microbench/l1_peak) and only falls
                               # back to this when the microbenchmark binary is missing
 
 # kernel classes of the wavefront pipeline -> kernel symbol (as rocprofv3 prints it) and the resource that bounds it
 KERNELS = {
-    "primary": ("fspt::k_wf_primary<false, true>", "hbm"),
+    "primary": ("fspt::k_wf_primary<false, true>", "valu"),
     "trace": ("fspt::k_wf_trace<false, true>", "l1"),
     "logic": ("fspt::k_wf_logic<false, true>", "hbm"),
     "resolve": ("fspt::k_wf_resolve", "hbm"),
@@ -150,6 +155,8 @@ def parse_args(argv=None):
     ap.add_argument("--tex-interleave-budget", type=int, default=None,
                     help="bytes of interleaved material textures the scene may use (A/B: 0 = single-layer images only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="only the headline workload (default: after it, BASELINE configs[2] and [4] at N = 1 / configs[3] at N > 1 as extra_configs)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of the timed run's accumulator")
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel", "stream"])
     ap.add_argument("--pool", type=int, default=0, help="stream scheduler: live paths per state set (0 = library default)")
@@ -279,69 +286,50 @@ def dry_run(args, rank, local_rank, world):
         raise SystemExit("dry run: exchanged frame is wrong")
 
 
-def main():
-    args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return self_launch(args)
+def _extra_argv(argv, over, steps, warmup):
+    """The command line of an extra config: this run's own arguments with the workload-selecting ones replaced."""
+    drop_val = {"--config", "--steps", "--warmup", "--width", "--height", "--scaling", "--mesh-n", "--aperture", "--sun-deg", "--sun-gain", "--batch"}
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in drop_val:
+            skip = True
+            continue
+        if any(a.startswith(d + "=") for d in drop_val):
+            continue
+        out.append(a)
+    out += ["--config", over["config"], "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extra-configs"]
+    return out
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
-                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ..., "
-                         f"or plain `python bench.py --gpus {args.gpus}`, which launches the ranks itself)")
-    n_gpus = world
-    if args.dry_run:
-        return dry_run(args, rank, local_rank, world)
 
-    # The request-rate peak the trace kernel is priced against is measured first, by a child process started BEFORE this
-    # process touches the GPU (no fork of a process that holds a HIP context).  Under a profiler the preloaded library
-    # has initialised the GPU before main() runs: such runs pass --l1-peak (tools/prof_r04.sh measures it once, outside
-    # rocprofv3) or --no-l1-microbench, and no child is ever started from this process.
-    global _L1_PEAK
-    if rank == 0 and _L1_PEAK is None:
-        if args.l1_peak is not None:
-            _L1_PEAK = (float(args.l1_peak), {"source": "--l1-peak (tools/microbench/l1_peak, measured outside this run)",
-                                              "gather_lane_requests_per_s": float(args.l1_peak)})
-        elif args.no_l1_microbench or _under_profiler():
-            _L1_PEAK = (L1_PEAK_FALLBACK, {"source": "fallback constant (microbenchmark not started: "
-                                                     + ("--no-l1-microbench" if args.no_l1_microbench else "profiler preload detected") + ")"})
-        else:
-            _L1_PEAK = l1_request_peak()
+def trim_extra(o, seconds):
+    """What extra_configs carries of a workload's full JSON object."""
+    r = o.get("roofline") or {}
+    keep = {k: o[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "reps", "rep_ms_per_step", "parity_check", "exchange_ms") if k in o}
+    keep["config"] = {k: o["config"][k] for k in ("workload", "scene_bytes", "bvh_nodes", "bvh_depth", "env_bins", "batch_ticks", "path_state_bytes", "primary_form", "scene_build_s", "sharding", "exchange") if k in o["config"]}
+    keep["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_range", "frac_vs_l1_microbench", "peak_is", "kernel", "kernel_class", "share_of_gpu_time", "avg_launch_ms", "launches", "traffic", "hbm_counter", "bytes_per_sample", "per_sample", "alg_over_hbm_peak")}
+    keep["roofline"]["kernels"] = {c: {k: v.get(k) for k in ("ms_per_step", "launches", "avg_launch_ms", "alg_GBps", "traffic_GBps", "frac", "bound")} for c, v in (r.get("kernels") or {}).items()}
+    keep["wall_s"] = round(seconds, 1)
+    return keep
+class Env:
+    """What every workload of one bench.py process shares: the rank's place in the job and its process group."""
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
 
+
+def run_workload(args, env):
+    """One workload (scene, frame, configuration) on this rank: warm-up, --reps timed regions of exactly --steps steps
+    between barriers, the read-out exchange inside every region, max over ranks; rank 0 returns the JSON object (with its
+    parity check against the oracle), the other ranks None."""
     import numpy as np
     import torch
     import fspt_amd
     from fspt_amd import scene as S
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (libfspt has no CPU path)")
-    if args.share_gpu:
-        local_rank = 0
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
-    torch.cuda.set_device(local_rank)
     from fspt_amd import distributed as D
-    # the process group's own timeout (what RCCL's watchdog applies to every collective) is generous - rank 0 checks the
-    # frame against the oracle and counts work while the others wait at the closing barrier; the tighter deadlines around
-    # the rendezvous, the barriers of the timed regions and the exchange are the Watchdogs below
-    dist = (D.init_process_group(backend="gloo" if args.share_gpu else "nccl", device=torch.device("cuda", local_rank),
-                                 timeout_s=max(600.0, 2 * args.rendezvous_timeout))
-            if n_gpus > 1 else None)
-    world_seen = dist.get_world_size() if dist is not None else 1
-    if world_seen != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but RCCL sees {world_seen} ranks")
-    rank_info = None
-    if n_gpus > 1:
-        # every rank says who it is before anything can hang (stderr; rank 0's JSON line stays alone on stdout)
-        rank_info = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
-                     "visible_devices": torch.cuda.device_count(),
-                     "peer_access_to_rank0_device": bool(local_rank == 0 or torch.cuda.can_device_access_peer(local_rank, 0)),
-                     "rccl": _rccl_version(torch),
-                     "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
-        sys.stderr.write("[bench rank] " + json.dumps(rank_info) + "\n"); sys.stderr.flush()
-
+    rank, local_rank, n_gpus, dist, world_seen, rank_info = env.rank, env.local_rank, env.n_gpus, env.dist, env.world_seen, env.rank_info
+    result = None
     t0 = time.perf_counter()
     if args.textured:
         arrays = S.bunny_scene_textured(n=args.mesh_n, sun_deg=args.sun_deg, sun_gain=args.sun_gain)
@@ -448,13 +436,106 @@ def main():
         if n_gpus > 1:
             out["exchange_ms"] = round(exch_ms[med], 3)  # read-out exchange + closing barrier of the median region (inside `value`)
             out["rank0"] = rank_info
+        result = out
+    pt.close()
+    return result
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if _under_profiler():
+            # the profiler's preloaded library has initialised the GPU in THIS process: starting (exec'ing) rank children
+            # from it is exactly what the pool forbids, and their kernels would not be the ones profiled anyway
+            raise SystemExit("bench.py: --gpus N > 1 under a profiler: profile ONE rank directly after `--` "
+                             "(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), not the launcher")
+        return self_launch(args)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ..., "
+                         f"or plain `python bench.py --gpus {args.gpus}`, which launches the ranks itself)")
+    n_gpus = world
+    if args.dry_run:
+        return dry_run(args, rank, local_rank, world)
+
+    # The request-rate peak the trace kernel is priced against is measured first, by a child process started BEFORE this
+    # process touches the GPU (no fork of a process that holds a HIP context).  Under a profiler the preloaded library
+    # has initialised the GPU before main() runs: such runs pass --l1-peak (tools/prof_r04.sh measures it once, outside
+    # rocprofv3) or --no-l1-microbench, and no child is ever started from this process.
+    global _L1_PEAK
+    if rank == 0 and _L1_PEAK is None:
+        if args.l1_peak is not None:
+            _L1_PEAK = (float(args.l1_peak), {"source": "--l1-peak (tools/microbench/l1_peak, measured outside this run)",
+                                              "gather_lane_requests_per_s": float(args.l1_peak)})
+        elif args.no_l1_microbench or _under_profiler():
+            _L1_PEAK = (L1_PEAK_FALLBACK, {"source": "fallback constant (microbenchmark not started: "
+                                                     + ("--no-l1-microbench" if args.no_l1_microbench else "profiler preload detected") + ")"})
+        else:
+            _L1_PEAK = l1_request_peak()
+
+    import numpy as np
+    import torch
+    import fspt_amd
+    from fspt_amd import scene as S
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libfspt has no CPU path)")
+    if args.share_gpu:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
+    torch.cuda.set_device(local_rank)
+    from fspt_amd import distributed as D
+    # the process group's own timeout (what RCCL's watchdog applies to every collective) is generous - rank 0 checks the
+    # frame against the oracle and counts work while the others wait at the closing barrier; the tighter deadlines around
+    # the rendezvous, the barriers of the timed regions and the exchange are the Watchdogs below
+    dist = (D.init_process_group(backend="gloo" if args.share_gpu else "nccl", device=torch.device("cuda", local_rank),
+                                 timeout_s=max(600.0, 2 * args.rendezvous_timeout))
+            if n_gpus > 1 else None)
+    world_seen = dist.get_world_size() if dist is not None else 1
+    if world_seen != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but RCCL sees {world_seen} ranks")
+    rank_info = None
+    if n_gpus > 1:
+        # every rank says who it is before anything can hang (stderr; rank 0's JSON line stays alone on stdout)
+        rank_info = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
+                     "visible_devices": torch.cuda.device_count(),
+                     "peer_access_to_rank0_device": bool(local_rank == 0 or torch.cuda.can_device_access_peer(local_rank, 0)),
+                     "rccl": _rccl_version(torch),
+                     "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+        sys.stderr.write("[bench rank] " + json.dumps(rank_info) + "\n"); sys.stderr.flush()
+
+    env = Env(rank=rank, local_rank=local_rank, n_gpus=n_gpus, dist=dist, world_seen=world_seen, rank_info=rank_info)
+    out = run_workload(args, env)
+    # ---- the other BASELINE configs on the same record: after the headline, whose JSON keys and
+    # timed regions are exactly what they were.  N = 1: configs[2] (1 M triangles) and configs[4] (aperture 0.1 + small
+    # sun) as extra_configs.c3 / .c5; N > 1 on the weak-scaled default: configs[3] (3840x2160 cut over the N ranks,
+    # strong scaling) as extra_configs.strong_c4.  Each with its own regions, per-kernel times and parity check.
+    extras = []
+    if not args.no_extra_configs and args.config == "c2" and args.pipeline == "wavefront" and not args.textured:
+        if n_gpus == 1:
+            extras = [("c3", dict(config="c3")), ("c5", dict(config="c5"))]
+        elif args.scaling == "weak":
+            extras = [("strong_c4", dict(config="c4"))]
+    for key, over in extras:
+        a2 = parse_args(_extra_argv(sys.argv[1:], over, steps=min(args.steps, 20), warmup=min(args.warmup, 5)))
+        t_x = time.perf_counter()
+        o2 = run_workload(a2, env)
+        if rank == 0 and out is not None and o2 is not None:
+            out.setdefault("extra_configs", {})[key] = trim_extra(o2, time.perf_counter() - t_x)
+    if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
-        if check is not None and not check["equal"]:
-            raise SystemExit("bench.py: the timed run's accumulator differs from the oracle")
+        bad = [k for k, v in [("headline", out)] + list(out.get("extra_configs", {}).items())
+               if v.get("parity_check") is not None and not v["parity_check"]["equal"]]
+        if bad:
+            raise SystemExit(f"bench.py: the timed run's accumulator differs from the oracle ({', '.join(bad)})")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    pt.close()
     return 0
 
 
@@ -577,14 +658,31 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
                 # reference-layout bytes (60 per step, 144 per leaf) next to it: cross-checks of `frac` that use no
                 # builder-measured peak
                 req_tbps = rps * 16.0 / 1e12
+                # which row of the guide's gather table prices it: by the bytes the traversal gathers from - 64 B per
+                # interior node + 36 B x leaf size per leaf (what fspt_scene_create uploads for the traversal kernels)
+                n_leaf = int((arrays.bvh.view("int32").reshape(-1, 9)[:, 2] > -1).sum())
+                trav_bytes = 64 * (arrays.n_nodes - n_leaf) + 36 * arrays.leaf_size * n_leaf
+                g_lo, g_hi, g_row = next((lo, hi, row) for lim, (lo, hi), row in GATHER_GUIDE_ROWS if trav_bytes <= lim)
                 kj.update({"lane_requests_per_step": round(tr_req), "achieved_Greq_per_s": round(rps / 1e9, 1),
                            "peak_Greq_per_s": round(l1_peak / 1e9, 1), "frac": round(rps / l1_peak, 4),
+                           "gather": {"traversal_bytes": trav_bytes, "requested_GBps": round(req_tbps * 1e3, 1), "guide_row": g_row,
+                                      "guide_GBps": [g_lo * 1e3, g_hi * 1e3], "frac": round(req_tbps / g_hi, 4),
+                                      "frac_range": [round(req_tbps / g_hi, 4), round(req_tbps / g_lo, 4)]},
                            "lds_served_interior_steps": round(act["trace_lds_steps"] / max(1, tr_int), 3),
                            "l2_gather": {"requested_TBps": round(req_tbps, 2), "reference_layout_TBps": round(gbps / 1e3, 2),
                                          "guide_TBps": list(L2_GATHER_GUIDE_TBPS),
                                          "requested_frac_of_guide": [round(req_tbps / g, 3) for g in reversed(L2_GATHER_GUIDE_TBPS)],
                                          "reference_layout_frac_of_guide": [round(gbps / 1e3 / g, 3) for g in reversed(L2_GATHER_GUIDE_TBPS)],
                                          "guide": "MI355X_MICROARCH.md, 'Indexed rows: gather into LDS', rows shared by every workgroup"}})
+            elif bound == "valu":
+                # the fused ray-generation + traversal + shading launch issues vector-ALU instructions (profiles/r04:
+                # TA / TD 0.37 / 0.50 busy, nothing on the memory side saturated): wave-instructions per second over
+                # the chip's issue rate, when the stamped SQ_INSTS_VALU count of this code exists
+                wi = prof["kernels"][pkey].get("valu_wave_instr_per_sample") if pkey else None
+                ach = wi * spt * steps / (ms / 1e3) / 1e9 if (wi is not None and ms > 0) else None
+                kj.update({"valu_wave_instr_per_sample": wi, "achieved_Ginstr_per_s": round(ach, 1) if ach is not None else None,
+                           "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": round(ach / VALU_PEAK_GINSTR, 4) if ach is not None else None,
+                           "frac_is": "VALU wave-instructions issued per second / (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction)"})
             elif bound == "hbm":
                 # HBM kernels are priced on what they really move between L2 and the fabric when the counters are available
                 # (cache-resident scene data never has to come from HBM), else on the algorithmic bytes
@@ -619,13 +717,23 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
         d_ms, d_n = stages[dom_class]
         total_ms = sum(v[0] for v in stages.values())
         if dom["bound"] == "l1" and dom_class == "trace":
-            roofline = {"bound": "l1", "achieved": dom["achieved_Greq_per_s"], "peak": dom["peak_Greq_per_s"], "unit": "Grequests/s",
-                        "frac": dom["frac"], "traffic": dom["traffic_bytes_per_launch"],
-                        "achieved_is": "per-lane vector-memory requests of this kernel (4 per interior step not served from LDS, "
-                                       "9 per leaf visit, 4 per path item; counted by the kernel's counting variant on this "
-                                       "frame) / its HIP-event time",
-                        "peak_is": "lane-requests/s of a pure 64-byte-record gather (4 x dwordx4 per lane) from an L2-resident "
-                                   "table at this kernel's occupancy", "peak_source": l1_src,
+            # Headline fraction: the bytes the kernel REQUESTS per second (16 per lane-request) over the
+            # rate the guide itself measured for a gather from a table of this size - recomputable from this line and
+            # MI355X_MICROARCH.md alone; `peak` is the upper end of the guide's range (the lower end: frac_range[1]).
+            # The same-box microbenchmark (lane-requests of a pure 64-byte-record gather) stays beside it.
+            gth = dom["gather"]
+            roofline = {"bound": "cache-gather", "achieved": gth["requested_GBps"], "peak": gth["guide_GBps"][1], "unit": "GB/s",
+                        "frac": gth["frac"], "frac_range": gth["frac_range"], "traffic": dom["traffic_bytes_per_launch"],
+                        "achieved_is": "16 B x the per-lane vector-memory requests of this kernel (4 per interior step not served "
+                                       "from LDS, 9 per leaf visit, 4 per path item; counted by the kernel's counting variant on "
+                                       "this frame) / its HIP-event time",
+                        "peak_is": f"MI355X_MICROARCH.md 'Indexed rows: gather into LDS', chip-wide rate of the row '{gth['guide_row']}' "
+                                   f"(the traversal gathers from {gth['traversal_bytes'] / 1e6:.1f} MB of node and leaf records)",
+                        "frac_vs_l1_microbench": dom["frac"],
+                        "l1_microbench": {"achieved_Greq_per_s": dom["achieved_Greq_per_s"], "peak_Greq_per_s": dom["peak_Greq_per_s"],
+                                          "is": "lane-requests/s of this kernel over those of a pure 64-byte-record gather (4 x dwordx4 per "
+                                                "lane) from an L2-resident table at this kernel's occupancy, measured in this run on this box",
+                                          "peak_source": l1_src},
                         "requests_per_launch": round(tr_req * steps / max(1, d_n))}
         else:
             roofline = {"bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

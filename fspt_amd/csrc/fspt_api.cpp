@@ -58,12 +58,24 @@ static const int WF_ARRAYS = 15;
 #define FSPT_SUSP_BUDGET 24 // profiles/r03/ab_trace_suspend_budget.log: 0 / 16 / 24 / 32 / 48 -> 3 883 / 3 938 / 3 940 / 3 935 / 3 921 Msamples/s in 20-step regions (same box, twice)
 #endif
 static const uint32_t ST_DEFAULT_SUSP_BUDGET = FSPT_SUSP_BUDGET;
-// Library's choice of the node form (fspt_target::node_form = -1), per kernel class; profiles/r05/ab_two_level_nodes*.log
+// Library's choice of the node form (fspt_target::node_form = -1), per kernel class.  Measured (profiles/r05/ab_two_level_*.log,
+// one box, interleaved): the two-level nodes LOSE in every regime they were built for - tail kernel 0.037 -> 0.040-0.045 ms
+// per tick (C2, 20 ticks), 0.82 -> 0.80-0.92 (single tick), 0.125 -> 0.145 (1 M triangles); trace launches 0.170 -> 0.21 /
+// 0.215 -> 0.26; primary 0.127 -> 0.138 / 0.176 -> 0.193.  Halving the dependent round trips buys nothing because a step's
+// time is not a cache-miss latency: it is the CU's vector-memory front end working through the lane-requests of all its
+// resident waves (16 waves x 4 instructions x (4.6 + 0.63 x active lanes) cycles = the 1 900 clocks per step round-4
+// measured in the tail kernel), and a two-level fetch issues 8 requests where the walk needs 4 or 8.  So: everything off.
 #ifndef FSPT_WIDE_PRIMARY
 #define FSPT_WIDE_PRIMARY 0
 #endif
 #ifndef FSPT_WIDE_TAIL
-#define FSPT_WIDE_TAIL 1
+#define FSPT_WIDE_TAIL 0
+#endif
+#ifndef FSPT_CARRY_BLOCKS
+#define FSPT_CARRY_BLOCKS 4u // trailing blocks of a logic launch that do k_wf_carry's work (0: a separate launch per round, as in rounds 3-4)
+#endif
+#ifndef FSPT_RESOLVE_CLEARS
+#define FSPT_RESOLVE_CLEARS 1 // the batch's resolve launch hands the live-path counts to the host and clears counters + pool heads (0: fill / copy commands)
 #endif
 #ifndef FSPT_WIDE_TRACE_BELOW
 #define FSPT_WIDE_TRACE_BELOW 0u // paths
@@ -102,6 +114,8 @@ struct fspt_target {
     fspt::WfCounts *counts = nullptr;
     uint32_t *heads = nullptr;             // trace pool heads (fspt_device.hpp)
     fspt::WfCounts *counts_host = nullptr; // pinned copy of the last batch's per-round counts (tail heuristic)
+    uint32_t *live_host = nullptr, *live_dev = nullptr; // ... or (counts_live) the live paths per round as the resolve launch wrote them: pinned host memory and its device address
+    bool counts_live = false;
     hipEvent_t counts_ready = nullptr;
     bool counts_pending = false;
     uint32_t counts_slots = 0;             // slots of the batch the copy describes
@@ -186,6 +200,7 @@ static size_t tile_image(const uint8_t *src, uint32_t w, uint32_t h, std::vector
 }
 
 static int flush_pending(fspt_target *t);
+static void prim_reset(fspt_target *t);
 static int materialise_rays(fspt_target *t);
 #define FLUSH_OR_RETURN(t) do { int rc_f = flush_pending(t); if (rc_f) return rc_f; } while (0)
 
@@ -714,6 +729,7 @@ int fspt_target_destroy(fspt_target *t) {
     hipFree(ln.counts);
     hipFree(ln.heads);
     if (ln.counts_host) hipHostFree(ln.counts_host);
+    if (ln.live_host) hipHostFree(ln.live_host);
     if (ln.counts_ready) hipEventDestroy(ln.counts_ready);
     if (ln.resolved) hipEventDestroy(ln.resolved);
     if (ln.stream_b) hipStreamSynchronize(ln.stream_b);
@@ -740,6 +756,7 @@ int fspt_target_set_shard(fspt_target *t, uint32_t shard, uint32_t n_shards, uin
   FLUSH_OR_RETURN(t);
   if (n_shards == 0 || shard >= n_shards) { fspt_set_error("shard %u of %u invalid", shard, n_shards); return FSPT_E_INVALID; }
   if (tile == 0 || tile % 8 != 0 || tile > 256) { fspt_set_error("tile %u must be a multiple of 8 in [8,256]", tile); return FSPT_E_INVALID; }
+  if (t->shard != shard || t->n_shards != n_shards || t->tile != tile) prim_reset(t);
   t->shard = shard; t->n_shards = n_shards; t->tile = tile;
   return FSPT_OK;
 }
@@ -823,18 +840,27 @@ static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
 // most one ray per launch; launch_wf: min(ceil(paths / 256), 8 blocks per CU) blocks of 256), two buffers, grown on
 // demand.  They are part of the target's path state (fspt_target_path_state_bytes, fspt_target_set_memory_limit): when
 // they do not fit what the limit leaves, traversals are simply not suspended (*on = false) - same results, a little slower.
-static int susp_ensure(fspt_target *t, fspt_target::WfLane &ln, uint64_t max_paths, bool *on) {
+static uint64_t susp_need(const fspt_target *t, uint64_t max_paths, uint32_t *stride_out, size_t *recs_out) {
   const uint32_t stride = ((uint32_t)fspt::WF_SUSP_HEADER + t->scene->d.stack_n + 3u) & ~3u;
   const uint64_t grid_max = (uint64_t)t->scene->num_cus * 8u;
   uint64_t blocks = (max_paths + 255u) / 256u;
   if (blocks > grid_max) blocks = grid_max;
   if (blocks < 1) blocks = 1;
   const size_t recs = (size_t)blocks * 256u;
+  if (stride_out) *stride_out = stride;
+  if (recs_out) *recs_out = recs;
+  return 2ull * recs * stride * sizeof(int);
+}
+static int susp_ensure(fspt_target *t, fspt_target::WfLane &ln, uint64_t max_paths, bool *on) {
+  uint32_t stride; size_t recs;
+  const uint64_t need = susp_need(t, max_paths, &stride, &recs);
   *on = true;
-  if (ln.susp[0] && ln.susp_stride == stride && ln.susp_recs >= recs) return FSPT_OK;
+  if (ln.susp[0] && ln.susp_stride == stride && ln.susp_recs >= recs) {
+    // the path state may have grown since the records were made: the limit covers both
+    if (!t->mem_limit || ln.bytes + ln.susp_bytes <= t->mem_limit) return FSPT_OK;
+  }
   for (int *&b : ln.susp) { if (b) { HIP_TRY(hipFree(b)); b = nullptr; } }
   ln.susp_bytes = 0; ln.susp_recs = 0;
-  const uint64_t need = 2ull * recs * stride * sizeof(int);
   if (t->mem_limit && ln.bytes + need > t->mem_limit) { *on = false; return FSPT_OK; }
   for (int *&b : ln.susp) {
     hipError_t e = hipMalloc((void **)&b, recs * stride * sizeof(int));
@@ -893,6 +919,11 @@ static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots, ui
   if (!ln.counts) HIP_TRY(hipMalloc((void **)&ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2)));
   if (!ln.heads) HIP_TRY(hipMalloc((void **)&ln.heads, WF_HEADS_BYTES));
   if (!ln.counts_host) HIP_TRY(hipHostMalloc((void **)&ln.counts_host, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), hipHostMallocDefault));
+  if (!ln.live_host) {
+    HIP_TRY(hipHostMalloc((void **)&ln.live_host, sizeof(uint32_t) * (WF_ROUNDS_MAX + 2), hipHostMallocMapped));
+    std::memset(ln.live_host, 0, sizeof(uint32_t) * (WF_ROUNDS_MAX + 2));
+    if (hipHostGetDevicePointer((void **)&ln.live_dev, ln.live_host, 0) != hipSuccess) { (void)hipGetLastError(); ln.live_dev = nullptr; } // (falls back to the copy command)
+  }
   if (!ln.counts_ready) HIP_TRY(hipEventCreateWithFlags(&ln.counts_ready, hipEventDisableTiming));
   HIP_TRY(hipStreamSynchronize(ln.stream));
   ln.slots = slots;
@@ -927,7 +958,15 @@ static int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ti
     // no-bounce-left flag share the word); WF_SLOT_BUDGET keeps every batch below that, a single tick of a frame beyond
     // 2^29 pixels does not fit
     if ((uint64_t)batch * work_total > 0x1FFFFFFFull) { fspt_set_error("frame too large for the wavefront pipeline (more than 2^29 paths per batch)"); return FSPT_E_INVALID; }
-    const uint64_t budget = t->mem_limit ? t->mem_limit / wf_slot_bytes() : ~0ull;
+    // the limit covers the suspension records too (susp_ensure): the slots get what the records this batch needs leave,
+    // unless the records alone would take more than a quarter of the limit - then traversals are simply not suspended
+    uint64_t budget = ~0ull;
+    if (t->mem_limit) {
+      uint64_t lim = t->mem_limit;
+      const uint64_t rec = (t->susp_budget != 0 && t->count == 0) ? susp_need(t, (uint64_t)batch * work_total, nullptr, nullptr) : 0;
+      if (rec <= lim / 4) lim -= rec;
+      budget = lim / wf_slot_bytes();
+    }
     int rc = wf_ensure(t, t->wf, (uint32_t)(batch * work_total), budget);
     if (rc != FSPT_E_NOMEM) return rc;
     if (batch <= 1) return rc; // one tick does not fit: give up (message set by wf_ensure)
@@ -949,6 +988,11 @@ static void prim_collect(fspt_target *t, bool wait) {
     st.runs[f]++;
   }
   t->prim_pending = false;
+}
+// the measurements describe one launch geometry (shard, viewport, node form, pipeline): a setter that changes it forgets them
+static void prim_reset(fspt_target *t) {
+  t->prim_pending = false; // (an event pair in flight is simply never read)
+  t->prim_ms.clear();
 }
 // ... and the form for the next batch of `ticks` ticks.  X = the form the scene's size suggests (per-lane refill pays
 // where ray lengths scatter: sub-pixel triangles), Y the other one.  Batch 1 of a size runs X - cold: a size's first batch
@@ -992,7 +1036,8 @@ static void wf_collect_counts(fspt_target *t, fspt_target::WfLane &ln) {
   if (!ln.counts_pending || hipEventQuery(ln.counts_ready) != hipSuccess) return;
   ln.counts_pending = false;
   if (!ln.counts_slots) return;
-  for (uint32_t r = 0; r < WF_ROUNDS_MAX + 2 && r < 80; ++r) t->live_frac[r] = (float)ln.counts_host[r].n_ext / (float)ln.counts_slots;
+  for (uint32_t r = 0; r < WF_ROUNDS_MAX + 2 && r < 80; ++r)
+    t->live_frac[r] = (float)(ln.counts_live ? ln.live_host[r] : ln.counts_host[r].n_ext) / (float)ln.counts_slots;
   t->live_known = true;
 }
 
@@ -1119,7 +1164,12 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
     bool prev_trace_suspends = false; // (no carry launch behind a trace launch that cannot have suspended anything)
     for (uint32_t r = 1; r <= last && r <= tail; ++r) {
       set_round(r);
-      if (r > 1 && susp_on && prev_trace_suspends) { if ((rc = launch(fspt::WF_K_CARRY))) return rc; } // the paths trace(r-1) suspended move on
+      // the paths trace(r-1) suspended move on: a few trailing blocks of the logic launch (FSPT_CARRY_BLOCKS 0: a launch of their own)
+      p.carry_blocks = 0u;
+      if (r > 1 && susp_on && prev_trace_suspends) {
+        if (FSPT_CARRY_BLOCKS) p.carry_blocks = FSPT_CARRY_BLOCKS;
+        else if ((rc = launch(fspt::WF_K_CARRY))) return rc;
+      }
       if (r == 1 && time_primary) HIP_TRY(hipEventRecord(t->prim_ev[0], st));
       if ((rc = launch(r == 1 ? fspt::WF_K_PRIMARY : fspt::WF_K_LOGIC))) return rc;
       if (r == 1 && time_primary) {
@@ -1144,16 +1194,25 @@ static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint3
       set_round(tail);
       if ((rc = launch(fspt::WF_K_TAIL))) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(ln.counts_host, ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), hipMemcpyDeviceToHost, st));
+    // The batch's live-path counts go to the host (the tail heuristic's statistics, never waited for) and the counters
+    // and pool heads are cleared for the next batch.  Rounds 1-4: a copy command in front of the resolve launch and two
+    // fill commands behind it (2.4 % + 1.2 % of a 20-tick batch's GPU time, profiles/r04/final_kernel_stats.csv); now
+    // block 0 of the resolve launch does all three (pinned host memory is written by the kernel itself).
+    const bool resolve_clears = FSPT_RESOLVE_CLEARS && ln.live_dev != nullptr;
+    p.live_out = resolve_clears ? ln.live_dev : nullptr;
+    p.zero_rounds = resolve_clears ? WF_ROUNDS_MAX + 2 : 0u;
+    if (!resolve_clears) HIP_TRY(hipMemcpyAsync(ln.counts_host, ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), hipMemcpyDeviceToHost, st));
+    // the running mean is order-dependent (tracer.fs:517): batches resolve in tick order - they follow each other on `st`
+    if ((rc = launch(fspt::WF_K_RESOLVE))) return rc;
+    p.zero_rounds = 0u;
     HIP_TRY(hipEventRecord(ln.counts_ready, st));
     ln.counts_pending = true;
     ln.counts_slots = nbt * work_total;
-    // the running mean is order-dependent (tracer.fs:517): batches resolve in tick order - they follow each other on `st`
-    if ((rc = launch(fspt::WF_K_RESOLVE))) return rc;
-    // the next batch's counters and pool heads are cleared now, behind this batch (the clears used to sit between a
-    // render call and its first kernel: ~0.1 ms of every timed region)
-    HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
-    HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, st));
+    ln.counts_live = resolve_clears;
+    if (!resolve_clears) {
+      HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
+      HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, st));
+    }
     ln.zeroed = true;
     done += nbt;
   }
@@ -1223,7 +1282,13 @@ static int st_plan(const fspt_target *t, uint32_t units, uint32_t nbt, uint32_t 
     // what the memory limit leaves per lane: 204 bytes per pool path + its share of the ring, 12 * (horizon + 3) / 2
     // (one stream: / 1) bytes, + one unit of rounding
     const uint64_t per_path = (wf_slot_bytes() - 12) + (overlap ? 6ull : 12ull) * (pl.horizon + 3u);
-    const uint64_t lane_limit = t->mem_limit;
+    uint64_t lane_limit = t->mem_limit;
+    // ... minus the suspension records of a pool-sized trace grid (they count as path state: susp_ensure), unless they
+    // alone would take more than a quarter of the limit - then this target's traversals are not suspended
+    if (t->susp_budget != 0 && t->count == 0) {
+      const uint64_t rec = susp_need(t, cap, nullptr, nullptr);
+      if (rec <= lane_limit / 4) lane_limit -= rec;
+    }
     const uint64_t round_up = 12ull * (pl.horizon + 3u) * pl.unit_slots;
     const uint64_t fit = lane_limit > round_up ? (lane_limit - round_up) / per_path : 0;
     if (cap > fit) cap = fit;
@@ -1360,8 +1425,10 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
         if (!overlap) {
           // ---- one stream: logic(it) first, so that plan(it) sees what really survived and fills the pool to the brim
           if (it >= 1) {
-            if (susp_run && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
+            p.carry_blocks = susp_run ? FSPT_CARRY_BLOCKS : 0u;
+            if (susp_run && !FSPT_CARRY_BLOCKS && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
             if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
+            p.carry_blocks = 0u;
           }
           if ((rc = launch(fspt::WF_K_PLAN, p, A))) return rc;
           if ((rc = launch(fspt::WF_K_PRIMARY, p, A))) return rc;
@@ -1390,8 +1457,10 @@ static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t
         }
         // ---- A: logic(it) on the results of trace(it - 1), then trace(it) once primary(it) has added its survivors
         if (it >= 1) {
-          if (susp_run && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
+          p.carry_blocks = susp_run ? FSPT_CARRY_BLOCKS : 0u;
+          if (susp_run && !FSPT_CARRY_BLOCKS && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
           if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
+          p.carry_blocks = 0u;
           HIP_TRY(hipEventRecord(ln.ev_logic[it % R], A));
         }
         HIP_TRY(hipStreamWaitEvent(A, ln.ev_b[it % R], 0));
@@ -1653,8 +1722,10 @@ int fspt_target_set_viewport(fspt_target *t, uint32_t w, uint32_t h) {
   if (!t) { fspt_set_error("fspt_target_set_viewport: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
   if (w > t->W || h > t->H) { fspt_set_error("fspt_target_set_viewport: %ux%u exceeds the target %ux%u", w, h, t->W, t->H); return FSPT_E_INVALID; }
-  t->vw = w ? w : t->W;
-  t->vh = h ? h : t->H;
+  const uint32_t nw = w ? w : t->W, nh = h ? h : t->H;
+  if (nw != t->vw || nh != t->vh) prim_reset(t);
+  t->vw = nw;
+  t->vh = nh;
   return FSPT_OK;
 }
 
@@ -1723,7 +1794,7 @@ int fspt_target_set_node_form(fspt_target *t, int primary, int trace, int tail, 
   FLUSH_OR_RETURN(t);
   for (int k = 0; k < 3; ++k) t->node_form[k] = v[k];
   if (trace_below >= 0) t->wide_trace_below = trace_below > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)trace_below;
-  t->prim_ms.clear(); // the primary-form measurements were taken with the other node form
+  prim_reset(t); // the primary-form measurements were taken with the other node form
   return FSPT_OK;
 }
 

@@ -252,6 +252,12 @@ struct WfP {
   int *susp[2];         // suspended-traversal records: trace(i) writes susp[cnt_out & 1], resumes susp[cnt_in & 1]
   uint32_t susp_stride; // ints per record (WF_SUSP_HEADER + stack entries, a multiple of 4)
   uint32_t susp_budget; // traversal steps a wave walks on after its last refill before it suspends (0: never)
+  // batch scheduler, resolve launch (the last kernel of a batch): block 0 copies the rounds' live-path counts to
+  // `live_out` (pinned host memory: the tail heuristic's statistics) and clears the counters and pool heads of
+  // `zero_rounds` rounds for the next batch - instead of two fill commands and a copy command behind every batch
+  uint32_t *live_out;
+  uint32_t zero_rounds;
+  uint32_t carry_blocks; // logic launch: this many trailing blocks do k_wf_carry's work instead (one launch less per round)
   uint32_t wide;        // bit k: kernel class k (WF_K_PRIMARY / WF_K_TRACE / WF_K_TAIL) walks the two-level nodes (scene.quads; same results)
   uint32_t primary_r;   // k_wf_primary: 1 = one traversal per lane, 2 = per-lane refill over 2 x 64 samples per wave (same results)
   uint32_t W, H;

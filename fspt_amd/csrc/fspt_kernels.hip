@@ -1097,15 +1097,21 @@ FM_DEV void carry_path(const WfSet &in, const WfSet &o, uint32_t i, uint32_t k) 
 // logic launch writes (same counter), marked - the next trace launch resumes the record instead of starting the path's
 // rays afresh - one round of lag counted, and the record learns the new index.  A kernel of its own, launched in front of
 // k_wf_logic: inside the logic kernel the few lines cost the shading loop registers (9 spilled, profiles/r03).
-__global__ __launch_bounds__(BLOCK_THREADS) void k_wf_carry(const WfP p) {
+// (Round 5: the same work is also done by WfP::carry_blocks trailing blocks of the logic LAUNCH - a branch at the top of
+// k_wf_logic that returns before the shading code, so its registers are not the shading loop's - which saves a launch
+// and its gap per round; the stand-alone kernel remains for hosts that ask for it.)
+FM_DEV void carry_records(const WfP &p, uint32_t first, uint32_t stride) {
   const uint32_t n = p.counts[p.cnt_in].n_susp;
   int *rec = p.susp[p.cnt_in & 1u];
-  for (uint32_t r = blockIdx.x * BLOCK_THREADS + threadIdx.x; r < n; r += gridDim.x * BLOCK_THREADS) {
+  for (uint32_t r = first; r < n; r += stride) {
     int *q = rec + (size_t)r * p.susp_stride;
     const uint32_t k_new = atomicAdd(&p.counts[p.cnt_out].n_ext, 1u);
     carry_path(p.set[p.set_in], p.set[p.set_out], (uint32_t)q[0], k_new);
     q[0] = (int)k_new;
   }
+}
+__global__ __launch_bounds__(BLOCK_THREADS) void k_wf_carry(const WfP p) {
+  carry_records(p, blockIdx.x * BLOCK_THREADS + threadIdx.x, gridDim.x * BLOCK_THREADS);
 }
 
 // ---- trace: intersectScene for the rays of one round; persistent waves, per-lane refill -------
@@ -1710,6 +1716,12 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
   extern __shared__ int lds_dyn[]; // the staged tables
   __shared__ uint16_t s_list[U * WF_LOGIC_THREADS];
   __shared__ uint32_t s_n, s_total, s_gbase;
+  // the launch's last carry_blocks blocks move the suspended traversals' paths on (k_wf_carry's work) and are done
+  const uint32_t n_blocks = gridDim.x - p.carry_blocks;
+  if (blockIdx.x >= n_blocks) {
+    carry_records(p, (blockIdx.x - n_blocks) * WF_LOGIC_THREADS + threadIdx.x, p.carry_blocks * WF_LOGIC_THREADS);
+    return;
+  }
   const int lane = threadIdx.x & (WAVE - 1);
   DScene S = p.scene;
   const float *s_rb = p.rb_trace;
@@ -1727,10 +1739,10 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
   Counters cnt = {0, 0, 0, 0, 0, 0};
 
   // paths per thread and iteration: as many as keep every block busy, at most U
-  uint32_t u_eff = (n_in + gridDim.x * WF_LOGIC_THREADS - 1) / (gridDim.x * WF_LOGIC_THREADS);
+  uint32_t u_eff = (n_in + n_blocks * WF_LOGIC_THREADS - 1) / (n_blocks * WF_LOGIC_THREADS);
   u_eff = u_eff < 1u ? 1u : (u_eff > (uint32_t)U ? (uint32_t)U : u_eff);
   const uint32_t span = u_eff * WF_LOGIC_THREADS;
-  for (uint32_t base = blockIdx.x * span; base < n_in; base += gridDim.x * span) {
+  for (uint32_t base = blockIdx.x * span; base < n_in; base += n_blocks * span) {
     // ---- 1: classify ----
     uint32_t own_fin = 0; // bit u: own path u finishes in this round (handled in 2a)
     for (uint32_t u = 0; u < u_eff; ++u) {
@@ -2008,6 +2020,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
   if (p.ctl) {
     u0 = p.res_from < 0 ? 0u : p.ctl->hist[p.res_from % WF_HIST];
     u1 = p.res_to == -2 ? (p.work_total >> 6) : (p.res_to < 0 ? 0u : p.ctl->hist[p.res_to % WF_HIST]);
+  }
+  if (p.zero_rounds && blockIdx.x == 0) {
+    // nobody reads this batch's counters or pool heads any more (every trace / logic / tail launch is done): hand the
+    // live-path counts to the host and clear both for the next batch
+    for (uint32_t r = threadIdx.x; r < p.zero_rounds; r += BLOCK_THREADS) {
+      if (p.live_out) p.live_out[r] = p.counts[r].n_ext;
+      p.counts[r].n_ext = 0u;
+      p.counts[r].n_susp = 0u;
+    }
+    for (uint32_t i = threadIdx.x; i < p.zero_rounds * WF_HEADS; i += BLOCK_THREADS) p.heads[(size_t)i * WF_HEAD_STRIDE] = 0u;
   }
   for (uint32_t ub = u0 + blockIdx.x * WAVES_PER_BLOCK; ub < u1; ub += gridDim.x * WAVES_PER_BLOCK) { // block-uniform trip count
     const uint32_t unit = ub + (uint32_t)wave;
@@ -2335,6 +2357,7 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
     const uint32_t prim_r = p.primary_r >= 2u ? 2u : 1u;
     const uint32_t per_block = kernel == WF_K_PRIMARY ? threads * prim_r : threads;
     uint32_t grid = min((total + per_block - 1) / per_block, (uint32_t)num_cus * blocks_per_cu);
+    if (kernel == WF_K_LOGIC) grid += p.carry_blocks; // (trailing blocks: k_wf_logic)
     const uint32_t tab_bytes = wf_table_bytes(p.scene.n_tex_sets, p.scene.n_bins, p.n_batch);
     const bool tab = WF_LOGIC_LDSTAB && tab_bytes <= WF_LDS_TABLE_MAX;
     if (kernel == WF_K_PRIMARY) {

@@ -5,7 +5,7 @@ common="$1"; shift
 for rep in 1 2; do
 for v in "$@"; do
 echo -n "== [$v] (rep $rep): "
-timeout 900 python3 bench.py $common $v --no-cpu-baseline --no-l1-microbench 2>/dev/null | python3 -c "
+timeout 900 python3 bench.py $common $v --no-cpu-baseline --no-extra-configs --no-l1-microbench 2>/dev/null | python3 -c "
 import sys,json
 for line in sys.stdin:
     if line.startswith('{'):

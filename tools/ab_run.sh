@@ -4,7 +4,7 @@ args="$1"; shift
 for rep in 1 2; do
 for n in "$@"; do
 echo -n "== $n (rep $rep): "
-FSPT_LIB=$PWD/ab_libs/$n.so timeout 600 python3 bench.py $args --no-cpu-baseline --no-l1-microbench 2>/dev/null | python3 -c "
+FSPT_LIB=$PWD/ab_libs/$n.so timeout 600 python3 bench.py $args --no-cpu-baseline --no-extra-configs --no-l1-microbench 2>/dev/null | python3 -c "
 import sys,json
 for line in sys.stdin:
     if line.startswith('{'):

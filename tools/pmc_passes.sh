@@ -16,7 +16,7 @@ for set in \
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
  "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > $O/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra-configs "$@" > $O/p$i.log 2>&1
 done
 python3 - "$O" <<'PY'
 import csv,glob,sys,collections,re

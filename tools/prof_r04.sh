@@ -18,7 +18,7 @@ L1ARG=${L1:+--l1-peak $L1}
 [ -z "$L1" ] && L1ARG=--no-l1-microbench
 echo "l1_peak: $L1" > $O/${T}_l1_peak.txt
 set -- $L1ARG "$@"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -- python3 $R/bench.py --no-cpu-baseline ${KT_ARGS:---steps 20 --warmup 5} "$@" > $O/${T}_kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_kt -- python3 $R/bench.py --no-cpu-baseline --no-extra-configs ${KT_ARGS:---steps 20 --warmup 5} "$@" > $O/${T}_kt.log 2>&1
 find $O/${T}_kt -name "*kernel_trace.csv" -size +8M -delete
 # the counter passes run the primary launch in the form this (lightly profiled) run settled on: under --pmc the kernels'
 # timings are distorted and the library's form tuner would measure the profiler, not the kernels
@@ -31,10 +31,10 @@ echo "primary form for the counter passes: ${PF:-tuner}" >> $O/${T}_l1_peak.txt
 # region, whose first batch has no live-path statistics yet, and four timed ones; the counters sum all five)
 TA=${TRAFFIC_ARGS:---steps 20 --warmup 20 --reps 4}
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/${T}_$c -- python3 $R/bench.py --no-cpu-baseline --no-parity-check $TA "$@" > $O/${T}_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/${T}_$c -- python3 $R/bench.py --no-cpu-baseline --no-extra-configs --no-parity-check $TA "$@" > $O/${T}_$c.log 2>&1
 done
 # request sizes behind FETCH_SIZE (profiles/r03/fetch_calib.json: every read request is a 128-byte line)
-timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/${T}_rdreq -- python3 $R/bench.py --no-cpu-baseline --no-parity-check $TA "$@" > $O/${T}_rdreq.log 2>&1
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/${T}_rdreq -- python3 $R/bench.py --no-cpu-baseline --no-extra-configs --no-parity-check $TA "$@" > $O/${T}_rdreq.log 2>&1
 i=0
 for set in \
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU" \
@@ -43,6 +43,6 @@ for set in \
  "TCP_PERF_SEL_TOTAL_HIT_LRU_READ TCP_PERF_SEL_TOTAL_MISS_LRU_READ TCP_PERF_SEL_TOTAL_MISS_EVICT_READ" \
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --output-format csv -d $O/${T}_sq$i -- python3 $R/bench.py ${SQ_ARGS:---steps 20 --warmup 0 --reps 1} --no-cpu-baseline --no-parity-check "$@" > $O/${T}_sq$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d $O/${T}_sq$i -- python3 $R/bench.py ${SQ_ARGS:---steps 20 --warmup 0 --reps 1} --no-cpu-baseline --no-extra-configs --no-parity-check "$@" > $O/${T}_sq$i.log 2>&1
 done
 echo prof done
