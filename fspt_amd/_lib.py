@@ -136,6 +136,11 @@ SIGNATURES = {
     "fspt_multi_last_gather_bytes": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "fspt_multi_size": (C.c_int, [_VP, _U32, _U32]),
     "fspt_multi_peer_access": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_int)]),
+    "fspt_multi_set_exchange": (C.c_int, [_VP, C.c_int]),
+    "fspt_multi_get_exchange": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fspt_target_shard_slots": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "fspt_target_pack_tiles": (C.c_int, [_VP, _VP, C.c_uint32]),
+    "fspt_target_unpack_tiles": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32]),
     "fspt_builder_create": (C.c_int, [C.POINTER(_VP)]),
     "fspt_builder_destroy": (C.c_int, [_VP]),
     "fspt_builder_add_obj": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(PropDesc)]),

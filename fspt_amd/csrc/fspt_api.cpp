@@ -5,22 +5,7 @@
 // (initBuffers 598-617), drawCamera (741-756), drawTracer (758-807), clear
 // (826-836) and the tick loop (838-857).  No CPU fallback: every device entry
 // point fails with FSPT_E_NO_DEVICE when there is no HIP device.
-#include "../../include/fspt.h"
-#include "../../include/fspt_tuning.h"
-#include "fspt_device.hpp"
-
-#include <cstdarg>
-#include <cstdio>
-#include <climits>
-#include <cstdint>
-#include <cstdlib>
-#include <cstring>
-#include <array>
-#include <atomic>
-#include <cmath>
-#include <map>
-#include <string>
-#include <vector>
+#include "fspt_internal.hpp"
 
 #ifndef FSPT_NODE_TREELET
 #define FSPT_NODE_TREELET 0 // nodes per treelet below the breadth-first top of the tree; 0 = pre-order (profiles/r02: A/B on the 1 M-triangle scene)
@@ -34,149 +19,6 @@ void fspt_set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-
-#define HIP_TRY(expr)                                                                             \
-  do {                                                                                            \
-    hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess) {                                                                       \
-      fspt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
-      return FSPT_E_HIP;                                                                          \
-    }                                                                                             \
-  } while (0)
-
-struct fspt_scene {
-  int device = 0;
-  int num_cus = 256;
-  fspt::DScene d{};
-  void *nodes = nullptr, *quads = nullptr /* two-level nodes, or NULL */, *tris = nullptr /* leaf records */, *slot_tri = nullptr, *shade = nullptr, *atlas = nullptr, *atlas4 = nullptr, *tex_sets = nullptr, *env = nullptr, *bins = nullptr;
-  uint32_t depth = 0, n_nodes = 0, n_tris = 0, n_interior = 0;
-  bool has_dielectric = false; // some triangle can refract (tracer.fs:481-488: unbounded path length)
-};
-
-static const int WF_ARRAYS = 15;
-#ifndef FSPT_SUSP_BUDGET
-#define FSPT_SUSP_BUDGET 24 // profiles/r03/ab_trace_suspend_budget.log: 0 / 16 / 24 / 32 / 48 -> 3 883 / 3 938 / 3 940 / 3 935 / 3 921 Msamples/s in 20-step regions (same box, twice)
-#endif
-static const uint32_t ST_DEFAULT_SUSP_BUDGET = FSPT_SUSP_BUDGET;
-// Library's choice of the node form (fspt_target::node_form = -1), per kernel class.  Measured (profiles/r05/ab_two_level_*.log,
-// one box, interleaved): the two-level nodes LOSE in every regime they were built for - tail kernel 0.037 -> 0.040-0.045 ms
-// per tick (C2, 20 ticks), 0.82 -> 0.80-0.92 (single tick), 0.125 -> 0.145 (1 M triangles); trace launches 0.170 -> 0.21 /
-// 0.215 -> 0.26; primary 0.127 -> 0.138 / 0.176 -> 0.193.  Halving the dependent round trips buys nothing because a step's
-// time is not a cache-miss latency: it is the CU's vector-memory front end working through the lane-requests of all its
-// resident waves (16 waves x 4 instructions x (4.6 + 0.63 x active lanes) cycles = the 1 900 clocks per step round-4
-// measured in the tail kernel), and a two-level fetch issues 8 requests where the walk needs 4 or 8.  So: everything off.
-#ifndef FSPT_WIDE_PRIMARY
-#define FSPT_WIDE_PRIMARY 0
-#endif
-#ifndef FSPT_WIDE_TAIL
-#define FSPT_WIDE_TAIL 0
-#endif
-#ifndef FSPT_CARRY_BLOCKS
-#define FSPT_CARRY_BLOCKS 4u // trailing blocks of a logic launch that do k_wf_carry's work (0: a separate launch per round, as in rounds 3-4)
-#endif
-#ifndef FSPT_RESOLVE_CLEARS
-#define FSPT_RESOLVE_CLEARS 1 // the batch's resolve launch hands the live-path counts to the host and clears counters + pool heads (0: fill / copy commands)
-#endif
-#ifndef FSPT_WIDE_TRACE_BELOW
-#define FSPT_WIDE_TRACE_BELOW 0u // paths
-#endif
-struct fspt_target {
-  fspt_scene *scene = nullptr;
-  uint32_t W = 0, H = 0;
-  float4 *accum_own = nullptr;
-  float4 *accum = nullptr;
-  float4 *ray_pos = nullptr, *ray_dir = nullptr;
-  bool rays_valid = false;
-  uint32_t *work_counters = nullptr; // ring of zeroed work counters, one per launch
-  uint32_t n_work_counters = 0;
-  unsigned long long *counters = nullptr; // 6 x u64 on device
-  int count = 0; // fspt_enable_counters: 0 off, 1 the reference's work, 2 the production kernels' work
-  uint32_t shard = 0, n_shards = 1, tile = 32;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timed = false;
-  uint32_t last_launches = 0;
-  // wavefront pipeline
-  uint32_t vw = 0, vh = 0;    // viewport (gl.viewport of the two draws); default = the whole target
-  int pipeline = 1;           // 0 = megakernel, 1 = wavefront
-  int sched = 0;              // wavefront pipeline: 0 = batch scheduler (all ticks x all pixels per batch), 1 = stream (fixed pool)
-  uint32_t pool_paths = 0;    // stream: paths per state set and lane (0 = default)
-  int stream_drain = -1;      // stream: iterations after the last generating one before the tail kernel takes over (-1 = default)
-  uint32_t stream_iter_cap = 0; // stream, test hook: at most this many iterations per run (the finishing launch does the rest)
-  uint32_t susp_budget = ST_DEFAULT_SUSP_BUDGET; // traversal steps a starved trace wave walks on before it parks its rays (0 = never)
-  int stream_overlap = -1;      // stream: plan / primary / resolve on a second HIP stream beside the previous trace (1), everything on one stream (0), default (-1)
-  uint32_t batch_ticks = 128; // ticks traced together by the wavefront pipeline (58 GB of path state at 1080p;
-                              // measured 64 / 128 / 256 -> 3 619 / 3 794 / 3 750 Msamples/s, profiles/r01)
-  // Path state and streams of the wavefront pipeline (either scheduler).  (Two such lanes with overlapped half-batches
-  // were measured in rounds 1-3 and gained nothing worth their memory: profiles/r02, profiles/r03/ab_staggered_lanes.log.)
-  struct WfLane {
-    void *mem[WF_ARRAYS] = {};
-    fspt::WfCounts *counts = nullptr;
-    uint32_t *heads = nullptr;             // trace pool heads (fspt_device.hpp)
-    fspt::WfCounts *counts_host = nullptr; // pinned copy of the last batch's per-round counts (tail heuristic)
-    uint32_t *live_host = nullptr, *live_dev = nullptr; // ... or (counts_live) the live paths per round as the resolve launch wrote them: pinned host memory and its device address
-    bool counts_live = false;
-    hipEvent_t counts_ready = nullptr;
-    bool counts_pending = false;
-    uint32_t counts_slots = 0;             // slots of the batch the copy describes
-    uint32_t slots = 0;        // allocated path slots (batch scheduler)
-    hipStream_t stream = nullptr;
-    hipEvent_t resolved = nullptr; // this lane's most recent resolve has finished
-    // stream scheduler (fspt_device.hpp: WfStreamCtl): a pool of st_cap paths per state set + a ring of st_fin finished colours
-    uint32_t st_cap = 0, st_fin = 0;
-    hipStream_t stream_b = nullptr;          // plan / primary / resolve run here, beside the previous iteration's trace
-    hipEvent_t ev_logic[fspt::WF_RING] = {}, ev_b[fspt::WF_RING] = {}, ev_run = nullptr, ev_b_last = nullptr;
-    fspt::WfStreamCtl *ctl = nullptr;
-    fspt::WfStreamCtl *ctl_host = nullptr;   // pinned copy of the last run's statistics (never waited for)
-    hipEvent_t ctl_ready = nullptr;
-    bool ctl_pending = false;
-    uint64_t ctl_key = 0, stat_key = 0;      // what the pending copy / the known statistics describe (units, ticks, pool, bounces)
-    uint32_t ctl_units = 0;                  // units of the run the pending copy describes
-    uint32_t stat_gen_iters = 0;             // iterations the last such run needed to hand out all its units
-    uint64_t bytes = 0;                      // path-state bytes this lane holds (either scheduler)
-    int *susp[2] = {nullptr, nullptr};       // suspended-traversal records of the trace launches (fspt_device.hpp), ping-pong
-    uint32_t susp_stride = 0;
-    size_t susp_recs = 0;                    // records per buffer
-    uint64_t susp_bytes = 0;                 // both buffers
-    bool zeroed = false;                     // counts / heads / ctl are zero (cleared behind the previous batch, off the next one's critical path)
-  } wf;
-  // Deferred two-call ticks (fspt_camera + fspt_trace): recorded, executed in batches at the next flush point
-  struct Deferred { fspt_camera_params cam; float rb_cam; uint32_t tick; float rb_trace; };
-  std::vector<Deferred> pending;
-  fspt_camera_params last_cam{}; // the most recent fspt_camera call (num_bounces / env_theta filled in by fspt_trace)
-  float last_rb_cam = 0.0f;
-  bool cam_recorded = false;     // last_cam is valid and newer than the ray buffers' contents
-  bool rays_injected = false;    // the ray buffers hold caller-supplied rays (fspt_set_rays): trace them as they are
-  bool defer = true;             // fspt_target_set_deferred
-  // Primary-form tuner (batch scheduler): k_wf_primary has two forms of its traversal phase with identical results
-  // (fspt_kernels.hip).  Which is faster depends on the scene and the batch size, so the target measures: HIP events
-  // around the primary launch of a batch, read back without waiting at the start of a later batch.  Per batch size: the
-  // first batch runs the form the scene's size suggests (X), the second the other one (Y), and as a rule that settles it
-  // - see prim_choose for the one case that takes a third batch.
-  int primary_form = 0;      // fspt_target_set_primary_form: 0 measure and choose, 1 / 2 forced
-  // batch ticks -> [form] {best ms per sample so far (< 0: none), measurements taken}
-  struct PrimStat { double best[3] = {-1.0, -1.0, -1.0}; uint32_t runs[3] = {0, 0, 0}; };
-  std::map<uint32_t, PrimStat> prim_ms;
-  hipEvent_t prim_ev[2] = {nullptr, nullptr};
-  bool prim_pending = false;
-  uint32_t prim_pending_form = 0, prim_pending_ticks = 0;
-  double prim_pending_samples = 0.0;
-  // Node form per kernel class (fspt_target_set_node_form): -1 the library's choice, 0 the 64-byte nodes, 1 the two-level
-  // nodes (fspt_device.hpp "quad"; only where the scene has them).  [0] primary launch, [1] trace launches, [2] tail kernel.
-  int node_form[3] = {-1, -1, -1};
-  uint32_t wide_trace_below = FSPT_WIDE_TRACE_BELOW; // library's choice for a trace launch: two-level nodes when it expects fewer paths than this
-  int tail_round = -1;       // fspt_target_set_tail: -1 adaptive, 0 never, r >= 1 after round r
-  float live_frac[80] = {};  // live paths after round r / slots of the batch, from the most recent finished batch
-  bool live_known = false;
-  uint32_t ticks_seen = 0;   // largest n_ticks of any call so far: path state is sized for min(batch_ticks, ticks_seen)
-  uint64_t mem_limit = 0;    // fspt_target_set_memory_limit: cap on the path-state bytes of this target (0 = none)
-  hipEvent_t ev_start = nullptr;
-  // per-launch stage timing (HIP events on the target's stream)
-  std::vector<hipEvent_t> ev_pool;
-  std::vector<int> ev_kind;   // kernel class of pair i
-  uint32_t ev_used = 0;       // pairs used by the last render
-  bool ev_overflow = false;
-};
 
 // RGBA8 image (row-major, w x h) -> 8 x 4-texel tiles (fspt_device.hpp: TEX_TILE_*), padded to whole tiles.
 // Returns the number of texels of the tiled image; with src == nullptr only that.
@@ -199,12 +41,8 @@ static size_t tile_image(const uint8_t *src, uint32_t w, uint32_t h, std::vector
   return n;
 }
 
-static int flush_pending(fspt_target *t);
-static void prim_reset(fspt_target *t);
-static int materialise_rays(fspt_target *t);
-#define FLUSH_OR_RETURN(t) do { int rc_f = flush_pending(t); if (rc_f) return rc_f; } while (0)
 
-static int check_device(int device) {
+int check_device(int device) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -661,13 +499,6 @@ int fspt_scene_depth(const fspt_scene *s, uint32_t *depth) {
 // ---------------------------------------------------------------------------
 // target
 // ---------------------------------------------------------------------------
-static const uint32_t WORK_RING = 4096;
-static const uint32_t WF_ROUNDS_MAX = fspt::MAX_PATH_ITERS + 4;
-static const uint32_t EV_PAIRS = 4096;
-static const size_t WF_HEADS_BYTES = (size_t)(WF_ROUNDS_MAX + 2) * fspt::WF_HEADS * fspt::WF_HEAD_STRIDE * sizeof(uint32_t);
-static const uint64_t WF_SLOT_BUDGET = 448ull << 20; // path slots, 216 B each (up to 101 GB of the 288 GB HBM: a 4K frame x 56 ticks)
-static_assert(WF_SLOT_BUDGET < (1ull << 29), "k_wf_trace keeps a path's state index in 29 bits");
-
 int fspt_target_create(fspt_scene *scene, uint32_t W, uint32_t H, fspt_target **out) {
   if (!scene || !out || W == 0 || H == 0) { fspt_set_error("fspt_target_create: bad argument"); return FSPT_E_INVALID; }
   if ((uint64_t)W * H > (1ull << 30)) { fspt_set_error("fspt_target_create: %ux%u too large", W, H); return FSPT_E_INVALID; }
@@ -822,693 +653,12 @@ int fspt_read_rays(fspt_target *t, float *pos, float *dir) {
   return FSPT_OK;
 }
 
-static void fill_trace_params(fspt_target *t, fspt::TraceP &p) {
-  p.scene = t->scene->d;
-  p.W = t->W; p.H = t->H;
-  p.vw = t->vw; p.vh = t->vh;
-  p.ray_pos = t->ray_pos; p.ray_dir = t->ray_dir;
-  p.accum = t->accum;
-  p.counters = t->count ? t->counters : nullptr;
-  p.shard = t->shard; p.n_shards = t->n_shards; p.tile = t->tile;
-  p.tiles_x = (t->W + t->tile - 1) / t->tile;
-  p.tiles_y = (t->H + t->tile - 1) / t->tile;
-  uint32_t n_tiles = p.tiles_x * p.tiles_y;
-  p.n_owned_tiles = (n_tiles > t->shard) ? (n_tiles - t->shard + t->n_shards - 1) / t->n_shards : 0;
-}
-
-// Records of suspended traversals: one per lane of the trace grid a launch over `max_paths` paths gets (a lane parks at
-// most one ray per launch; launch_wf: min(ceil(paths / 256), 8 blocks per CU) blocks of 256), two buffers, grown on
-// demand.  They are part of the target's path state (fspt_target_path_state_bytes, fspt_target_set_memory_limit): when
-// they do not fit what the limit leaves, traversals are simply not suspended (*on = false) - same results, a little slower.
-static uint64_t susp_need(const fspt_target *t, uint64_t max_paths, uint32_t *stride_out, size_t *recs_out) {
-  const uint32_t stride = ((uint32_t)fspt::WF_SUSP_HEADER + t->scene->d.stack_n + 3u) & ~3u;
-  const uint64_t grid_max = (uint64_t)t->scene->num_cus * 8u;
-  uint64_t blocks = (max_paths + 255u) / 256u;
-  if (blocks > grid_max) blocks = grid_max;
-  if (blocks < 1) blocks = 1;
-  const size_t recs = (size_t)blocks * 256u;
-  if (stride_out) *stride_out = stride;
-  if (recs_out) *recs_out = recs;
-  return 2ull * recs * stride * sizeof(int);
-}
-static int susp_ensure(fspt_target *t, fspt_target::WfLane &ln, uint64_t max_paths, bool *on) {
-  uint32_t stride; size_t recs;
-  const uint64_t need = susp_need(t, max_paths, &stride, &recs);
-  *on = true;
-  if (ln.susp[0] && ln.susp_stride == stride && ln.susp_recs >= recs) {
-    // the path state may have grown since the records were made: the limit covers both
-    if (!t->mem_limit || ln.bytes + ln.susp_bytes <= t->mem_limit) return FSPT_OK;
-  }
-  for (int *&b : ln.susp) { if (b) { HIP_TRY(hipFree(b)); b = nullptr; } }
-  ln.susp_bytes = 0; ln.susp_recs = 0;
-  if (t->mem_limit && ln.bytes + need > t->mem_limit) { *on = false; return FSPT_OK; }
-  for (int *&b : ln.susp) {
-    hipError_t e = hipMalloc((void **)&b, recs * stride * sizeof(int));
-    if (e == hipErrorOutOfMemory) {
-      (void)hipGetLastError();
-      for (int *&c : ln.susp) { if (c) { (void)hipFree(c); c = nullptr; } }
-      *on = false;
-      return FSPT_OK;
-    }
-    HIP_TRY(e);
-  }
-  ln.susp_stride = stride;
-  ln.susp_recs = recs;
-  ln.susp_bytes = need;
-  return FSPT_OK;
-}
-
-// bytes per path slot of every path-state array (fspt_device.hpp: WfP)
-// two state sets of A B C E D P (float4) | hit (float2) | shadow_hit (int) | fin (3 floats)   = 216 bytes per slot
-static const size_t WF_ARRAY_BYTES[WF_ARRAYS] = {16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 8, 4, 12};
-static size_t wf_slot_bytes() {
-  size_t b = 0;
-  for (size_t x : WF_ARRAY_BYTES) b += x;
-  return b;
-}
-
-static void wf_release(fspt_target::WfLane &ln) {
-  if (ln.stream) hipStreamSynchronize(ln.stream);
-  if (ln.stream_b) hipStreamSynchronize(ln.stream_b);
-  for (void *&m : ln.mem) { if (m) { hipFree(m); m = nullptr; } }
-  ln.slots = 0;
-  ln.st_cap = ln.st_fin = 0;
-  ln.bytes = 0;
-  ln.zeroed = false;
-}
-
-// Path state of one lane for `slots` path slots.  `budget_slots` = what fspt_target_set_memory_limit leaves this lane;
-// exceeding it is reported exactly like the device running out of memory (FSPT_E_NOMEM: the caller shrinks the batch).
-static int wf_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t slots, uint64_t budget_slots) {
-  (void)t;
-  if (ln.slots >= slots && ln.counts && !ln.st_cap) return FSPT_OK;
-  wf_release(ln);
-  for (int i = 0; i < WF_ARRAYS; ++i) {
-    hipError_t e = slots > budget_slots ? hipErrorOutOfMemory : hipMalloc(&ln.mem[i], (size_t)slots * WF_ARRAY_BYTES[i]);
-    if (e == hipErrorOutOfMemory) {
-      // not enough free HBM (or over the target's memory limit) for this batch size: give everything back
-      (void)hipGetLastError();
-      wf_release(ln);
-      fspt_set_error("path state for %u slots (%zu bytes) does not fit %s", slots, (size_t)slots * wf_slot_bytes(),
-                     slots > budget_slots ? "the target's memory limit" : "the free device memory");
-      return FSPT_E_NOMEM;
-    }
-    HIP_TRY(e);
-    HIP_TRY(hipMemsetAsync(ln.mem[i], 0, (size_t)slots * WF_ARRAY_BYTES[i], ln.stream)); // touch every page once, now
-  }
-  if (!ln.counts) HIP_TRY(hipMalloc((void **)&ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2)));
-  if (!ln.heads) HIP_TRY(hipMalloc((void **)&ln.heads, WF_HEADS_BYTES));
-  if (!ln.counts_host) HIP_TRY(hipHostMalloc((void **)&ln.counts_host, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), hipHostMallocDefault));
-  if (!ln.live_host) {
-    HIP_TRY(hipHostMalloc((void **)&ln.live_host, sizeof(uint32_t) * (WF_ROUNDS_MAX + 2), hipHostMallocMapped));
-    std::memset(ln.live_host, 0, sizeof(uint32_t) * (WF_ROUNDS_MAX + 2));
-    if (hipHostGetDevicePointer((void **)&ln.live_dev, ln.live_host, 0) != hipSuccess) { (void)hipGetLastError(); ln.live_dev = nullptr; } // (falls back to the copy command)
-  }
-  if (!ln.counts_ready) HIP_TRY(hipEventCreateWithFlags(&ln.counts_ready, hipEventDisableTiming));
-  HIP_TRY(hipStreamSynchronize(ln.stream));
-  ln.slots = slots;
-  ln.bytes = (uint64_t)slots * wf_slot_bytes();
-  return FSPT_OK;
-}
-
-// Ticks per batch for a call of n_ticks (0 = the configured steady state, fspt_target_prepare).
-// Path state is sized for the largest call seen so far, not for the configured batch: a host that only ever calls
-// fspt_trace (one tick at a time, like main.js:842-843) holds one tick of path state, not 128.
-static uint32_t wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ticks) {
-  uint32_t batch = t->batch_ticks;
-  if (n_ticks) {
-    uint32_t want = n_ticks > t->ticks_seen ? n_ticks : t->ticks_seen;
-    if (batch > want) batch = want;
-  }
-  uint64_t fit = WF_SLOT_BUDGET / work_total;
-  if (fit < 1) fit = 1;
-  if (batch > fit) batch = (uint32_t)fit;
-  if (batch < 1) batch = 1;
-  if (batch > (uint32_t)fspt::WF_MAX_BATCH) batch = fspt::WF_MAX_BATCH;
-  return batch;
-}
-
-// Plan the batch and make sure its path state is allocated.  When the device is short of memory (or the target's
-// memory limit is lower) the batch is halved until it fits (results do not depend on the batch size).
-static int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &batch) {
-  if (n_ticks > t->ticks_seen) t->ticks_seen = n_ticks;
-  while (true) {
-    batch = wf_plan(t, work_total, n_ticks);
-    // the trace kernel carries a path's state index in 29 bits (fspt_kernels.hip k_wf_trace: item kind and the
-    // no-bounce-left flag share the word); WF_SLOT_BUDGET keeps every batch below that, a single tick of a frame beyond
-    // 2^29 pixels does not fit
-    if ((uint64_t)batch * work_total > 0x1FFFFFFFull) { fspt_set_error("frame too large for the wavefront pipeline (more than 2^29 paths per batch)"); return FSPT_E_INVALID; }
-    // the limit covers the suspension records too (susp_ensure): the slots get what the records this batch needs leave,
-    // unless the records alone would take more than a quarter of the limit - then traversals are simply not suspended
-    uint64_t budget = ~0ull;
-    if (t->mem_limit) {
-      uint64_t lim = t->mem_limit;
-      const uint64_t rec = (t->susp_budget != 0 && t->count == 0) ? susp_need(t, (uint64_t)batch * work_total, nullptr, nullptr) : 0;
-      if (rec <= lim / 4) lim -= rec;
-      budget = lim / wf_slot_bytes();
-    }
-    int rc = wf_ensure(t, t->wf, (uint32_t)(batch * work_total), budget);
-    if (rc != FSPT_E_NOMEM) return rc;
-    if (batch <= 1) return rc; // one tick does not fit: give up (message set by wf_ensure)
-    t->batch_ticks = batch / 2;
-  }
-}
-
-// Primary-form tuner (fspt_target::prim_ms): fold a finished measurement in (wait = block until it has finished) ...
-static void prim_collect(fspt_target *t, bool wait) {
-  if (!t->prim_pending) return;
-  if (wait) { if (hipEventSynchronize(t->prim_ev[1]) != hipSuccess) return; }
-  else if (hipEventQuery(t->prim_ev[1]) != hipSuccess) return;
-  float ms = 0.0f;
-  if (hipEventElapsedTime(&ms, t->prim_ev[0], t->prim_ev[1]) == hipSuccess && t->prim_pending_samples > 0.0) {
-    fspt_target::PrimStat &st = t->prim_ms[t->prim_pending_ticks];
-    const double v = (double)ms / t->prim_pending_samples;
-    const uint32_t f = t->prim_pending_form;
-    if (st.best[f] < 0.0 || v < st.best[f]) st.best[f] = v;
-    st.runs[f]++;
-  }
-  t->prim_pending = false;
-}
-// the measurements describe one launch geometry (shard, viewport, node form, pipeline): a setter that changes it forgets them
-static void prim_reset(fspt_target *t) {
-  t->prim_pending = false; // (an event pair in flight is simply never read)
-  t->prim_ms.clear();
-}
-// ... and the form for the next batch of `ticks` ticks.  X = the form the scene's size suggests (per-lane refill pays
-// where ray lengths scatter: sub-pixel triangles), Y the other one.  Batch 1 of a size runs X - cold: a size's first batch
-// is 4-8 % slower (first use of that much path state, clocks, caches) - batch 2 runs Y.  If X won although it ran cold,
-// or lost by more than a cold start explains (25 %: the first 128-tick batch - 57 GB of path state used for the first
-// time - has been seen 23 % slow), the matter is settled after those two batches; otherwise X gets a
-// warm run (batch 3) and the better best-run wins.  (Forms are measured on whole batches: timed on halves of a batch
-// the refill form - 512 samples per block iteration - looked 10-20 % worse than it is, profiles/r04/primary_form_tuner_split.log.)
-static uint32_t prim_choose(const fspt_target *t, uint32_t ticks) {
-  const uint32_t X = t->scene->n_tris >= (1u << 18) ? 2u : 1u, Y = 3u - X;
-  const auto it = t->prim_ms.find(ticks);
-  if (it == t->prim_ms.end()) return X;
-  const fspt_target::PrimStat &st = it->second;
-  if (st.runs[X] == 0) return X;
-  if (st.runs[Y] == 0) return Y;
-  if (st.runs[X] == 1) { // X has only its cold run
-    if (st.best[X] <= st.best[Y]) return X;
-    if (st.best[X] > 1.25 * st.best[Y]) return Y;
-    return X; // its warm run
-  }
-  return st.best[X] <= st.best[Y] ? X : Y;
-}
-
-static int ev_begin(fspt_target *t, int kind, hipStream_t stream) {
-  if (t->ev_used >= EV_PAIRS) { t->ev_overflow = true; return -1; }
-  if (t->ev_pool.size() < (size_t)(t->ev_used + 1) * 2) {
-    hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { t->ev_overflow = true; return -1; }
-    t->ev_pool.push_back(a); t->ev_pool.push_back(b);
-    t->ev_kind.push_back(kind);
-  }
-  int i = (int)t->ev_used++;
-  t->ev_kind[i] = kind;
-  hipEventRecord(t->ev_pool[2 * i], stream);
-  return i;
-}
-static void ev_end(fspt_target *t, int i, hipStream_t stream) { if (i >= 0) hipEventRecord(t->ev_pool[2 * i + 1], stream); }
-
-// Live-path statistics of the most recent finished batch (copied to pinned memory behind the batch, never waited for).
-static void wf_collect_counts(fspt_target *t, fspt_target::WfLane &ln) {
-  if (!ln.counts_pending || hipEventQuery(ln.counts_ready) != hipSuccess) return;
-  ln.counts_pending = false;
-  if (!ln.counts_slots) return;
-  for (uint32_t r = 0; r < WF_ROUNDS_MAX + 2 && r < 80; ++r)
-    t->live_frac[r] = (float)(ln.counts_live ? ln.live_host[r] : ln.counts_host[r].n_ext) / (float)ln.counts_slots;
-  t->live_known = true;
-}
-
-// The round after which the tail kernel takes over (> last: never).  Adaptive, from the previous batch's live-path
-// counts.  Two costs are compared per candidate round r (both grow with the rounds still to go, last - r):
-//   staying in the wavefront: every further round is a trace launch + a logic launch at their latency floors;
-//   the tail kernel: one chain of dependent extension rays per remaining round, times how often its resident lane
-//   pairs (4 blocks/CU x 4 waves x 32 pairs) have to be re-filled to get through the n_r live paths.
-// Hand over at the first r with  n_r <= 0.9 * (last - r) * resident pairs.  The constant is fitted to hand-over scans
-// on two scenes at 1920x1080 (profiles/r02/probe_tail_round_paired.log, probe_tail_round_c3.log): 70 k triangles:
-// 1 tick -> after round 2 (562 K paths, 7 rounds to go: 1.74 ms vs 1.93 after round 3), 20 ticks -> round 5, 128 ticks
-// -> never (all equal there); 1 M triangles, 20 ticks: round 6 (round 5, 386 K paths with 4 rounds to go, costs 3 %);
-// re-scanned with the tail kernel at 4 waves/SIMD: 0.62 / 0.9 / 1.25 / 1.6 (profiles/r02/ab_tail_handover_coefficient.log).
-#ifndef FSPT_TAIL_COEF
-#define FSPT_TAIL_COEF 0.9
-#endif
-static uint32_t wf_tail_round(const fspt_target *t, uint64_t slots, uint32_t last) {
-  if (t->tail_round == 0) return last + 1;
-  if (t->tail_round > 0) return (uint32_t)t->tail_round;
-  if (!t->live_known) return last + 1;
-  const double pairs = (double)t->scene->num_cus * 4.0 * 4.0 * 32.0;
-  for (uint32_t r = 1; r < last && r < 80; ++r)
-    if ((double)t->live_frac[r] * (double)slots <= FSPT_TAIL_COEF * (double)(last - r) * pairs) return r;
-  return last + 1;
-}
-
-// Which node form a launch of kernel class `kind` over (an expected) `paths` paths walks: WfP::wide's bit for it.
-static uint32_t wide_bit(const fspt_target *t, int kind, double paths) {
-  if (!t->scene->quads || t->count) return 0u;
-  const int slot = kind == fspt::WF_K_PRIMARY ? 0 : kind == fspt::WF_K_TRACE ? 1 : kind == fspt::WF_K_TAIL ? 2 : -1;
-  if (slot < 0) return 0u;
-  bool on;
-  if (t->node_form[slot] >= 0) on = t->node_form[slot] != 0;
-  else if (slot == 0) on = FSPT_WIDE_PRIMARY != 0;
-  else if (slot == 2) on = FSPT_WIDE_TAIL != 0;
-  else on = paths >= 0.0 && paths < (double)t->wide_trace_below;
-  return on ? 1u << kind : 0u;
-}
-
-// n_ticks ticks through the wavefront pipeline.  rays_from_buffers: two-call form (n_ticks == 1).
-static int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
-                            const float *rb_cam, const float *rb_trace, bool rays_from_buffers) {
-  fspt::TraceP tp{};
-  fill_trace_params(t, tp);
-  const uint32_t work_total = tp.n_owned_tiles * tp.tile * tp.tile;
-  if (work_total == 0) return FSPT_OK;
-  // path state: sized for the largest call so far (fspt_target_prepare sizes it for the configured batch up front, so
-  // that a short warm-up call does not cause a reallocation inside a later, longer call)
-  uint32_t batch;
-  int rc = wf_plan_and_ensure(t, work_total, n_ticks, batch);
-  if (rc) return rc;
-
-  fspt::WfP p{};
-  p.scene = t->scene->d;
-  p.W = t->W; p.H = t->H; p.vw = t->vw; p.vh = t->vh; p.work_total = work_total;
-  p.env_theta = cam->env_theta; p.num_bounces = cam->num_bounces;
-  std::memcpy(p.cam.P, cam->P, 12); std::memcpy(p.cam.I, cam->I, 12);
-  p.cam.fov_scale = cam->fov_scale; p.cam.lens[0] = cam->lens[0]; p.cam.lens[1] = cam->lens[1];
-  p.ray_pos = t->ray_pos; p.ray_dir = t->ray_dir;
-  p.accum = t->accum;
-  p.counters = t->count ? t->counters : nullptr;
-  p.shard = tp.shard; p.n_shards = tp.n_shards; p.tile = tp.tile; p.tiles_x = tp.tiles_x; p.tiles_y = tp.tiles_y;
-  p.n_owned_tiles = tp.n_owned_tiles;
-  const int cus = t->scene->num_cus;
-  const bool gen = !rays_from_buffers;
-  const uint32_t nb = cam->num_bounces;
-
-  // everything already queued on the target's stream (clear, ray upload, earlier renders) comes first
-  HIP_TRY(hipEventRecord(t->ev_start, t->stream));
-  fspt_target::WfLane &ln = t->wf;
-  hipStream_t st = ln.stream;
-  HIP_TRY(hipStreamWaitEvent(st, t->ev_start, 0));
-
-  uint32_t done = 0;
-  while (done < n_ticks) {
-    auto launch = [&](int kind) -> int {
-      int e = kind >= fspt::WF_K_KINDS ? -1 : ev_begin(t, kind, st);
-      hipError_t err = fspt::launch_wf(kind, p, t->count, cus, st);
-      ev_end(t, e, st);
-      if (err != hipSuccess) { fspt_set_error("wavefront launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
-      return FSPT_OK;
-    };
-    for (int k = 0; k < 2; ++k) {
-      fspt::WfSet &ws = p.set[k];
-      ws.A = (float4 *)ln.mem[6 * k + 0]; ws.B = (float4 *)ln.mem[6 * k + 1]; ws.C = (float4 *)ln.mem[6 * k + 2];
-      ws.E = (float4 *)ln.mem[6 * k + 3]; ws.D = (float4 *)ln.mem[6 * k + 4]; ws.P = (float4 *)ln.mem[6 * k + 5];
-    }
-    p.hit = (float2 *)ln.mem[12]; p.shadow_hit = (int *)ln.mem[13];
-    p.fin = (float *)ln.mem[14];
-    p.counts = ln.counts;
-    p.heads = ln.heads;
-    uint32_t nbt = n_ticks - done < batch ? n_ticks - done : batch;
-    p.n_batch = nbt;
-    p.first_tick = first_tick + done;
-    p.ctl = nullptr; p.ring_slots = nbt * work_total; p.finish = 0;
-    // suspended traversals: off while counting (the tail kernel re-traces a carried path's rays, which would count twice)
-    bool susp_on = t->susp_budget != 0 && t->count == 0;
-    if (susp_on && (rc = susp_ensure(t, ln, (uint64_t)nbt * work_total, &susp_on))) return rc;
-    p.susp[0] = susp_on ? ln.susp[0] : nullptr; p.susp[1] = susp_on ? ln.susp[1] : nullptr; p.susp_stride = ln.susp_stride; p.susp_budget = susp_on ? t->susp_budget : 0u;
-    for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
-    // the previous batch's live-path counts, if their copy has landed: where the tail kernel takes over
-    wf_collect_counts(t, ln);
-    if (!ln.zeroed) {
-      HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
-      HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, st));
-    }
-    ln.zeroed = false;
-    p.gen_rays = gen ? 1u : 0u;
-    // Round 1 = the primary launch (ray generation + primary traversal + its shading); round r >= 2: logic consumes the
-    // results of trace r-1 and shades bounce r-1.  After round nb+1 every path has finished unless a refraction kept `i`
-    // from advancing (tracer.fs:488).  After round `tail` the tail kernel runs whatever is still alive to completion.
-    const uint32_t last = nb + 1;
-    uint32_t tail = wf_tail_round(t, (uint64_t)nbt * work_total, last);
-    if ((t->scene->has_dielectric || susp_on) && tail > last) tail = last; // refraction / a suspended traversal: paths may outlive `last` rounds
-    auto set_round = [&](uint32_t r) { p.round = r; p.cnt_in = r - 1; p.cnt_out = r; p.set_in = (r - 1) & 1u; p.set_out = r & 1u; };
-    // the primary launch's form: forced, or measured (see fspt_target::prim_ms)
-    prim_collect(t, false);
-    uint32_t form = 1;
-    if (t->primary_form == 1 || t->primary_form == 2) form = (uint32_t)t->primary_form;
-    else if (t->count == 0) form = prim_choose(t, nbt); // (the counting variants are not what is timed: form 1 unless forced)
-    p.primary_r = form;
-    p.wide = wide_bit(t, fspt::WF_K_PRIMARY, -1.0) | wide_bit(t, fspt::WF_K_TAIL, -1.0);
-    const bool time_primary = t->count == 0 && !t->prim_pending;
-    bool prev_trace_suspends = false; // (no carry launch behind a trace launch that cannot have suspended anything)
-    for (uint32_t r = 1; r <= last && r <= tail; ++r) {
-      set_round(r);
-      // the paths trace(r-1) suspended move on: a few trailing blocks of the logic launch (FSPT_CARRY_BLOCKS 0: a launch of their own)
-      p.carry_blocks = 0u;
-      if (r > 1 && susp_on && prev_trace_suspends) {
-        if (FSPT_CARRY_BLOCKS) p.carry_blocks = FSPT_CARRY_BLOCKS;
-        else if ((rc = launch(fspt::WF_K_CARRY))) return rc;
-      }
-      if (r == 1 && time_primary) HIP_TRY(hipEventRecord(t->prim_ev[0], st));
-      if ((rc = launch(r == 1 ? fspt::WF_K_PRIMARY : fspt::WF_K_LOGIC))) return rc;
-      if (r == 1 && time_primary) {
-        HIP_TRY(hipEventRecord(t->prim_ev[1], st));
-        t->prim_pending = true; t->prim_pending_form = form; t->prim_pending_ticks = nbt;
-        t->prim_pending_samples = (double)nbt * (double)work_total;
-      }
-      if (r < last && r < tail) {
-        // (the last trace launch in front of the tail kernel parks its long rays like every other: the carry launch
-        // moves those paths on and the tail kernel - a bundle of dependent chains with lanes to spare - traces their rays
-        // again from the root.  Letting them finish in the trace launch, as rounds 3 and early 4 did, kept the chip
-        // waiting for a handful of rays: 1 M-triangle scene trace 0.249 -> 0.215 ms per tick, a single tick of C2 0.27 ->
-        // 0.18, profiles/r04/ab_last_trace_suspends.log)
-        // a trace launch expected to be small (the previous batch's live-path counts) is a bundle of dependent chains
-        p.wide = (p.wide & ~(1u << fspt::WF_K_TRACE)) |
-                 wide_bit(t, fspt::WF_K_TRACE, t->live_known && r < 80 ? (double)t->live_frac[r] * (double)nbt * (double)work_total : -1.0);
-        if ((rc = launch(fspt::WF_K_TRACE))) return rc;
-        prev_trace_suspends = p.susp_budget != 0;
-      }
-    }
-    if (tail <= last && (tail < last || t->scene->has_dielectric || susp_on)) {
-      set_round(tail);
-      if ((rc = launch(fspt::WF_K_TAIL))) return rc;
-    }
-    // The batch's live-path counts go to the host (the tail heuristic's statistics, never waited for) and the counters
-    // and pool heads are cleared for the next batch.  Rounds 1-4: a copy command in front of the resolve launch and two
-    // fill commands behind it (2.4 % + 1.2 % of a 20-tick batch's GPU time, profiles/r04/final_kernel_stats.csv); now
-    // block 0 of the resolve launch does all three (pinned host memory is written by the kernel itself).
-    const bool resolve_clears = FSPT_RESOLVE_CLEARS && ln.live_dev != nullptr;
-    p.live_out = resolve_clears ? ln.live_dev : nullptr;
-    p.zero_rounds = resolve_clears ? WF_ROUNDS_MAX + 2 : 0u;
-    if (!resolve_clears) HIP_TRY(hipMemcpyAsync(ln.counts_host, ln.counts, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), hipMemcpyDeviceToHost, st));
-    // the running mean is order-dependent (tracer.fs:517): batches resolve in tick order - they follow each other on `st`
-    if ((rc = launch(fspt::WF_K_RESOLVE))) return rc;
-    p.zero_rounds = 0u;
-    HIP_TRY(hipEventRecord(ln.counts_ready, st));
-    ln.counts_pending = true;
-    ln.counts_slots = nbt * work_total;
-    ln.counts_live = resolve_clears;
-    if (!resolve_clears) {
-      HIP_TRY(hipMemsetAsync(ln.counts, 0, sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2), st));
-      HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, st));
-    }
-    ln.zeroed = true;
-    done += nbt;
-  }
-  HIP_TRY(hipEventRecord(ln.resolved, st));
-  HIP_TRY(hipStreamWaitEvent(t->stream, ln.resolved, 0));
-  return FSPT_OK;
-}
-
-// ---------------------------------------------------------------------------
-// Stream scheduler (fspt_device.hpp: WfStreamCtl; fspt_target_set_pipeline code 2)
-// ---------------------------------------------------------------------------
-static const uint32_t ST_DEFAULT_POOL = 16u << 20; // paths per state set (3.4 GB; profiles/r03/sweep_stream_pool.log)
-static const bool ST_DEFAULT_OVERLAP = true; // profiles/r03/ab_stream_overlap.log: 8 Mi pool, 20 / 128 steps: 3 733 / 4 095 Msamples/s against 3 702 / 3 975 on one stream
-static const size_t ST_CTL_BYTES = sizeof(fspt::WfStreamCtl);
-static const size_t ST_COUNTS_BYTES = sizeof(fspt::WfCounts) * (WF_ROUNDS_MAX + 2);
-
-// Path state of one lane for the stream scheduler: two state sets + ray results for `cap` paths, `fin_slots` finished colours.
-static int st_ensure(fspt_target *t, fspt_target::WfLane &ln, uint32_t cap, uint32_t fin_slots, uint64_t budget_bytes) {
-  (void)t;
-  if (ln.st_cap >= cap && ln.st_fin >= fin_slots && ln.counts && ln.ctl) return FSPT_OK; // (a larger pool from an earlier call is kept)
-  wf_release(ln);
-  const uint64_t need = (uint64_t)cap * (wf_slot_bytes() - 12) + (uint64_t)fin_slots * 12;
-  for (int i = 0; i < WF_ARRAYS; ++i) {
-    const size_t bytes = i == 14 ? (size_t)fin_slots * 12 : (size_t)cap * WF_ARRAY_BYTES[i];
-    hipError_t e = need > budget_bytes ? hipErrorOutOfMemory : hipMalloc(&ln.mem[i], bytes);
-    if (e == hipErrorOutOfMemory) {
-      (void)hipGetLastError();
-      wf_release(ln);
-      fspt_set_error("path pool of %u paths + %u finished samples (%llu bytes) does not fit %s", cap, fin_slots, (unsigned long long)need,
-                     need > budget_bytes ? "the target's memory limit" : "the free device memory");
-      return FSPT_E_NOMEM;
-    }
-    HIP_TRY(e);
-    HIP_TRY(hipMemsetAsync(ln.mem[i], 0, bytes, ln.stream)); // touch every page once, now
-  }
-  if (!ln.counts) HIP_TRY(hipMalloc((void **)&ln.counts, ST_COUNTS_BYTES));
-  if (!ln.heads) HIP_TRY(hipMalloc((void **)&ln.heads, WF_HEADS_BYTES));
-  if (!ln.counts_host) HIP_TRY(hipHostMalloc((void **)&ln.counts_host, ST_COUNTS_BYTES, hipHostMallocDefault));
-  if (!ln.counts_ready) HIP_TRY(hipEventCreateWithFlags(&ln.counts_ready, hipEventDisableTiming));
-  if (!ln.ctl) HIP_TRY(hipMalloc((void **)&ln.ctl, ST_CTL_BYTES));
-  if (!ln.ctl_host) HIP_TRY(hipHostMalloc((void **)&ln.ctl_host, ST_CTL_BYTES, hipHostMallocDefault));
-  HIP_TRY(hipStreamSynchronize(ln.stream));
-  ln.st_cap = cap; ln.st_fin = fin_slots;
-  ln.bytes = need;
-  return FSPT_OK;
-}
-
-// Geometry of a stream run: n_batch ticks of a lane's share of the frame.
-struct StPlan {
-  uint32_t cap, unit_slots, take_max, horizon, ring_slots, units;
-};
-static int st_plan(const fspt_target *t, uint32_t units, uint32_t nbt, uint32_t nb, StPlan &pl) {
-  const bool overlap = t->stream_overlap < 0 ? ST_DEFAULT_OVERLAP : t->stream_overlap != 0;
-  pl.units = units;
-  pl.unit_slots = 64u * nbt;
-  uint64_t cap = t->pool_paths ? t->pool_paths : ST_DEFAULT_POOL;
-  // a pool larger than the run needs is memory for nothing: everything fits when cap = the run's samples
-  const uint64_t all = (uint64_t)units * pl.unit_slots;
-  if (cap > all) cap = all;
-  if (cap < 2ull * pl.unit_slots) cap = 2ull * pl.unit_slots;
-  // every path generated in iteration k has ended after logic(k + horizon): the bounce budget, or - when a material can
-  // refract, tracer.fs:488 - the cap on loop iterations
-  pl.horizon = t->scene->has_dielectric ? (uint32_t)fspt::MAX_PATH_ITERS : (nb ? nb : 0u);
-  // a suspended traversal makes its path lag a round, at most WF_LAG_MAX times (fspt_device.hpp)
-  if (t->susp_budget != 0 && t->count == 0) pl.horizon += fspt::WF_LAG_MAX;
-  if (t->mem_limit) {
-    // what the memory limit leaves per lane: 204 bytes per pool path + its share of the ring, 12 * (horizon + 3) / 2
-    // (one stream: / 1) bytes, + one unit of rounding
-    const uint64_t per_path = (wf_slot_bytes() - 12) + (overlap ? 6ull : 12ull) * (pl.horizon + 3u);
-    uint64_t lane_limit = t->mem_limit;
-    // ... minus the suspension records of a pool-sized trace grid (they count as path state: susp_ensure), unless they
-    // alone would take more than a quarter of the limit - then this target's traversals are not suspended
-    if (t->susp_budget != 0 && t->count == 0) {
-      const uint64_t rec = susp_need(t, cap, nullptr, nullptr);
-      if (rec <= lane_limit / 4) lane_limit -= rec;
-    }
-    const uint64_t round_up = 12ull * (pl.horizon + 3u) * pl.unit_slots;
-    const uint64_t fit = lane_limit > round_up ? (lane_limit - round_up) / per_path : 0;
-    if (cap > fit) cap = fit;
-    if (cap < 2ull * pl.unit_slots) { fspt_set_error("the target's memory limit leaves no room for a pool of two units (%u paths)", 2u * pl.unit_slots); return FSPT_E_NOMEM; }
-  }
-  if (cap > 0x1FFFFFFFull) cap = 0x1FFFFFFFull; // k_wf_trace: 29 bits of state index
-  pl.cap = (uint32_t)cap;
-  // overlapped: plan(i) runs before logic(i) and has to leave room for every live path; one stream: it runs after
-  pl.take_max = (uint32_t)(cap / (overlap ? 2 : 1) / pl.unit_slots);
-  if (pl.take_max < 1) pl.take_max = 1;
-  const uint64_t ring_units = (uint64_t)(pl.horizon + 3u) * pl.take_max;
-  const uint64_t ring = (ring_units < units ? ring_units : units) * pl.unit_slots; // never more than the run itself
-  if (ring > 0xFFFFFFFFull) { fspt_set_error("frame too large for the stream scheduler (fin ring of %llu samples)", (unsigned long long)ring); return FSPT_E_INVALID; }
-  pl.ring_slots = (uint32_t)ring;
-  return FSPT_OK;
-}
-
-static void st_collect(fspt_target::WfLane &ln) {
-  if (!ln.ctl_pending || hipEventQuery(ln.ctl_ready) != hipSuccess) return;
-  ln.ctl_pending = false;
-  ln.stat_key = ln.ctl_key;
-  uint64_t gen = (uint64_t)ln.ctl_host->last_gen_it + 1u;
-  // the finishing launch had to generate units itself: the iterations were too few - scale the estimate up
-  const uint32_t fin = ln.ctl_host->fin_gen_units, units = ln.ctl_units;
-  if (fin && units > fin) gen = (gen * units + (units - fin) - 1) / (units - fin) + 1;
-  else if (fin) gen = gen * 2 + 1;
-  ln.stat_gen_iters = (uint32_t)(gen > 100000 ? 100000 : gen);
-}
-
-// n_ticks ticks through the stream scheduler.  Everything is enqueued without waiting for the device.
-static int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
-                         const float *rb_cam, const float *rb_trace, bool rays_from_buffers) {
-  fspt::TraceP tp{};
-  fill_trace_params(t, tp);
-  const uint32_t work_total = tp.n_owned_tiles * tp.tile * tp.tile;
-  if (work_total == 0) return FSPT_OK;
-  const uint32_t units_total = work_total >> 6; // tile is a multiple of 8: whole 64-pixel patches
-  const uint32_t nb = cam->num_bounces;
-  const int cus = t->scene->num_cus;
-  constexpr uint32_t R = fspt::WF_RING;
-  const bool overlap = t->stream_overlap < 0 ? ST_DEFAULT_OVERLAP : t->stream_overlap != 0;
-  const bool susp_on = t->susp_budget != 0 && t->count == 0;
-
-  fspt::WfP base{};
-  base.scene = t->scene->d;
-  base.W = t->W; base.H = t->H; base.vw = t->vw; base.vh = t->vh;
-  base.env_theta = cam->env_theta; base.num_bounces = nb;
-  std::memcpy(base.cam.P, cam->P, 12); std::memcpy(base.cam.I, cam->I, 12);
-  base.cam.fov_scale = cam->fov_scale; base.cam.lens[0] = cam->lens[0]; base.cam.lens[1] = cam->lens[1];
-  base.ray_pos = t->ray_pos; base.ray_dir = t->ray_dir;
-  base.accum = t->accum;
-  base.counters = t->count ? t->counters : nullptr;
-  base.shard = tp.shard; base.n_shards = tp.n_shards; base.tile = tp.tile; base.tiles_x = tp.tiles_x; base.tiles_y = tp.tiles_y;
-  base.n_owned_tiles = tp.n_owned_tiles;
-  base.gen_rays = rays_from_buffers ? 0u : 1u;
-  base.primary_r = 1u; // (iterations of varying size: the plain form)
-  base.wide = wide_bit(t, fspt::WF_K_PRIMARY, -1.0) | wide_bit(t, fspt::WF_K_TAIL, -1.0);
-
-  // everything already queued on the target's stream (clear, ray upload, earlier renders) comes first
-  HIP_TRY(hipEventRecord(t->ev_start, t->stream));
-  fspt_target::WfLane &ln = t->wf;
-  HIP_TRY(hipStreamWaitEvent(ln.stream, t->ev_start, 0));
-
-  int rc = FSPT_OK;
-  auto launch = [&](int kind, const fspt::WfP &p, hipStream_t st) -> int {
-    int e = kind >= fspt::WF_K_KINDS ? -1 : ev_begin(t, kind, st);
-    hipError_t err = fspt::launch_wf(kind, p, t->count, cus, st);
-    ev_end(t, e, st);
-    if (err != hipSuccess) { fspt_set_error("stream launch %d failed: %s", kind, hipGetErrorString(err)); return FSPT_E_HIP; }
-    return FSPT_OK;
-  };
-
-  uint32_t done = 0;
-  while (done < n_ticks) {
-    // a run covers batch_ticks ticks (what fspt_target_prepare sized the pool for), at most WF_MAX_BATCH
-    const uint32_t run_max = t->batch_ticks && t->batch_ticks < (uint32_t)fspt::WF_MAX_BATCH ? t->batch_ticks : (uint32_t)fspt::WF_MAX_BATCH;
-    uint32_t nbt = n_ticks - done < run_max ? n_ticks - done : run_max;
-    // the samples of a run are numbered in 32 bits (kernels: g = first + i): a frame beyond 2^32 / 128 pixels runs fewer ticks at a time
-    while (nbt > 1 && (uint64_t)work_total * nbt > 0xFFFFFFFFull) nbt /= 2;
-    if ((uint64_t)work_total * nbt > 0xFFFFFFFFull) { fspt_set_error("frame too large for the stream scheduler (more than 2^32 pixels per shard)"); return FSPT_E_INVALID; }
-    fspt::WfP p = base;
-    StPlan pl;
-    uint32_t iters = 0;
-    int res_done = -1; // the iteration whose cursor position marks what has been folded into the accumulator
-    bool susp_run = susp_on;
-    {
-      const uint32_t units = units_total;
-      if ((rc = st_plan(t, units, nbt, nb, pl))) return rc;
-      const uint64_t budget = t->mem_limit ? t->mem_limit : ~0ull;
-      if ((rc = st_ensure(t, ln, pl.cap, pl.ring_slots, budget))) return rc;
-      for (int k = 0; k < 2; ++k) {
-        fspt::WfSet &ws = p.set[k];
-        ws.A = (float4 *)ln.mem[6 * k + 0]; ws.B = (float4 *)ln.mem[6 * k + 1]; ws.C = (float4 *)ln.mem[6 * k + 2];
-        ws.E = (float4 *)ln.mem[6 * k + 3]; ws.D = (float4 *)ln.mem[6 * k + 4]; ws.P = (float4 *)ln.mem[6 * k + 5];
-      }
-      p.hit = (float2 *)ln.mem[12]; p.shadow_hit = (int *)ln.mem[13]; p.fin = (float *)ln.mem[14];
-      p.counts = ln.counts; p.heads = ln.heads; p.ctl = ln.ctl;
-      p.work_total = units * 64u; p.n_batch = nbt; p.first_tick = first_tick + done;
-      p.ring_slots = pl.ring_slots; p.cap = pl.cap; p.take_max = pl.take_max;
-      p.wide |= wide_bit(t, fspt::WF_K_TRACE, (double)pl.cap); // (every trace launch of a run is about pool-sized)
-      if (susp_run && (rc = susp_ensure(t, ln, pl.cap, &susp_run))) return rc;
-      p.susp[0] = susp_run ? ln.susp[0] : nullptr; p.susp[1] = susp_run ? ln.susp[1] : nullptr; p.susp_stride = ln.susp_stride; p.susp_budget = susp_run ? t->susp_budget : 0u;
-      p.serial = overlap ? 0u : 1u;
-      for (uint32_t j = 0; j < nbt; ++j) { p.rb_cam[j] = rb_cam ? rb_cam[done + j] : 0.0f; p.rb_trace[j] = rb_trace[done + j]; }
-      // how many iterations hand out all units: what the last such run needed, else from the pool's equilibrium
-      // (about 0.45 of the pool is new samples per iteration at 30 % survival per step)
-      st_collect(ln);
-      const uint64_t key = ((uint64_t)units << 32) ^ ((uint64_t)nbt << 24) ^ ((uint64_t)nb << 16) ^ (uint64_t)pl.cap * 0x9E3779B97F4A7C15ull;
-      uint32_t take_eq = (uint32_t)((overlap ? 0.45 : 0.75) * pl.cap / pl.unit_slots);
-      if (take_eq > pl.take_max) take_eq = pl.take_max;
-      if (take_eq < 1) take_eq = 1;
-      uint32_t gen = (units + take_eq - 1) / take_eq + (units > take_eq ? 1u : 0u);
-      if (ln.stat_key == key && ln.stat_gen_iters) gen = ln.stat_gen_iters;
-      const uint32_t drain = t->stream_drain >= 0 ? (uint32_t)t->stream_drain : (gen > 1 ? 2u : 0u);
-      iters = gen + drain;
-      if (t->stream_iter_cap && iters > t->stream_iter_cap) iters = t->stream_iter_cap;
-      if (iters < 1) iters = 1;
-      ln.ctl_key = key;
-      ln.ctl_units = units;
-      // a fresh run: cursor 0, no history, counters and pool heads zero
-      if (!ln.zeroed) {
-        HIP_TRY(hipMemsetAsync(ln.ctl, 0, ST_CTL_BYTES, ln.stream));
-        HIP_TRY(hipMemsetAsync(ln.counts, 0, ST_COUNTS_BYTES, ln.stream));
-        HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, ln.stream));
-      }
-      ln.zeroed = false;
-      HIP_TRY(hipEventRecord(ln.ev_run, ln.stream));
-      HIP_TRY(hipStreamWaitEvent(ln.stream_b, ln.ev_run, 0));
-    }
-    for (uint32_t it = 0; it < iters; ++it) {
-      {
-        hipStream_t A = ln.stream, B = overlap ? ln.stream_b : ln.stream;
-        p.round = it; p.cnt_in = (it + R - 1) % R; p.cnt_out = it % R; p.set_in = (it + 1) & 1u; p.set_out = it & 1u;
-        if (!overlap) {
-          // ---- one stream: logic(it) first, so that plan(it) sees what really survived and fills the pool to the brim
-          if (it >= 1) {
-            p.carry_blocks = susp_run ? FSPT_CARRY_BLOCKS : 0u;
-            if (susp_run && !FSPT_CARRY_BLOCKS && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
-            if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
-            p.carry_blocks = 0u;
-          }
-          if ((rc = launch(fspt::WF_K_PLAN, p, A))) return rc;
-          if ((rc = launch(fspt::WF_K_PRIMARY, p, A))) return rc;
-          const int to = (int)it - (int)pl.horizon; // after logic(it) every path generated up to iteration `to` has ended
-          if (to >= 0 && to > res_done) {
-            p.res_from = res_done; p.res_to = to;
-            if ((rc = launch(fspt::WF_K_RESOLVE, p, A))) return rc;
-            res_done = to;
-          }
-          { const uint32_t keep = p.susp_budget;
-            if (it + 1 == iters) p.susp_budget = 0;
-            if ((rc = launch(fspt::WF_K_TRACE, p, A))) return rc;
-            p.susp_budget = keep; }
-          continue;
-        }
-        // ---- B: plan + primary of iteration `it` (beside trace(it - 1)), then the resolve that logic(it - 1) made possible
-        if (it >= 2) HIP_TRY(hipStreamWaitEvent(B, ln.ev_logic[(it - 1) % R], 0)); // logic(it-1) read the set primary(it) writes
-        if ((rc = launch(fspt::WF_K_PLAN, p, B))) return rc;
-        if ((rc = launch(fspt::WF_K_PRIMARY, p, B))) return rc;
-        HIP_TRY(hipEventRecord(ln.ev_b[it % R], B));
-        const int to = (int)it - 1 - (int)pl.horizon; // after logic(it-1) every path generated up to iteration `to` has ended
-        if (to >= 0 && to > res_done) {
-          p.res_from = res_done; p.res_to = to;
-          if ((rc = launch(fspt::WF_K_RESOLVE, p, B))) return rc;
-          res_done = to;
-        }
-        // ---- A: logic(it) on the results of trace(it - 1), then trace(it) once primary(it) has added its survivors
-        if (it >= 1) {
-          p.carry_blocks = susp_run ? FSPT_CARRY_BLOCKS : 0u;
-          if (susp_run && !FSPT_CARRY_BLOCKS && (rc = launch(fspt::WF_K_CARRY, p, A))) return rc;
-          if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
-          p.carry_blocks = 0u;
-          HIP_TRY(hipEventRecord(ln.ev_logic[it % R], A));
-        }
-        HIP_TRY(hipStreamWaitEvent(A, ln.ev_b[it % R], 0));
-        { // (the run's last trace launch lets its long rays finish: the tail kernel would trace them again from the start)
-          const uint32_t keep = p.susp_budget;
-          if (it + 1 == iters) p.susp_budget = 0;
-          if ((rc = launch(fspt::WF_K_TRACE, p, A))) return rc;
-          p.susp_budget = keep;
-        }
-      }
-    }
-    // ---- the end of the run: logic on the last trace's results, then the tail kernel runs whatever is alive to
-    // completion and generates whatever the cursor has not handed out; then the rest is folded into the accumulator
-    {
-      hipStream_t A = ln.stream, B = overlap ? ln.stream_b : ln.stream;
-      const uint32_t it = iters;
-      p.round = it; p.cnt_in = (it + R - 1) % R; p.cnt_out = it % R; p.set_in = (it + 1) & 1u; p.set_out = it & 1u;
-      // (no carry launch: the run's last trace launch does not suspend)
-      if ((rc = launch(fspt::WF_K_LOGIC, p, A))) return rc;
-      p.finish = 1;
-      if ((rc = launch(fspt::WF_K_TAIL, p, A))) return rc;
-      HIP_TRY(hipEventRecord(ln.ev_b_last, B));
-      HIP_TRY(hipStreamWaitEvent(A, ln.ev_b_last, 0)); // the resolves so far ran on B
-      // everything the iterations handed out (up to the last plan's cursor): the units the finishing launch generated
-      // itself went straight into the accumulator
-      p.res_from = res_done; p.res_to = (int)it - 1;
-      if ((rc = launch(fspt::WF_K_RESOLVE, p, A))) return rc;
-      HIP_TRY(hipMemcpyAsync(ln.ctl_host, ln.ctl, ST_CTL_BYTES, hipMemcpyDeviceToHost, A));
-      HIP_TRY(hipEventRecord(ln.ctl_ready, A));
-      ln.ctl_pending = true;
-      HIP_TRY(hipEventRecord(ln.resolved, A));
-      // cleared for the next run behind this one, not in front of the next one's first kernel
-      HIP_TRY(hipMemsetAsync(ln.ctl, 0, ST_CTL_BYTES, A));
-      HIP_TRY(hipMemsetAsync(ln.counts, 0, ST_COUNTS_BYTES, A));
-      HIP_TRY(hipMemsetAsync(ln.heads, 0, WF_HEADS_BYTES, A));
-      ln.zeroed = true;
-      HIP_TRY(hipStreamWaitEvent(B, ln.resolved, 0)); // the next run's B work comes after this run
-    }
-    done += nbt;
-  }
-  HIP_TRY(hipStreamWaitEvent(t->stream, ln.resolved, 0));
-  return FSPT_OK;
-}
+} // extern "C"
 
 // Every path ends after MAX_PATH_ITERS loop iterations (the cap on tracer.fs:488's `i--`), and `i` never exceeds the
 // iteration count: a larger NUM_BOUNCES cannot change any sample.  Clamping keeps the per-round tables
 // (WfCounts[WF_ROUNDS_MAX + 2], the 8-bit bounce field of the path flags) in range for any caller value.
-static uint32_t clamp_bounces(uint32_t nb) { return nb > (uint32_t)FSPT_MAX_BOUNCES ? (uint32_t)FSPT_MAX_BOUNCES : nb; }
+uint32_t clamp_bounces(uint32_t nb) { return nb > (uint32_t)FSPT_MAX_BOUNCES ? (uint32_t)FSPT_MAX_BOUNCES : nb; }
 
 // n_ticks ticks with ray generation in the path kernels and explicit per-tick randBase values, on either pipeline
 static int render_ticks(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
@@ -1553,7 +703,7 @@ static int render_ticks(fspt_target *t, const fspt_camera_params *cam, uint32_t 
 // k_camera followed by a trace of the ray buffers, tests/test_parity_gpu.py).  Called by everything that observes or
 // changes state the ticks depend on.
 static bool same_view(const fspt_camera_params &a, const fspt_camera_params &b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
-static int flush_pending(fspt_target *t) {
+int flush_pending(fspt_target *t) {
   if (t->pending.empty()) return FSPT_OK;
   std::vector<fspt_target::Deferred> q;
   q.swap(t->pending); // (a failing batch drops the rest: the error is reported once)
@@ -1573,7 +723,7 @@ static int flush_pending(fspt_target *t) {
 }
 
 // the ray buffers as the most recent fspt_camera call left them (drawCamera's two render targets)
-static int materialise_rays(fspt_target *t) {
+int materialise_rays(fspt_target *t) {
   if (!t->cam_recorded) return FSPT_OK;
   fspt::CameraP c;
   std::memcpy(c.P, t->last_cam.P, 12); std::memcpy(c.I, t->last_cam.I, 12);
@@ -1582,6 +732,8 @@ static int materialise_rays(fspt_target *t) {
   t->cam_recorded = false;
   return FSPT_OK;
 }
+
+extern "C" {
 
 int fspt_trace(fspt_target *t, uint32_t tick, float rand_base, float env_theta, uint32_t num_bounces) {
   if (!t) { fspt_set_error("fspt_trace: NULL target"); return FSPT_E_INVALID; }
@@ -1907,178 +1059,6 @@ int fspt_get_trace_lds_steps(fspt_target *t, uint64_t *steps) {
   HIP_TRY(hipMemcpyAsync(&v, t->counters + 6, 8, hipMemcpyDeviceToHost, t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
   *steps = v;
-  return FSPT_OK;
-}
-
-// ---------------------------------------------------------------------------
-// one frame over several devices (include/fspt.h: fspt_multi_*)
-// ---------------------------------------------------------------------------
-struct fspt_multi {
-  uint32_t W = 0, H = 0;
-  std::vector<int> devices;
-  std::vector<fspt_scene *> scenes;
-  std::vector<fspt_target *> targets;
-  std::vector<float4 *> packed;   // per target: its own pixels in work-index order (on its device)
-  std::vector<float4 *> staging;  // per target: the same, on devices[0]
-  std::vector<hipEvent_t> arrived;
-  std::vector<int> peer_direct;   // per target: bit 0 = its device can write devices[0]'s memory directly, bit 1 = the reverse
-  uint64_t gather_bytes = 0;
-};
-
-static void multi_pack_params(fspt_target *t, fspt::TilePackP &q) {
-  fspt::TraceP tp{};
-  fill_trace_params(t, tp);
-  q.W = t->W; q.H = t->H; q.vw = t->W; q.vh = t->H; // the read-out moves whole tiles, whatever the viewport
-  q.shard = tp.shard; q.n_shards = tp.n_shards; q.tile = tp.tile; q.tiles_x = tp.tiles_x; q.tiles_y = tp.tiles_y;
-  q.n_owned_tiles = tp.n_owned_tiles;
-}
-
-int fspt_multi_destroy(fspt_multi *m) {
-  if (!m) return FSPT_OK;
-  for (size_t i = 0; i < m->targets.size(); ++i) {
-    if (m->targets[i]) { hipSetDevice(m->devices[i]); hipStreamSynchronize(m->targets[i]->stream); }
-  }
-  for (size_t i = 0; i < m->devices.size(); ++i) {
-    if (i < m->packed.size() && m->packed[i]) { hipSetDevice(m->devices[i]); hipFree(m->packed[i]); }
-    if (i < m->staging.size() && m->staging[i]) { hipSetDevice(m->devices[0]); hipFree(m->staging[i]); }
-    if (i < m->arrived.size() && m->arrived[i]) { hipSetDevice(m->devices[i]); hipEventDestroy(m->arrived[i]); }
-  }
-  for (fspt_target *t : m->targets) fspt_target_destroy(t);
-  for (fspt_scene *s : m->scenes) fspt_scene_destroy(s);
-  delete m;
-  return FSPT_OK;
-}
-
-int fspt_multi_create(const fspt_scene_desc *desc, const int *devices, uint32_t n_devices, uint32_t W, uint32_t H, fspt_multi **out) {
-  if (!desc || !devices || !out || n_devices == 0 || n_devices > 64) { fspt_set_error("fspt_multi_create: bad argument (1..64 devices)"); return FSPT_E_INVALID; }
-  *out = nullptr;
-  fspt_multi *m = new fspt_multi();
-  m->W = W; m->H = H;
-  m->devices.assign(devices, devices + n_devices);
-  m->packed.assign(n_devices, nullptr); m->staging.assign(n_devices, nullptr); m->arrived.assign(n_devices, nullptr); m->peer_direct.assign(n_devices, 3);
-  int rc = FSPT_OK;
-  for (uint32_t i = 0; i < n_devices && rc == FSPT_OK; ++i) {
-    // one scene copy per DISTINCT device (a device listed twice shares it)
-    fspt_scene *s = nullptr;
-    for (uint32_t j = 0; j < i; ++j) if (devices[j] == devices[i]) { s = m->targets[j]->scene; break; }
-    if (!s) { rc = fspt_scene_create(desc, devices[i], &s); if (rc == FSPT_OK) m->scenes.push_back(s); }
-    fspt_target *t = nullptr;
-    if (rc == FSPT_OK) rc = fspt_target_create(s, W, H, &t);
-    if (rc == FSPT_OK) { m->targets.push_back(t); rc = fspt_target_set_shard(t, i, n_devices, 32); }
-    if (rc == FSPT_OK && i > 0) {
-      fspt::TilePackP q{};
-      multi_pack_params(t, q);
-      const size_t bytes = (size_t)q.n_owned_tiles * q.tile * q.tile * sizeof(float4);
-      hipError_t e = hipSetDevice(devices[i]);
-      if (e == hipSuccess) e = hipMalloc((void **)&m->packed[i], bytes ? bytes : 16);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&m->arrived[i], hipEventDisableTiming);
-      if (e == hipSuccess) e = hipSetDevice(devices[0]);
-      if (e == hipSuccess) e = hipMalloc((void **)&m->staging[i], bytes ? bytes : 16);
-      if (e == hipSuccess && devices[i] != devices[0]) {
-        // The gather copy is issued on the SENDING device's stream and writes devices[0]'s memory (multi_gather), so
-        // the mapping that matters is devices[i] -> devices[0]; the reverse one is enabled too (hipMemcpyPeerAsync may
-        // pick either end's copy engine).  Without peer access the copy still works, staged through the host.
-        int can_out = 0, can_in = 0;
-        (void)hipDeviceCanAccessPeer(&can_out, devices[i], devices[0]);
-        (void)hipDeviceCanAccessPeer(&can_in, devices[0], devices[i]);
-        if (can_out && hipSetDevice(devices[i]) == hipSuccess && hipDeviceEnablePeerAccess(devices[0], 0) != hipSuccess) (void)hipGetLastError(); // already enabled
-        if (can_in && hipSetDevice(devices[0]) == hipSuccess && hipDeviceEnablePeerAccess(devices[i], 0) != hipSuccess) (void)hipGetLastError();
-        m->peer_direct[i] = (can_out ? 1 : 0) | (can_in ? 2 : 0);
-      } else if (e == hipSuccess) {
-        m->peer_direct[i] = 3; // the same device
-      }
-      if (e != hipSuccess) { fspt_set_error("fspt_multi_create: %s", hipGetErrorString(e)); rc = FSPT_E_HIP; }
-    }
-  }
-  if (rc != FSPT_OK) { fspt_multi_destroy(m); return rc; }
-  *out = m;
-  return FSPT_OK;
-}
-
-int fspt_multi_target(fspt_multi *m, uint32_t i, fspt_target **out) {
-  if (!m || !out || i >= m->targets.size()) { fspt_set_error("fspt_multi_target: bad argument"); return FSPT_E_INVALID; }
-  *out = m->targets[i];
-  return FSPT_OK;
-}
-
-#define MULTI_EACH(call)                                                     \
-  do {                                                                       \
-    if (!m) { fspt_set_error("fspt_multi: NULL handle"); return FSPT_E_INVALID; } \
-    for (fspt_target *t : m->targets) { int rc_ = (call); if (rc_) return rc_; }  \
-    return FSPT_OK;                                                          \
-  } while (0)
-
-int fspt_multi_camera(fspt_multi *m, const float P[3], const float I[3], float fov_scale, const float lens[2], float rand_base) {
-  MULTI_EACH(fspt_camera(t, P, I, fov_scale, lens, rand_base));
-}
-int fspt_multi_trace(fspt_multi *m, uint32_t tick, float rand_base, float env_theta, uint32_t num_bounces) {
-  MULTI_EACH(fspt_trace(t, tick, rand_base, env_theta, num_bounces));
-}
-int fspt_multi_render(fspt_multi *m, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks, uint64_t seed) {
-  MULTI_EACH(fspt_render(t, cam, first_tick, n_ticks, seed));
-}
-int fspt_multi_clear(fspt_multi *m) { MULTI_EACH(fspt_clear(t)); }
-int fspt_multi_sync(fspt_multi *m) { MULTI_EACH(fspt_sync(t)); }
-
-// every device packs its own tiles and sends them to devices[0] on its own stream; devices[0] scatters them
-static int multi_gather(fspt_multi *m) {
-  fspt_target *t0 = m->targets[0];
-  m->gather_bytes = 0;
-  for (fspt_target *t : m->targets) FLUSH_OR_RETURN(t); // recorded two-call ticks of every device run before its tiles are packed
-  for (size_t i = 1; i < m->targets.size(); ++i) {
-    fspt_target *t = m->targets[i];
-    fspt::TilePackP q{};
-    multi_pack_params(t, q);
-    const size_t bytes = (size_t)q.n_owned_tiles * q.tile * q.tile * sizeof(float4);
-    if (!bytes) continue;
-    HIP_TRY(hipSetDevice(m->devices[i]));
-    q.accum = t->accum; q.packed = m->packed[i];
-    HIP_TRY(fspt::launch_tile_pack(q, false, t->stream));
-    HIP_TRY(hipMemcpyPeerAsync(m->staging[i], m->devices[0], m->packed[i], m->devices[i], bytes, t->stream));
-    HIP_TRY(hipEventRecord(m->arrived[i], t->stream));
-    m->gather_bytes += bytes;
-  }
-  HIP_TRY(hipSetDevice(m->devices[0]));
-  for (size_t i = 1; i < m->targets.size(); ++i) {
-    fspt::TilePackP q{};
-    multi_pack_params(m->targets[i], q);
-    if (!q.n_owned_tiles) continue;
-    HIP_TRY(hipStreamWaitEvent(t0->stream, m->arrived[i], 0));
-    q.accum = t0->accum; q.packed = m->staging[i];
-    HIP_TRY(fspt::launch_tile_pack(q, true, t0->stream));
-  }
-  return FSPT_OK;
-}
-
-int fspt_multi_read_radiance(fspt_multi *m, float *out) {
-  if (!m || !out) { fspt_set_error("fspt_multi_read_radiance: NULL argument"); return FSPT_E_INVALID; }
-  int rc = multi_gather(m);
-  if (rc) return rc;
-  return fspt_read_radiance(m->targets[0], out);
-}
-
-int fspt_multi_draw(fspt_multi *m, float exposure, float saturation, int denoise, float max_sigma, uint8_t *out_rgba8) {
-  if (!m || !out_rgba8) { fspt_set_error("fspt_multi_draw: NULL argument"); return FSPT_E_INVALID; }
-  int rc = multi_gather(m);
-  if (rc) return rc;
-  return fspt_draw(m->targets[0], exposure, saturation, denoise, max_sigma, out_rgba8);
-}
-
-int fspt_multi_size(fspt_multi *m, uint32_t *W, uint32_t *H) {
-  if (!m || !W || !H) { fspt_set_error("fspt_multi_size: NULL argument"); return FSPT_E_INVALID; }
-  *W = m->W; *H = m->H;
-  return FSPT_OK;
-}
-
-int fspt_multi_peer_access(fspt_multi *m, uint32_t i, int *mask) {
-  if (!m || !mask || i >= m->targets.size()) { fspt_set_error("fspt_multi_peer_access: bad argument"); return FSPT_E_INVALID; }
-  *mask = m->peer_direct[i];
-  return FSPT_OK;
-}
-
-int fspt_multi_last_gather_bytes(fspt_multi *m, uint64_t *bytes) {
-  if (!m || !bytes) { fspt_set_error("fspt_multi_last_gather_bytes: NULL argument"); return FSPT_E_INVALID; }
-  *bytes = m->gather_bytes;
   return FSPT_OK;
 }
 

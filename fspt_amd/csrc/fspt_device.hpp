@@ -285,7 +285,8 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
 // multi-device read-out: a shard's own pixels <-> a packed array in work-index order (work_to_pixel)
 struct TilePackP {
   float4 *accum;   // full-size W x H accumulator
-  float4 *packed;  // n_owned_tiles * tile^2 entries
+  float4 *packed;  // n_owned_tiles * tile^2 entries (channels 3: that many RGB triples, alpha = 1 on unpack, tracer.fs:517)
+  uint32_t channels; // 0 / 4: RGBA, 3: RGB
   uint32_t W, H, vw, vh;
   uint32_t shard, n_shards, tile, tiles_x, tiles_y, n_owned_tiles;
 };

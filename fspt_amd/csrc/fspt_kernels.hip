@@ -2103,7 +2103,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_tile_pack(const TilePackP p) 
   for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
     uint32_t x, y;
     if (!work_to_pixel(p, w, x, y)) continue;
-    if (UNPACK) p.accum[(size_t)y * p.W + x] = p.packed[w];
+    if (p.channels == 3u) {
+      float *q = reinterpret_cast<float *>(p.packed) + 3 * (size_t)w;
+      if (UNPACK) { const V3 c = ld3(q); p.accum[(size_t)y * p.W + x] = make_float4(c.x, c.y, c.z, 1.0f); }
+      else { const float4 a = p.accum[(size_t)y * p.W + x]; st3(q, v3(a.x, a.y, a.z)); }
+    } else if (UNPACK) p.accum[(size_t)y * p.W + x] = p.packed[w];
     else p.packed[w] = p.accum[(size_t)y * p.W + x];
   }
 }

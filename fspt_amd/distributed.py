@@ -114,10 +114,25 @@ class TileGather:
     to 1 itself, on every unpack (the bound accumulator may have been cleared in between: fspt_clear zeroes alpha too).
     Only valid when every owned pixel is traced (full-frame viewport); channels = 4 (default) ships the buffer as it is."""
 
-    def __init__(self, rank, world, width, height, device, tile=TILE, dst=0, channels=4):
+    def __init__(self, rank, world, width, height, device, tile=TILE, dst=0, channels=4, tracer=None):
         import torch
         assert channels in (3, 4)
         self.rank, self.world, self.dst, self.C = rank, world, dst, channels
+        self.tracer = tracer
+        if tracer is not None:
+            # The library's own pack / unpack kernels (include/fspt_multi.h: fspt_target_pack_tiles / _unpack_tiles - the
+            # k_tile_pack the single-process fspt_multi_* host uses): a shard's pixels in work-index order, one launch per
+            # piece, no index tensors.  `tracer` must be sharded (rank, world, tile) and bound to the accumulator that is
+            # exchanged.  (Without a tracer - CPU tensors, the gloo tests - the torch indexing path below does the same.)
+            slots = [tracer.shard_slots(r, world) for r in range(world)]
+            self.n_max = max(slots)
+            self.send = torch.zeros((max(1, self.n_max), channels), dtype=torch.float32, device=device)
+            self.recv = None
+            if rank == dst:
+                self.big = torch.zeros((world * max(1, self.n_max), channels), dtype=torch.float32, device=device)
+                self.recv = list(self.big.split(max(1, self.n_max)))
+                self.slots = slots
+            return
         self.idx = owned_pixel_index(rank, world, width, height, tile, device)
         counts = [int(owner_mask(r, world, width, height, tile).sum()) for r in range(world)]
         self.n_max = max(counts)
@@ -145,6 +160,9 @@ class TileGather:
     def pack(self, accum):
         """Own pixels of accum ([H, W, 4]) -> self.send ([n_max, channels])."""
         import torch
+        if self.tracer is not None:
+            self.tracer.pack_tiles(self.send.data_ptr(), self.C)  # (accum is the tracer's bound accumulator; blocking)
+            return self.send
         flat = accum.view(-1, 4)
         n = self.idx.numel()
         if n:
@@ -159,6 +177,14 @@ class TileGather:
 
     def unpack(self, accum):
         """`dst` only: the other ranks' rows of self.big -> their pixels of accum."""
+        if self.tracer is not None:
+            import torch
+            if accum.is_cuda:
+                torch.cuda.current_stream(accum.device).synchronize()  # the gather ran on torch's stream, the kernels run on the library's
+            for r in range(self.world):
+                if r != self.dst and self.slots[r]:
+                    self.tracer.unpack_tiles(self.recv[r].data_ptr(), r, self.world, self.C)
+            return accum
         if self.all_idx is None:
             return accum
         flat = accum.view(-1, 4)

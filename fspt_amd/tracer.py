@@ -121,6 +121,21 @@ class PathTracer:
         self._keep = keep
         L.check(L.lib().fspt_target_bind_accumulator(self._t, C.c_void_p(device_ptr)))
 
+    # ---- the two ends of a one-process-per-GPU read-out exchange (include/fspt.h) -----------------------------
+    def shard_slots(self, shard, n_shards):
+        """Entries of shard `shard`'s packed pixel array: owned tiles x tile^2."""
+        n = C.c_uint64()
+        L.check(L.lib().fspt_target_shard_slots(self._t, int(shard), int(n_shards), C.byref(n)))
+        return int(n.value)
+
+    def pack_tiles(self, packed_ptr, channels=4):
+        """This target's own pixels -> packed[slots][channels] (device pointer).  Blocking."""
+        L.check(L.lib().fspt_target_pack_tiles(self._t, C.c_void_p(packed_ptr), int(channels)))
+
+    def unpack_tiles(self, packed_ptr, shard, n_shards, channels=4):
+        """Packed pixels of shard `shard` of `n_shards` -> the accumulator (channels 3: alpha = 1).  Blocking."""
+        L.check(L.lib().fspt_target_unpack_tiles(self._t, C.c_void_p(packed_ptr), int(shard), int(n_shards), int(channels)))
+
     def set_pipeline(self, pipeline, batch_ticks=0):
         """'wavefront' (batches), 'stream' (fixed pool of live paths) or 'megakernel'; results are bit-identical
         (include/fspt_tuning.h)."""
@@ -382,6 +397,19 @@ class MultiPathTracer:
         m = C.c_int()
         L.check(L.lib().fspt_multi_peer_access(self._m, int(i), C.byref(m)))
         return m.value
+
+    EXCHANGES = {"peer": 0, "rccl_gather": 1, "rccl_reduce": 2}
+
+    def set_exchange(self, mode):
+        """Read-out exchange: 'peer' (hipMemcpyPeerAsync of packed tiles, default), 'rccl_gather' (ncclSend / ncclRecv of
+        the same tiles) or 'rccl_reduce' (ncclReduce(SUM) of own-tiles-only frames); RCCL needs distinct devices."""
+        L.check(L.lib().fspt_multi_set_exchange(self._m, int(self.EXCHANGES.get(mode, mode))))
+
+    def exchange(self):
+        """(mode code, RCCL version or 0 when RCCL is not loaded)."""
+        m = C.c_int(); v = C.c_int()
+        L.check(L.lib().fspt_multi_get_exchange(self._m, C.byref(m), C.byref(v)))
+        return m.value, v.value
 
     def last_gather_bytes(self):
         b = C.c_uint64()

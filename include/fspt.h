@@ -148,37 +148,8 @@ float fspt_rand_base_next(uint64_t *state);
  * only pixels x < w, y < h are traced, the rest keeps its contents.  0, 0 restores the whole target. */
 int fspt_target_set_viewport(fspt_target *target, uint32_t w, uint32_t h);
 
-/* ------------------------------------------------------------------------
- * One frame over several GPUs of a node, driven by ONE host thread (README.md:28: "tiled rendering" is a TODO in the
- * reference).  One target per listed device owns every n_devices-th 32x32 tile (the RNG depends on pixel coordinates
- * and randBase only - camera.fs:38, tracer.fs:458 - so the assembled frame is bit-identical to a single-GPU render).
- * The draw calls enqueue on every device and return; NO data moves while rendering.  fspt_multi_read_radiance /
- * fspt_multi_draw do the one exchange: packed tiles travel to devices[0] with peer copies (xGMI) on the devices' own
- * streams and are scattered into its accumulator.  A device may be listed more than once (a 1-GPU box exercises the
- * path that way).
- * ---------------------------------------------------------------------- */
-typedef struct fspt_multi fspt_multi;
-int fspt_multi_create(const fspt_scene_desc *desc, const int *devices, uint32_t n_devices,
-                      uint32_t width, uint32_t height, fspt_multi **out);
-int fspt_multi_destroy(fspt_multi *m);
-/* the per-device target i (for fspt_target_set_pipeline / _set_tail / _prepare / counters); owned by m */
-int fspt_multi_target(fspt_multi *m, uint32_t i, fspt_target **out);
-int fspt_multi_camera(fspt_multi *m, const float P[3], const float I[3], float fov_scale, const float lens[2],
-                      float rand_base);                                     /* drawCamera on every device   */
-int fspt_multi_trace(fspt_multi *m, uint32_t tick, float rand_base, float env_theta, uint32_t num_bounces);
-int fspt_multi_render(fspt_multi *m, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
-                      uint64_t seed);                                       /* fspt_render on every device  */
-int fspt_multi_clear(fspt_multi *m);
-int fspt_multi_sync(fspt_multi *m);
-/* Gather (see above), then what fspt_read_radiance / fspt_draw do on the assembled frame.  Blocking. */
-int fspt_multi_read_radiance(fspt_multi *m, float *out);
-int fspt_multi_draw(fspt_multi *m, float exposure, float saturation, int denoise, float max_sigma, uint8_t *out_rgba8);
-/* Bytes that crossed between devices in the most recent gather (the exchange's payload: 16 bytes per foreign pixel). */
-int fspt_multi_last_gather_bytes(fspt_multi *m, uint64_t *bytes);
-int fspt_multi_size(fspt_multi *m, uint32_t *width, uint32_t *height);  /* the frame fspt_multi_create was given */
-/* How target i's tiles reach devices[0]: bit 0 = its device can write devices[0]'s memory (the direction the gather
- * copy runs), bit 1 = the reverse mapping; 0 = staged through the host; a target on devices[0] itself reports 3. */
-int fspt_multi_peer_access(fspt_multi *m, uint32_t i, int *mask);
+/* Several GPUs (one frame cut into 32x32 tiles over the devices of a node; the reference has nothing here - README.md:28
+ * lists "Tiled rendering" as a TODO): include/fspt_multi.h, included at the end of this file. */
 
 /* clear() (main.js:826-836). */
 int fspt_clear(fspt_target *target);
@@ -289,4 +260,5 @@ int fspt_device_count(void);
 #ifdef __cplusplus
 }
 #endif
+#include "fspt_multi.h"
 #endif /* FSPT_H */

@@ -12,7 +12,7 @@ from fspt_amd import _lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-HEADERS = ("fspt.h", "fspt_tuning.h")  # the drop-in boundary; scheduling knobs + measurement hooks
+HEADERS = ("fspt.h", "fspt_multi.h", "fspt_tuning.h")  # the drop-in boundary; scheduling knobs + measurement hooks
 
 
 def header_functions(names=HEADERS):

@@ -1227,6 +1227,14 @@ def test_multi_two_physical_devices(medium_scene, camera):
              5, 2, _advance_seed(3, 5), want)
     assert np.array_equal(mp.readRadiance(), want)
     assert np.array_equal(mp.draw(1.0, 1.0, False, 3.0), O.draw(want, 1.0, 1.0, False, 3.0))
+    # the same read-out through RCCL inside the library (ncclCommInitAll over [0, 1]): send / recv of the packed tiles,
+    # then the sum-reduce of own-tiles-only frames north_star names - every mode the same frame
+    for mode, nbytes in (("rccl_gather", len(range(1, n_tiles, 2)) * 32 * 32 * 16), ("rccl_reduce", W * H * 16), ("peer", None)):
+        mp.set_exchange(mode)
+        assert mp.exchange()[0] == mp.EXCHANGES[mode] and mp.exchange()[1] > 0
+        assert np.array_equal(mp.readRadiance(), want), mode
+        if nbytes is not None:
+            assert mp.last_gather_bytes() == nbytes
     mp.close()
 
 
@@ -1281,6 +1289,92 @@ def test_multi_render_returns_before_the_devices_are_done(medium_scene, camera, 
     pt.render(2 * ticks)
     assert np.array_equal(got, pt.readRadiance())
     pt.close()
+
+
+def test_multi_rccl_exchange_on_one_device(medium_scene, camera):
+    """The library's RCCL exchanges on the 1-GPU pool: librccl is loaded on demand, ncclCommInitAll makes a one-rank
+    communicator, the reduce mode packs the device's tiles, builds its own-tiles-only frame and runs ncclReduce(SUM) on it
+    (one rank: the sum is the frame itself), the gather mode has nothing to send; both give the oracle's frame.  Two
+    physical devices: test_multi_two_physical_devices.  A device listed twice cannot have an RCCL communicator."""
+    from fspt_amd import MultiPathTracer
+    W, H = 200, 136
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 5,
+             0, 3, 9, want)
+    mp = MultiPathTracer(medium_scene, W, H, [0], num_bounces=5)
+    mp.set_camera(camera["P"], camera["I"], camera["fov_scale"], camera["env_theta"], camera["focal_depth"], camera["aperture"])
+    assert mp.exchange() [0] == 0
+    mp.seed(9)
+    mp.render(2)
+    mp.set_exchange("rccl_reduce")
+    mode, version = mp.exchange()
+    assert mode == 2 and version >= 20000, (mode, version)  # NCCL-style version code of the loaded RCCL
+    part = mp.readRadiance()
+    assert part[..., 3].min() == 1.0
+    mp.render(1)                       # the accumulation goes on behind a read-out that replaced the accumulator's contents
+    assert np.array_equal(mp.readRadiance(), want)
+    mp.set_exchange("rccl_gather")
+    assert np.array_equal(mp.readRadiance(), want) and mp.last_gather_bytes() == 0
+    assert np.array_equal(mp.draw(1.0, 1.0, False, 3.0), O.draw(want, 1.0, 1.0, False, 3.0))
+    mp.close()
+    mp2 = MultiPathTracer(medium_scene, W, H, [0, 0], num_bounces=5)
+    with pytest.raises(L.FsptError):
+        mp2.set_exchange("rccl_reduce")
+    mp2.close()
+
+
+def test_close_executes_recorded_ticks_into_a_bound_accumulator(small_scene, camera):
+    """tick() only RECORDS (deferred execution, include/fspt.h) and fspt_target_destroy drops what is recorded -
+    it never writes to a caller-owned buffer, which may be gone.  PathTracer.close() therefore executes the recorded
+    ticks first (it still holds the bound tensor): bind, tick x 3, close, read the tensor - all three ticks are in it."""
+    import torch
+    W, H = 96, 64
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
+             0, 3, 31, want)
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    pt = make_pt(small_scene, W, H, camera, 4)
+    pt.bind_accumulator(acc.data_ptr(), keep=acc)
+    pt.seed(31)
+    for _ in range(3):
+        pt.tick()
+    pt.close()
+    torch.cuda.synchronize()
+    assert np.array_equal(acc.cpu().numpy(), want)
+
+
+def test_pack_and_unpack_tiles_through_the_c_abi(small_scene, camera):
+    """fspt_target_pack_tiles / fspt_target_unpack_tiles (include/fspt_multi.h): the two ends of a one-process-per-GPU
+    read-out - what fspt_amd.distributed.TileGather runs on a GPU.  Three shards rendered by three targets into bound
+    torch tensors on a frame with ragged tiles (100x70: the last tile column is 4 pixels wide, the last row 6 high);
+    shards 1 and 2 packed (RGBA and RGB), their pieces unpacked into shard 0's accumulator: the oracle's frame."""
+    import torch
+    from fspt_amd import distributed as D
+    W, H, n = 100, 70, 3
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
+             0, 2, 23, want)
+    sc = Scene(small_scene)
+    for ch in (4, 3):
+        pts, accs = [], []
+        for r in range(n):
+            acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+            pt = make_pt(sc, W, H, camera, 4)
+            pt.set_shard(r, n, D.TILE)
+            pt.bind_accumulator(acc.data_ptr(), keep=acc)
+            pt.seed(23)
+            pt.render(2)
+            pts.append(pt); accs.append(acc)
+        slots = [pts[0].shard_slots(r, n) for r in range(n)]
+        assert slots == [len(range(r, 4 * 3, n)) * 32 * 32 for r in range(n)]  # 4 x 3 tiles of 32 x 32, holes included
+        g = [D.TileGather(r, n, W, H, accs[r].device, channels=ch, tracer=pts[r]) for r in range(n)]
+        for r in (1, 2):
+            g[0].recv[r].copy_(g[r].pack(accs[r]))
+        torch.cuda.synchronize()
+        got = g[0].unpack(accs[0]).cpu().numpy()
+        assert np.array_equal(got, want), ch
+        for pt in pts:
+            pt.close()
 
 
 def test_bound_torch_accumulator_and_tile_gather_on_gpu(small_scene, camera):
