@@ -587,7 +587,10 @@ int fspt_target_set_shard(fspt_target *t, uint32_t shard, uint32_t n_shards, uin
   FLUSH_OR_RETURN(t);
   if (n_shards == 0 || shard >= n_shards) { fspt_set_error("shard %u of %u invalid", shard, n_shards); return FSPT_E_INVALID; }
   if (tile == 0 || tile % 8 != 0 || tile > 256) { fspt_set_error("tile %u must be a multiple of 8 in [8,256]", tile); return FSPT_E_INVALID; }
-  if (t->shard != shard || t->n_shards != n_shards || t->tile != tile) prim_reset(t);
+  if (t->shard != shard || t->n_shards != n_shards || t->tile != tile) {
+    prim_reset(t);
+    if (t->stream_fallback) { HIP_TRY(hipSetDevice(t->scene->device)); wf_release(t->wf); t->stream_fallback = false; }
+  }
   t->shard = shard; t->n_shards = n_shards; t->tile = tile;
   return FSPT_OK;
 }
@@ -666,8 +669,17 @@ static int render_ticks(fspt_target *t, const fspt_camera_params *cam, uint32_t 
   t->ev_used = 0; t->ev_overflow = false;
   if (t->pipeline == 1) {
     HIP_TRY(hipEventRecord(t->ev0, t->stream));
-    int rc = t->sched == 1 ? render_stream(t, cam, first_tick, n_ticks, rbc, rbt, false)
-                           : render_wavefront(t, cam, first_tick, n_ticks, rbc, rbt, false);
+    int rc;
+    if (t->sched == 1 || t->stream_fallback) {
+      rc = render_stream(t, cam, first_tick, n_ticks, rbc, rbt, false);
+    } else {
+      rc = render_wavefront(t, cam, first_tick, n_ticks, rbc, rbt, false);
+      if (rc == FSPT_E_NOMEM) {
+        // fewer than FSPT_MIN_BATCH ticks of path state fit (nothing has been launched yet): the bounded pool instead
+        t->stream_fallback = true;
+        rc = render_stream(t, cam, first_tick, n_ticks, rbc, rbt, false);
+      }
+    }
     if (rc) return rc;
     HIP_TRY(hipEventRecord(t->ev1, t->stream));
     t->timed = true; t->last_launches = n_ticks;
@@ -890,13 +902,14 @@ int fspt_target_set_pipeline(fspt_target *t, int pipeline, uint32_t batch_ticks)
     return FSPT_E_INVALID;
   }
   const int sched = pipeline == 2 ? 1 : 0;
-  if (pipeline != 0 && sched != t->sched) {
+  if (pipeline != 0 && (sched != t->sched || t->stream_fallback)) {
     // the two schedulers size the path state differently: give it back (the next render allocates what it needs)
     HIP_TRY(hipSetDevice(t->scene->device));
     wf_release(t->wf);
   }
   t->pipeline = pipeline == 0 ? 0 : 1;
   if (pipeline != 0) t->sched = sched;
+  t->stream_fallback = false;
   if (batch_ticks) t->batch_ticks = batch_ticks;
   return FSPT_OK;
 }
@@ -973,6 +986,7 @@ int fspt_target_live_paths(fspt_target *t, double *frac, uint32_t n_rounds) {
 int fspt_target_set_memory_limit(fspt_target *t, uint64_t bytes) {
   if (!t) { fspt_set_error("fspt_target_set_memory_limit: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
+  if (t->stream_fallback) { HIP_TRY(hipSetDevice(t->scene->device)); wf_release(t->wf); t->stream_fallback = false; } // what fits is decided afresh
   t->mem_limit = bytes;
   return FSPT_OK;
 }
@@ -995,7 +1009,13 @@ int fspt_target_prepare(fspt_target *t) {
   fill_trace_params(t, tp);
   const uint64_t work_total = (uint64_t)tp.n_owned_tiles * tp.tile * tp.tile;
   if (work_total == 0) return FSPT_OK;
-  if (t->sched == 1) {
+  if (t->sched == 0 && !t->stream_fallback) {
+    uint32_t batch;
+    const int rc = wf_plan_and_ensure(t, work_total, 0, batch);
+    if (rc != FSPT_E_NOMEM) return rc;
+    t->stream_fallback = true; // (see render_ticks)
+  }
+  {
     // the pool of the configured steady state: runs of batch_ticks ticks (at most WF_MAX_BATCH per run)
     const uint32_t units_total = (uint32_t)(work_total >> 6);
     const uint32_t nbt = t->batch_ticks < (uint32_t)fspt::WF_MAX_BATCH ? (t->batch_ticks ? t->batch_ticks : 1u) : (uint32_t)fspt::WF_MAX_BATCH;
@@ -1004,8 +1024,6 @@ int fspt_target_prepare(fspt_target *t) {
     if (rc == FSPT_OK) rc = st_ensure(t, t->wf, pl.cap, pl.ring_slots, t->mem_limit ? t->mem_limit : ~0ull);
     return rc;
   }
-  uint32_t batch;
-  return wf_plan_and_ensure(t, work_total, 0, batch);
 }
 
 int fspt_last_stage_ms(fspt_target *t, float ms[5], uint32_t launches[5]) {

@@ -66,6 +66,9 @@ static const uint32_t ST_DEFAULT_SUSP_BUDGET = FSPT_SUSP_BUDGET;
 // Measured (profiles/r05/ab_fixed_costs_*.log): 4 blocks x 512 threads are a straggler - a few thousand records, one
 // memory-side atomic each - the logic launch waits for: logic 0.124 -> 0.152 ms per tick on C2, 0.125 -> 0.178 on the 1 M-triangle scene
 #endif
+#ifndef FSPT_MIN_BATCH
+#define FSPT_MIN_BATCH 8 // ticks a batch of the batch scheduler holds at least; a frame whose path state allows fewer runs on the stream scheduler
+#endif
 #ifndef FSPT_RESOLVE_CLEARS
 #define FSPT_RESOLVE_CLEARS 1 // the batch's resolve launch hands the live-path counts to the host and clears counters + pool heads (0: fill / copy commands)
 #endif
@@ -92,6 +95,7 @@ struct fspt_target {
   uint32_t vw = 0, vh = 0;    // viewport (gl.viewport of the two draws); default = the whole target
   int pipeline = 1;           // 0 = megakernel, 1 = wavefront
   int sched = 0;              // wavefront pipeline: 0 = batch scheduler (all ticks x all pixels per batch), 1 = stream (fixed pool)
+  bool stream_fallback = false; // sched 0, but the path state of FSPT_MIN_BATCH ticks did not fit: calls run on the stream scheduler (cleared by every setter that changes what fits)
   uint32_t pool_paths = 0;    // stream: paths per state set and lane (0 = default)
   int stream_drain = -1;      // stream: iterations after the last generating one before the tail kernel takes over (-1 = default)
   uint32_t stream_iter_cap = 0; // stream, test hook: at most this many iterations per run (the finishing launch does the rest)

@@ -48,21 +48,9 @@ FM_DEV float cos_poly(float r) {
   float q = fma_(-0.5f, z, 1.0f);
   return fma_(p * z, z, q);
 }
-#ifndef FSPT_EXP_SIN_F32
-#define FSPT_EXP_SIN_F32 0 // TIMING EXPERIMENT ONLY (not the contract, results differ from the oracle): binary32 four-constant reduction
-#endif
+// (Round 5 timed a binary32 four-constant reduction for |x| <= 2e5 in place of the binary64 one: primary launch 0.1274 vs
+// 0.1275-0.130 ms per tick, nothing - the reduction is not what the shading waits for; profiles/r05/ab_carry_sin_c2_20.log.)
 FM_DEV float reduce_pio2(float x, int &quadrant) {
-#if FSPT_EXP_SIN_F32
-  if (__builtin_expect(__ballot(!(abs_(x) <= 2.0e5f)) == 0ull, 1)) {
-    const float kf = __builtin_rintf(x * 0.6366197723675814f);
-    float r = fma_(-kf, 1.5625f, x);
-    r = fma_(-kf, 0.0081787109375f, r);
-    r = fma_(-kf, 0.00011730194091796875f, r);
-    r = fma_(-kf, 3.1391647326017846e-07f, r);
-    quadrant = (int)kf & 3;
-    return r;
-  }
-#endif
   const double TWO_OVER_PI = 0.63661977236758134308;
   const double PIO2_HI = 1.57079632673412561417e+00;
   const double PIO2_LO = 6.07710050650619224932e-11;

@@ -131,6 +131,12 @@ static uint32_t wf_plan(const fspt_target *t, uint64_t work_total, uint32_t n_ti
 // memory limit is lower) the batch is halved until it fits (results do not depend on the batch size).
 int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ticks, uint32_t &batch) {
   if (n_ticks > t->ticks_seen) t->ticks_seen = n_ticks;
+  // A batch that does not fit the device (or the target's memory limit) is halved - but not below FSPT_MIN_BATCH ticks
+  // (or what the call wants, if that is less): every batch pays the same dozen launches at their latency floors, and a
+  // frame that cannot hold 8 ticks of path state is what the stream scheduler's FIXED pool is for.  FSPT_E_NOMEM then
+  // tells the caller (render_ticks, fspt_target_prepare) to take that one; the configured batch size is left alone.
+  const uint32_t configured = t->batch_ticks, want0 = wf_plan(t, work_total, n_ticks);
+  const uint32_t floor_ticks = want0 < (uint32_t)FSPT_MIN_BATCH ? want0 : (uint32_t)FSPT_MIN_BATCH;
   while (true) {
     batch = wf_plan(t, work_total, n_ticks);
     // the trace kernel carries a path's state index in 29 bits (fspt_kernels.hip k_wf_trace: item kind and the
@@ -148,7 +154,7 @@ int wf_plan_and_ensure(fspt_target *t, uint64_t work_total, uint32_t n_ticks, ui
     }
     int rc = wf_ensure(t, t->wf, (uint32_t)(batch * work_total), budget);
     if (rc != FSPT_E_NOMEM) return rc;
-    if (batch <= 1) return rc; // one tick does not fit: give up (message set by wf_ensure)
+    if (batch / 2 < floor_ticks || batch <= 1) { t->batch_ticks = configured; return rc; } // (message set by wf_ensure)
     t->batch_ticks = batch / 2;
   }
 }

@@ -153,7 +153,9 @@ int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t first_
     bool susp_run = susp_on;
     {
       const uint32_t units = units_total;
-      if ((rc = st_plan(t, units, nbt, nb, pl))) return rc;
+      // a memory limit too tight for a pool of two units of this run's length: shorter runs (a unit is 64 pixels x the run's ticks)
+      while ((rc = st_plan(t, units, nbt, nb, pl)) == FSPT_E_NOMEM && nbt > 1) nbt /= 2;
+      if (rc) return rc;
       const uint64_t budget = t->mem_limit ? t->mem_limit : ~0ull;
       if ((rc = st_ensure(t, ln, pl.cap, pl.ring_slots, budget))) return rc;
       for (int k = 0; k < 2; ++k) {

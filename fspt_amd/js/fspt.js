@@ -340,6 +340,8 @@ class PathTracer {
     return p;
   }
   clear() { addon.clear(this._target); this.pingpong = 0; }                                  // main.js:826-836
+  /** wait until every enqueued (and recorded) tick is on the accumulator (gl.finish) */
+  sync() { addon.sync(this._target); }
   readRadiance(out) {
     out = out || new Float32Array(this.resolution[0] * this.resolution[1] * 4);
     if (out.length !== this.resolution[0] * this.resolution[1] * 4) throw new RangeError('readRadiance: need W*H*4 floats');

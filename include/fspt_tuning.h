@@ -71,9 +71,12 @@ int fspt_target_set_primary_form(fspt_target *target, int form);
 int fspt_target_get_primary_form(fspt_target *target, uint32_t batch_ticks, int *form, double ms_per_sample[2]);
 /* fspt_trace executes at once (0) instead of being recorded and batched (1, default; fspt.h: fspt_camera). */
 int fspt_target_set_deferred(fspt_target *target, int enable);
-/* Cap on the target's path-state bytes (0 = none): a batch that does not fit the cap - or the free device memory - is
- * halved until it does; the stream scheduler shrinks its pool; suspension records that do not fit are not used.
- * FSPT_E_NOMEM when even one tick (two units of the pool) does not fit. */
+/* Cap on the target's path-state bytes (0 = none): state sets, ray results, finished samples and suspension records
+ * together.  A batch that does not fit the cap - or the free device memory - is halved, down to 8 ticks (or the call's
+ * own tick count, if that is less); a frame that cannot hold that much runs its calls on the STREAM scheduler instead,
+ * whose path state is a fixed pool sized to the cap (its runs shortened until two units of the pool fit); suspension
+ * records that would take more than a quarter of the cap are not used.  Results never depend on any of it.
+ * FSPT_E_NOMEM when not even a pool of two one-tick units (128 paths) fits. */
 int fspt_target_set_memory_limit(fspt_target *target, uint64_t bytes);
 /* Path-state bytes currently allocated by this target (state sets, ray results, finished samples, suspension
  * records) and the batch size in use (after any halving). */

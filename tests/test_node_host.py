@@ -385,3 +385,63 @@ def test_js_cli_frame_sequence(tmp_path):
         assert d.max() <= 2 and (d > 0).mean() < 0.02, (n, d.max(), (d > 0).mean())
         imgs.append(got)
     assert (imgs[0] != imgs[1]).mean() > 0.01  # the animated prop really moved
+
+
+def _node_bench(scene_json, *extra, timeout=600):
+    r = subprocess.run(["node", os.path.join(ROOT, "fspt_amd", "js", "bench.js"), "--scene", scene_json, "--focal-depth", "2",
+                        "--aperture", "0.02", *[str(x) for x in extra]], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    return json.loads(lines[0])
+
+
+def test_write_bench_scene_is_the_bench_scene(tmp_path):
+    """tools/write_bench_scene.py puts bench.py's synthetic workload on disk the way the reference stores scenes (scene JSON,
+    OBJ files, an RGBE sky image): read back by the Python scene-file loader it gives bunny_scene()'s arrays, byte for byte."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import write_bench_scene as WB
+    from fspt_amd import scene_file as SFp
+    path = WB.write(str(tmp_path), mesh_n=8, env_size=(64, 32))
+    loaded = SFp.load_scene_file(path)
+    arrays = loaded[0] if isinstance(loaded, tuple) else loaded
+    want = S.bunny_scene(n=8, env_size=(64, 32))
+    for k in ("bvh", "tri", "mat", "norm", "uv", "bins", "env", "atlas"):
+        assert np.array_equal(np.asarray(getattr(arrays, k)).view(np.uint8), np.asarray(getattr(want, k)).view(np.uint8)), k
+
+
+@pytest.mark.gpu
+def test_js_bench_matches_oracle_and_the_python_host_rate(tmp_path):
+    """fspt_amd/js/bench.js: the reference's host language drives the timed workload - scene off disk
+    through loadSceneFile / buildScene, ticks through PathTracer.render() over the N-API addon.  (i) a small frame of it
+    equals the oracle bit for bit (all warm-up + timed ticks, bench.py's seed and camera); (ii) on bench.py's headline
+    workload (69 316 triangles, 1920x1080, depth 8, 20-step regions) its Msamples/s is within 3 % of the Python host's on
+    the same box, measured back to back - the host language costs nothing, the work is in the kernels."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import write_bench_scene as WB
+    # (i) parity on a small workload
+    small = WB.write(str(tmp_path / "small"), mesh_n=12, env_size=(256, 128))
+    W, H, nb = 160, 96, 8
+    rad = str(tmp_path / "frame.f32")
+    d = _node_bench(small, "--width", W, "--height", H, "--bounces", nb, "--steps", 3, "--warmup", 2, "--reps", 2, "--out-radiance", rad)
+    assert d["unit"] == "Msamples/s" and d["steps"] == 3 and d["config"]["ticks_rendered"] == 8 and d["value"] > 0
+    got = np.fromfile(rad, np.float32).reshape(H, W, 4)
+    arrays = S.bunny_scene(n=12, env_size=(256, 128))
+    cam = S.BUNNY_CAMERA
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(arrays, W, H, cam["P"], cam["I"], cam["fov_scale"], S.lens_features(cam["focal_depth"], cam["aperture"]), cam["env_theta"],
+             nb, 0, 8, 1, want)
+    assert np.array_equal(got, want)
+    # (ii) the headline workload, Node host then Python host, twice (best of each: the box's clocks settle)
+    full = WB.write(str(tmp_path / "full"), mesh_n=76)
+    js, py = [], []
+    for _ in range(2):
+        js.append(_node_bench(full, "--steps", 20, "--warmup", 5, "--reps", 5)["value"])
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                            "--no-extra-configs", "--no-l1-microbench", "--no-parity-check"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        py.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["value"])
+    assert max(js) >= 0.97 * max(py), (js, py)
+    print(f"Node host {js} vs Python host {py} Msamples/s")

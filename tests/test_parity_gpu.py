@@ -1698,13 +1698,14 @@ def test_fuzz_random_scenes_bitwise(seed):
 
 
 def test_batch_is_halved_when_path_state_does_not_fit(small_scene, camera):
-    """Path state over the target's memory limit is handled exactly like running out of device memory: every lane
-    is released and the batch halved until it fits (two lanes fall back to one); the result does not depend on the
-    batch size.  Also: path state is sized for the calls actually made (a one-tick call holds one tick of state)."""
+    """Path state over the target's memory limit is handled exactly like running out of device memory: the batch is
+    halved until it fits - down to 8 ticks; a frame that cannot hold 8 ticks of path state runs on the stream scheduler's
+    fixed pool instead (sized to the limit), and the result never depends on any of it.  Also: path state is sized for the
+    calls actually made (a one-tick call holds one tick of state)."""
     W, H = 96, 64
     want = np.zeros((H, W, 4), np.float32)
     O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4,
-             0, 9, 31, want)
+             0, 19, 31, want)
     work_total = 3 * 2 * 1024  # 32x32 tiles covering 96x64
     pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
     pt.set_trace_budget(0)  # (no suspension records: the path state is the slots alone)
@@ -1722,23 +1723,44 @@ def test_batch_is_halved_when_path_state_does_not_fit(small_scene, camera):
     with_records = pt.path_state_bytes()[0]
     assert work_total * slot < with_records <= work_total * slot + 2 * (work_total + 256) * (8 + 64 + 4) * 4
     pt.close()
+    # room for 10 ticks: 128 -> 64 -> 32 -> 16 -> 8 fit (the records too, or they are left out)
     pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
-    pt.set_memory_limit(3 * work_total * slot)  # room for 3 ticks: 128 -> 64 -> ... -> 2 fit (+ the records, or none)
+    pt.set_memory_limit(10 * work_total * slot)
     pt.prepare()
-    assert pt.path_state_bytes() == (2 * work_total * slot, 2)
+    assert pt.path_state_bytes()[1] == 8 and pt.path_state_bytes()[0] >= 8 * work_total * slot
     pt.seed(31)
-    pt.render(9)
+    pt.render(19)
     assert np.array_equal(pt.readRadiance(), want)
-    assert pt.last_stage_ms()["primary"][1] == 5  # 9 ticks in batches of 2
-    assert pt.path_state_bytes()[0] <= 3 * work_total * slot  # records included, or left out when they did not fit
+    assert pt.last_stage_ms()["primary"][1] == 3  # 19 ticks in batches of 8
+    assert pt.path_state_bytes()[0] <= 10 * work_total * slot  # records included
     pt.close()
-    # room for one tick only (and for no records at all: traversals are then simply not suspended)
+    # room for 3 ticks only: fewer than 8 - the stream scheduler's bounded pool runs the call (the configured batch size stays)
+    pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
+    pt.set_memory_limit(3 * work_total * slot)
+    pt.seed(31)
+    pt.render(19)
+    assert np.array_equal(pt.readRadiance(), want)
+    nbytes, batch = pt.path_state_bytes()
+    assert 0 < nbytes <= 3 * work_total * slot and batch == 128
+    assert pt.last_stage_ms()["primary"][1] > 3  # the stream scheduler's iterations, not batches
+    # ... a call of fewer ticks than 8 that DOES fit as one batch is a batch again once the limit allows it
+    pt.set_memory_limit(0)
+    pt.render(2)
+    pt.close()
+    # room for one tick only
     pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
     pt.set_memory_limit(work_total * slot + slot // 2)
     pt.seed(31)
-    pt.render(9)
+    pt.render(19)
     assert np.array_equal(pt.readRadiance(), want)
-    assert pt.path_state_bytes() == (work_total * slot, 1)
+    assert pt.path_state_bytes()[0] <= work_total * slot + slot // 2
+    pt.close()
+    # a one-tick call under the same limit fits as a batch of one (nothing wants 8 ticks)
+    pt = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
+    pt.set_trace_budget(0)
+    pt.set_memory_limit(work_total * slot + slot // 2)
+    pt.render(1)
+    assert pt.path_state_bytes() == (work_total * slot, 128) and pt.last_stage_ms()["primary"][1] == 1
     pt.close()
     pt2 = make_pt(small_scene, W, H, camera, 4, "wavefront", 128)
     pt2.set_memory_limit(10 * slot)
