@@ -955,7 +955,8 @@ int fspt_target_get_primary_form(fspt_target *t, uint32_t batch_ticks, int *form
 int fspt_target_set_node_form(fspt_target *t, int primary, int trace, int tail, int64_t trace_below) {
   if (!t) { fspt_set_error("fspt_target_set_node_form: NULL target"); return FSPT_E_INVALID; }
   const int v[3] = {primary, trace, tail};
-  for (int x : v) if (x < -1 || x > 1) { fspt_set_error("fspt_target_set_node_form: form %d (want -1, 0 or 1)", x); return FSPT_E_INVALID; }
+  for (int k = 0; k < 3; ++k)
+    if (v[k] < -1 || v[k] > (k == 2 ? 2 : 1)) { fspt_set_error("fspt_target_set_node_form: form %d (want -1, 0, 1; the tail also 2 = adaptive)", v[k]); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);
   for (int k = 0; k < 3; ++k) t->node_form[k] = v[k];
   if (trace_below >= 0) t->wide_trace_below = trace_below > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)trace_below;

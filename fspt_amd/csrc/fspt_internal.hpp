@@ -66,6 +66,9 @@ static const uint32_t ST_DEFAULT_SUSP_BUDGET = FSPT_SUSP_BUDGET;
 // Measured (profiles/r05/ab_fixed_costs_*.log): 4 blocks x 512 threads are a straggler - a few thousand records, one
 // memory-side atomic each - the logic launch waits for: logic 0.124 -> 0.152 ms per tick on C2, 0.125 -> 0.178 on the 1 M-triangle scene
 #endif
+#ifndef FSPT_BATCH_ON_TARGET_STREAM
+#define FSPT_BATCH_ON_TARGET_STREAM 1 // the batch scheduler's launches go to the target's stream (0: a stream of their own behind events, rounds 1-4)
+#endif
 #ifndef FSPT_MIN_BATCH
 #define FSPT_MIN_BATCH 8 // ticks a batch of the batch scheduler holds at least; a frame whose path state allows fewer runs on the stream scheduler
 #endif

@@ -283,19 +283,24 @@ FM_DEV void trace_rays(const DScene &S, int *stack, V3 o, bool hasA, V3 dA, V3 d
 // where it stands until its ray is finished (cur == REF_SENTINEL) or it has done `budget` loop iterations in this call;
 // the call returns when no lane has anything left to do within its budget.  `anyhit`: stop at the first hit (NEE
 // shadow rays, tracer.fs:502).  Same node sequence and arithmetic as trace_rays, whatever the slicing.
-template <bool COUNT, bool WIDE = false>
+// WIDE: 0 the 64-byte nodes, 1 the two-level nodes, 2 the caller says per call (`wide_now`, wave-uniform): the traversal
+// state - node reference, stack entries - means the same in both walks (the two arrays are indexed alike), so a ray can
+// change form between any two steps.
+template <bool COUNT, int WIDE = 0>
 FM_DEV void trace_slice(const DScene &S, int *stack, V3 o, V3 d, V3 inv /* 1 / d */, bool anyhit, int &cur, int &sp, float &t, int &hit,
-                        uint32_t budget, uint32_t &n /* loop iterations (memory round trips) this lane has used of the budget */, Counters &cnt) {
-  const float4 *__restrict__ nodes = WIDE ? S.quads : S.nodes;
+                        uint32_t budget, uint32_t &n /* loop iterations (memory round trips) this lane has used of the budget */, Counters &cnt,
+                        bool wide_now = false) {
+  const float4 *__restrict__ nodes = S.nodes;
+  const float4 *__restrict__ quads = S.quads;
   const float *__restrict__ leaves = S.leaves;
   const uint32_t leaf_size = S.leaf_size;
   while (cur != REF_SENTINEL && n < budget) {
     while (cur >= 0 && n < budget) {
       if (COUNT) cnt.steps++;
       ++n;
-      if constexpr (WIDE) {
+      if (WIDE == 1 || (WIDE == 2 && wide_now)) {
         float4 a0, a1, a2, b0, b1, b2; int4 ar; int2 br;
-        quad_load(nodes + (size_t)cur * QUAD_F4, a0, a1, a2, ar, b0, b1, b2, br);
+        quad_load(quads + (size_t)cur * QUAD_F4, a0, a1, a2, ar, b0, b1, b2, br);
         quad_step<COUNT>(a0, a1, a2, ar, b0, b1, b2, br, o, inv, t, stack, sp, cur, cnt.steps);
         continue;
       }
@@ -1631,7 +1636,7 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
         }
         if (__ballot(have) == 0ull) { if (next >= w_hi) break; else continue; }
         uint32_t used = 0;
-        trace_slice<COUNT, WIDE>(S, stack, o, d, inv, false, cur, sp, t, hit, WF_PRIMARY_SLICE, used, cnt);
+        trace_slice<COUNT, WIDE ? 1 : 0>(S, stack, o, d, inv, false, cur, sp, t, hit, WF_PRIMARY_SLICE, used, cnt);
       }
     }
     // advance_path: a hit is shaded (and the path lives on) unless the bounce budget is already used up
@@ -1835,7 +1840,13 @@ FM_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src, WAVE), __shfl(v.y, s
 // sample into the pixel's accumulator value in its registers, in tick order (tracer.fs:515-517 is order-dependent) -
 // nothing of such a unit goes through the fin ring, and the run's last resolve ends where this launch began
 // (WfStreamCtl::hist of the last plan).
-template <bool COUNT, bool ANYHIT, bool GEN, bool WIDE = false>
+// WIDE (node form of the traversal, trace_slice): 0 the 64-byte nodes, 1 the two-level nodes, 2 ADAPTIVE - the 64-byte
+// nodes while the wave can still refill its pairs from the list (the CU's vector-memory front end is what its resident waves
+// share: fewer requests per step win), the two-level nodes once the list is used up: what remains of the launch is the
+// dependent chains of the paths still alive, walked by a few lanes on a mostly idle chip - there a step costs a cache-miss
+// latency, and two levels per round trip shorten the chain (profiles/r05/launch_list_*.txt: the tail launch is 0.8 ms of a
+// 9.9 ms batch on the 70 k-triangle scene, 2.4 of 13.3 ms on the 1 M-triangle one, most of it this end phase).
+template <bool COUNT, bool ANYHIT, bool GEN, int WIDE = 0>
 __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const WfP p) {
   extern __shared__ int lds_stack[];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -1974,7 +1985,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
     if (r_state != RAY_GOING) r_cur = REF_SENTINEL;
     uint32_t used = 0;
     trace_slice<COUNT, WIDE>(S, stack, o, d, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), ANYHIT && !is_main, r_cur, r_sp, r_t, r_hit, WF_TAIL_SLICE,
-                             used, cnt);
+                             used, cnt, exhausted && pool_next == pool_end && gen_done);
     if (r_state == RAY_GOING && r_cur == REF_SENTINEL) r_state = RAY_DONE;
     // a pair is ready when its extension ray is done and its shadow ray is done or was never cast
     const int st_other = __shfl(r_state, lane | 1, WAVE);
@@ -2349,10 +2360,11 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
         hipLaunchKernelGGL((k_wf_tail<C, A, false, Wd>), dim3(grid), dim3(BLOCK_THREADS), lds, stream, p);   \
       }                                                                                                      \
     } while (0)
-    if (count == 1) FSPT_LAUNCH_TAIL(true, false, false);
-    else if (count == 2) FSPT_LAUNCH_TAIL(true, true, false);
-    else if (wide) FSPT_LAUNCH_TAIL(false, true, true);
-    else FSPT_LAUNCH_TAIL(false, true, false);
+    if (count == 1) FSPT_LAUNCH_TAIL(true, false, 0);
+    else if (count == 2) FSPT_LAUNCH_TAIL(true, true, 0);
+    else if (wide && p.tail_adaptive) FSPT_LAUNCH_TAIL(false, true, 2);
+    else if (wide) FSPT_LAUNCH_TAIL(false, true, 1);
+    else FSPT_LAUNCH_TAIL(false, true, 0);
 #undef FSPT_LAUNCH_TAIL
   } else if (kernel == WF_K_LOGIC || kernel == WF_K_PRIMARY) {
     // resident blocks per CU at WF_LOGIC_WAVES waves per SIMD (4 SIMDs): 2 blocks of 512 threads at 4 waves; twice that many in flight

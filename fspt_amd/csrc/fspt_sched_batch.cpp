@@ -69,6 +69,7 @@ size_t wf_slot_bytes() {
 void wf_release(fspt_target::WfLane &ln) {
   if (ln.stream) hipStreamSynchronize(ln.stream);
   if (ln.stream_b) hipStreamSynchronize(ln.stream_b);
+  if (FSPT_BATCH_ON_TARGET_STREAM) (void)hipDeviceSynchronize(); // (the batch scheduler's launches are on the target's stream)
   for (void *&m : ln.mem) { if (m) { hipFree(m); m = nullptr; } }
   ln.slots = 0;
   ln.st_cap = ln.st_fin = 0;
@@ -202,6 +203,10 @@ uint32_t prim_choose(const fspt_target *t, uint32_t ticks) {
 }
 
 int ev_begin(fspt_target *t, int kind, hipStream_t stream) {
+  // FSPT_STAGE_EVENTS=0 (environment, read once): no event pair around the launches - fspt_last_stage_ms then reports
+  // zeros; a measurement hook for what the events themselves cost (profiles/r05/ab_stream_events.log)
+  static const bool events_on = !(getenv("FSPT_STAGE_EVENTS") && getenv("FSPT_STAGE_EVENTS")[0] == '0');
+  if (!events_on) return -1;
   if (t->ev_used >= EV_PAIRS) { t->ev_overflow = true; return -1; }
   if (t->ev_pool.size() < (size_t)(t->ev_used + 1) * 2) {
     hipEvent_t a, b;
@@ -255,7 +260,7 @@ uint32_t wide_bit(const fspt_target *t, int kind, double paths) {
   const int slot = kind == fspt::WF_K_PRIMARY ? 0 : kind == fspt::WF_K_TRACE ? 1 : kind == fspt::WF_K_TAIL ? 2 : -1;
   if (slot < 0) return 0u;
   bool on;
-  if (t->node_form[slot] >= 0) on = t->node_form[slot] != 0;
+  if (t->node_form[slot] >= 0) on = t->node_form[slot] != 0; // (tail: 1 always two-level, 2 adaptive - WfP::tail_adaptive)
   else if (slot == 0) on = FSPT_WIDE_PRIMARY != 0;
   else if (slot == 2) on = FSPT_WIDE_TAIL != 0;
   else on = paths >= 0.0 && paths < (double)t->wide_trace_below;
@@ -290,11 +295,16 @@ int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint32_t fir
   const bool gen = !rays_from_buffers;
   const uint32_t nb = cam->num_bounces;
 
-  // everything already queued on the target's stream (clear, ray upload, earlier renders) comes first
-  HIP_TRY(hipEventRecord(t->ev_start, t->stream));
+  // The batch scheduler runs on the target's own stream: everything already queued there (clear, ray upload, earlier
+  // renders) comes first by stream order.  (Rounds 1-4 ran it on a stream of its own behind an event of the target's
+  // stream and made the target's stream wait for an event behind the last resolve: two hops between hardware queues per
+  // call - ~0.12 ms of launch latency in front of every 20-tick region, profiles/r05/launch_list_c2.txt.)
   fspt_target::WfLane &ln = t->wf;
-  hipStream_t st = ln.stream;
-  HIP_TRY(hipStreamWaitEvent(st, t->ev_start, 0));
+  hipStream_t st = FSPT_BATCH_ON_TARGET_STREAM ? t->stream : ln.stream;
+  if (!FSPT_BATCH_ON_TARGET_STREAM) {
+    HIP_TRY(hipEventRecord(t->ev_start, t->stream));
+    HIP_TRY(hipStreamWaitEvent(st, t->ev_start, 0));
+  }
 
   uint32_t done = 0;
   while (done < n_ticks) {
@@ -345,6 +355,7 @@ int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint32_t fir
     else if (t->count == 0) form = prim_choose(t, nbt); // (the counting variants are not what is timed: form 1 unless forced)
     p.primary_r = form;
     p.wide = wide_bit(t, fspt::WF_K_PRIMARY, -1.0) | wide_bit(t, fspt::WF_K_TAIL, -1.0);
+    p.tail_adaptive = (t->node_form[2] < 0 ? FSPT_WIDE_TAIL : t->node_form[2]) == 2 ? 1u : 0u;
     const bool time_primary = t->count == 0 && !t->prim_pending;
     bool prev_trace_suspends = false; // (no carry launch behind a trace launch that cannot have suspended anything)
     for (uint32_t r = 1; r <= last && r <= tail; ++r) {
@@ -401,8 +412,10 @@ int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint32_t fir
     ln.zeroed = true;
     done += nbt;
   }
-  HIP_TRY(hipEventRecord(ln.resolved, st));
-  HIP_TRY(hipStreamWaitEvent(t->stream, ln.resolved, 0));
+  if (!FSPT_BATCH_ON_TARGET_STREAM) {
+    HIP_TRY(hipEventRecord(ln.resolved, st));
+    HIP_TRY(hipStreamWaitEvent(t->stream, ln.resolved, 0));
+  }
   return FSPT_OK;
 }
 

@@ -162,7 +162,7 @@ class PathTracer:
 
     def set_node_form(self, primary=-1, trace=-1, tail=-1, trace_below=-1):
         """Node form per kernel class: -1 the library's choice, 0 the 64-byte nodes, 1 the two-level nodes (two traversal
-        steps per memory round trip; bit-identical results).  trace_below: the library's choice for a trace launch is
+        steps per memory round trip; bit-identical results); tail also 2 = adaptive (two-level once a wave's list is used up).  trace_below: the library's choice for a trace launch is
         two-level when it expects fewer paths than this (include/fspt_tuning.h)."""
         L.check(L.lib().fspt_target_set_node_form(self._t, int(primary), int(trace), int(tail), int(trace_below)))
 

@@ -49,6 +49,8 @@ int fspt_target_set_tail(fspt_target *target, int round);
  * the same order.  The first is faster where the vector-memory request rate binds (large trace launches on a
  * cache-resident scene), the second where a launch is a bundle of dependent chains (tail kernel, small trace launches,
  * scenes beyond the L2).  primary / trace / tail: -1 the library's choice, 0 the 64-byte nodes, 1 the two-level nodes;
+ * tail = 2: ADAPTIVE - the 64-byte nodes while a wave can refill its lanes from the list of live paths, the two-level
+ * nodes from then on (a traversal changes form in mid-walk: node references and stack entries mean the same in both);
  * trace_below >= 0: the library's choice for a trace launch is "two-level when it expects fewer paths than this" (from
  * the previous batch's live-path counts); < 0 keeps the current threshold.  Ignored on a scene without two-level nodes
  * and by the counting kernel variants. */

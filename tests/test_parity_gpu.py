@@ -125,12 +125,13 @@ def test_two_level_nodes_intersect_bitwise(which, small_scene, medium_scene):
     assert np.array_equal(t1, t) and np.array_equal(idx1, idx) and np.array_equal(steps1, steps)
 
 
-@pytest.mark.parametrize("forms", [(1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1), (-1, -1, -1)])
+@pytest.mark.parametrize("forms", [(1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 2), (-1, -1, -1)])
 @pytest.mark.parametrize("pipeline,tail,prim", [("wavefront", 0, 1), ("wavefront", 2, 2), ("wavefront", -1, 0), ("stream", 0, 1)])
 def test_two_level_nodes_render_bitwise(medium_scene, camera, forms, pipeline, tail, prim):
     """fspt_target_set_node_form: the primary launch (both forms of its traversal phase), the trace launches (with
     suspended traversals: a record written by one node form may be resumed by the other) and the tail kernel on the
-    two-level nodes, each alone and together, on both schedulers: the oracle's radiance, bit for bit."""
+    two-level nodes (tail form 2: adaptive - a ray changes node form in mid-traversal when its wave's list runs dry),
+    each alone and together, on both schedulers: the oracle's radiance, bit for bit."""
     W, H, nb = 120, 72, 6
     want = np.zeros((H, W, 4), np.float32)
     O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], nb, 0, 7, 21, want)
@@ -866,7 +867,8 @@ def test_stream_refraction_keeps_units_open(pool):
 
 def test_stream_pool_follows_the_memory_limit(medium_scene, camera):
     """fspt_target_set_memory_limit caps the stream scheduler's pool + ring as it caps the batch scheduler's path state;
-    the frame does not change; a limit too small for two units is refused with FSPT_E_NOMEM."""
+    the frame does not change; a limit too small for two units of the run shortens the runs, one too small for two one-tick
+    units is refused with FSPT_E_NOMEM."""
     W, H, ticks = 320, 200, 40
     want = np.zeros((H, W, 4), np.float32)
     O.render(medium_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"],
@@ -885,8 +887,18 @@ def test_stream_pool_follows_the_memory_limit(medium_scene, camera):
     nbytes, _ = pt.path_state_bytes()
     assert 0 < nbytes <= 16 << 20 and nbytes < free_bytes
     pt.close()
+    # a limit too small for two units of a 40-tick run (2 x 64 pixels x 40 ticks of path state): the runs get shorter
+    # (round 5; rounds 3-4 refused) ...
     pt = make_pt(medium_scene, W, H, camera, 8, "stream")
     pt.set_memory_limit(100 << 10)
+    pt.seed(3)
+    pt.render(ticks)
+    assert np.array_equal(pt.readRadiance(), want)
+    assert 0 < pt.path_state_bytes()[0] <= 100 << 10
+    pt.close()
+    # ... and one that cannot hold two ONE-tick units (128 paths) is refused
+    pt = make_pt(medium_scene, W, H, camera, 8, "stream")
+    pt.set_memory_limit(8 << 10)
     pt.seed(3)
     with pytest.raises(L.FsptError) as e:
         pt.render(ticks)
@@ -1685,7 +1697,7 @@ def test_fuzz_random_scenes_bitwise(seed):
         pt.eye, pt.dir, pt.fovScale, pt.envTheta, pt.lensFeatures = cam["P"], cam["I"], cam["fov_scale"], cam["env_theta"], cam["lens"]
         pt.set_pipeline(pipeline, 2)
         pt.set_trace_budget(1 + seed % 5)
-        pt.set_node_form((seed >> 0) & 1, (seed >> 1) & 1, (seed >> 2) & 1)  # every mix of node forms, by seed
+        pt.set_node_form((seed >> 0) & 1, (seed >> 1) & 1, (seed >> 2) % 3)  # every mix of node forms, by seed (tail: 0, 1, 2 = adaptive)
         if pipeline == "wavefront":
             pt.set_primary_form(2 - seed % 2)
         if pool:
