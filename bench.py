@@ -155,6 +155,9 @@ def parse_args(argv=None):
     ap.add_argument("--tex-interleave-budget", type=int, default=None,
                     help="bytes of interleaved material textures the scene may use (A/B: 0 = single-layer images only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-events", default="last", choices=["last", "all"],
+                    help="which timed regions carry the per-launch HIP event pairs behind the per-kernel times (they cost ~1.3 %% of a "
+                         "20-step region): only the last one (default; the reported per-kernel times and the roofline are that region's), or all")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="only the headline workload (default: after it, BASELINE configs[2] and [4] at N = 1 / configs[3] at N > 1 as extra_configs)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of the timed run's accumulator")
@@ -386,6 +389,8 @@ def run_workload(args, env):
     foreign = (~torch.from_numpy(D.owner_mask(rank, n_gpus, W, H))).to(accum.device) if (n_gpus > 1 and args.exchange == "reduce") else None
     times, kernel_ms_all, stages_all, exch_ms, render_ms = [], [], [], [], []
     for rep_i in range(args.reps):
+        # per-launch HIP event pairs (the per-kernel times of the report) in the last region only, unless asked otherwise
+        pt.set_stage_timing(args.stage_events == "all" or rep_i == args.reps - 1)
         barrier(f"barrier before region {rep_i}")
         t_start = time.perf_counter()
         pt.render(args.steps)
@@ -411,10 +416,14 @@ def run_workload(args, env):
         kernel_ms_all.append(pt.last_kernel_ms())
         stages_all.append(pt.last_stage_ms() if args.pipeline != "megakernel" else None)
     order = sorted(range(args.reps), key=lambda i: times[i])
-    med = order[(args.reps - 1) // 2]  # the median region (lower median for an even count): its own stage timings are reported
+    med = order[(args.reps - 1) // 2]  # the median region (lower median for an even count): `value`
     elapsed = times[med]
-    kernel_ms, launches = kernel_ms_all[med]
-    stages = stages_all[med]
+    # the region whose launches carried HIP event pairs: its stage timings (and its own wall time) are what the per-kernel
+    # part of the report is about
+    ev_rep = med if args.stage_events == "all" else args.reps - 1
+    kernel_ms, launches = kernel_ms_all[ev_rep]
+    stages = stages_all[ev_rep]
+    pt.set_stage_timing(True)  # (the counting ticks of report() and anything after read stage times again)
 
     total_samples = float(W) * H * args.steps
     value = total_samples / elapsed / 1e6
@@ -433,6 +442,9 @@ def run_workload(args, env):
                                  accum.cpu().numpy())
         out = report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed, times, kernel_ms, launches,
                      stages, build_s)
+        out["stage_events"] = {"regions": args.stage_events, "region": ev_rep, "region_ms_per_step": round(times[ev_rep] * 1e3 / args.steps, 4),
+                               "is": "the timed region whose launches carried HIP event pairs (fspt_target_set_stage_timing): roofline.kernels.* "
+                                     "and roofline.avg_launch_ms are that region's; `value` is the median of all regions"}
         out["parity_check"] = check
         if n_gpus > 1:
             out["exchange_ms"] = round(exch_ms[med], 3)  # read-out exchange + closing barrier of the median region (inside `value`)

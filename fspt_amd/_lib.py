@@ -117,6 +117,7 @@ SIGNATURES = {
     "fspt_target_set_pool": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_uint32, C.c_int]),
     "fspt_target_set_trace_budget": (C.c_int, [_VP, C.c_uint32]),
     "fspt_last_stage_ms": (C.c_int, [_VP, _F, _U32]),
+    "fspt_target_set_stage_timing": (C.c_int, [_VP, C.c_int]),
     "fspt_target_prepare": (C.c_int, [_VP]),
     "fspt_target_set_tail": (C.c_int, [_VP, C.c_int]),
     "fspt_target_set_deferred": (C.c_int, [_VP, C.c_int]),

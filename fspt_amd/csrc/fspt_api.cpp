@@ -964,6 +964,13 @@ int fspt_target_set_node_form(fspt_target *t, int primary, int trace, int tail, 
   return FSPT_OK;
 }
 
+int fspt_target_set_stage_timing(fspt_target *t, int enable) {
+  if (!t) { fspt_set_error("fspt_target_set_stage_timing: NULL target"); return FSPT_E_INVALID; }
+  FLUSH_OR_RETURN(t);
+  t->stage_events = enable != 0;
+  return FSPT_OK;
+}
+
 int fspt_target_set_tail(fspt_target *t, int round) {
   if (!t) { fspt_set_error("fspt_target_set_tail: NULL target"); return FSPT_E_INVALID; }
   FLUSH_OR_RETURN(t);

@@ -54,7 +54,12 @@ static const uint32_t ST_DEFAULT_SUSP_BUDGET = FSPT_SUSP_BUDGET;
 // 0.215 -> 0.26; primary 0.127 -> 0.138 / 0.176 -> 0.193.  Halving the dependent round trips buys nothing because a step's
 // time is not a cache-miss latency: it is the CU's vector-memory front end working through the lane-requests of all its
 // resident waves (16 waves x 4 instructions x (4.6 + 0.63 x active lanes) cycles = the 1 900 clocks per step round-4
-// measured in the tail kernel), and a two-level fetch issues 8 requests where the walk needs 4 or 8.  So: everything off.
+// measured in the tail kernel), and a two-level fetch issues 8 requests where the walk needs 4 or 8.  The ADAPTIVE tail
+// (two-level nodes only once a wave's list is used up - the launch's end phase, a few lanes walking dependent chains on a
+// mostly idle chip) loses as well: 0.037-0.039 -> 0.038-0.040 / 0.80-0.82 -> 0.83-0.88 / 0.120-0.128 -> 0.136-0.145
+// (ab_tail_adaptive_*.log) - the second node array is touched by that phase alone, so its lines come from the Infinity Cache
+// or HBM where the 64-byte nodes, which every trace launch keeps warm, hit the L2: half as many fetches at twice the
+// latency.  So: everything off; the form stays selectable (fspt_target_set_node_form) and tested.
 #ifndef FSPT_WIDE_PRIMARY
 #define FSPT_WIDE_PRIMARY 0
 #endif
@@ -175,6 +180,7 @@ struct fspt_target {
   std::vector<int> ev_kind;   // kernel class of pair i
   uint32_t ev_used = 0;       // pairs used by the last render
   bool ev_overflow = false;
+  bool stage_events = true;   // fspt_target_set_stage_timing: a HIP event pair around every launch (fspt_last_stage_ms)
 };
 
 static const uint32_t WORK_RING = 4096;

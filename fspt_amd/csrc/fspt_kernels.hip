@@ -1108,11 +1108,21 @@ FM_DEV void carry_path(const WfSet &in, const WfSet &o, uint32_t i, uint32_t k) 
 FM_DEV void carry_records(const WfP &p, uint32_t first, uint32_t stride) {
   const uint32_t n = p.counts[p.cnt_in].n_susp;
   int *rec = p.susp[p.cnt_in & 1u];
-  for (uint32_t r = first; r < n; r += stride) {
-    int *q = rec + (size_t)r * p.susp_stride;
-    const uint32_t k_new = atomicAdd(&p.counts[p.cnt_out].n_ext, 1u);
-    carry_path(p.set[p.set_in], p.set[p.set_out], (uint32_t)q[0], k_new);
-    q[0] = (int)k_new;
+  // one reservation per WAVE (same-address atomics serialise at the memory side, ~15 ns each: a few thousand records,
+  // one atomic each, were most of this launch's 11-27 us, profiles/r05/launch_list_c2.txt)
+  for (uint32_t r = first;; r += stride) {
+    const bool act = r < n;
+    const unsigned long long m = __ballot(act);
+    if (m == 0ull) break;
+    uint32_t base = 0;
+    if ((threadIdx.x & (WAVE - 1)) == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&p.counts[p.cnt_out].n_ext, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), WAVE);
+    if (act) {
+      int *q = rec + (size_t)r * p.susp_stride;
+      const uint32_t k_new = base + lane_rank(m);
+      carry_path(p.set[p.set_in], p.set[p.set_out], (uint32_t)q[0], k_new);
+      q[0] = (int)k_new;
+    }
   }
 }
 __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_carry(const WfP p) {

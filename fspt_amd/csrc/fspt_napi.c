@@ -424,6 +424,26 @@ static napi_value MultiClear(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_multi_clear((fspt_multi *)h));
   return undefined(env);
 }
+/* multiSetExchange(multi, mode): 0 peer copies, 1 RCCL send / recv of the packed tiles, 2 RCCL sum-reduce (fspt_multi.h) */
+static napi_value MultiSetExchange(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h; int32_t mode;
+  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_int32(env, a[1], &mode));
+  FSPT_OK_OR_THROW(fspt_multi_set_exchange((fspt_multi *)h, mode));
+  return undefined(env);
+}
+/* multiGetExchange(multi) -> {mode, rcclVersion} */
+static napi_value MultiGetExchange(napi_env env, napi_callback_info info) {
+  napi_value a[1], o, v; void *h; int mode = 0, ver = 0;
+  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  FSPT_OK_OR_THROW(fspt_multi_get_exchange((fspt_multi *)h, &mode, &ver));
+  NAPI_OK(napi_create_object(env, &o));
+  NAPI_OK(napi_create_int32(env, mode, &v));
+  NAPI_OK(napi_set_named_property(env, o, "mode", v));
+  NAPI_OK(napi_create_int32(env, ver, &v));
+  NAPI_OK(napi_set_named_property(env, o, "rcclVersion", v));
+  return o;
+}
 static napi_value MultiSync(napi_env env, napi_callback_info info) {
   napi_value a[1]; void *h;
   if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
@@ -863,7 +883,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"setMemoryLimit", SetMemoryLimit}, {"setTextureInterleaveBudget", SetTextureInterleaveBudget}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail}, {"setDeferred", SetDeferred},
       {"renderAsync", RenderAsync}, {"multiCreate", MultiCreate}, {"multiDestroy", MultiDestroy}, {"multiTarget", MultiTarget},
       {"multiCamera", MultiCamera}, {"multiTrace", MultiTrace}, {"multiRender", MultiRender}, {"multiRenderAsync", MultiRenderAsync},
-      {"multiClear", MultiClear}, {"multiSync", MultiSync}, {"multiReadRadiance", MultiReadRadiance}, {"multiDraw", MultiDraw},
+      {"multiClear", MultiClear}, {"multiSync", MultiSync}, {"multiSetExchange", MultiSetExchange}, {"multiGetExchange", MultiGetExchange}, {"multiReadRadiance", MultiReadRadiance}, {"multiDraw", MultiDraw},
       {"enableCounters", EnableCounters}, {"counters", GetCounters}, {"builderCreate", BuilderCreate}, {"builderDestroy", BuilderDestroy},
       {"builderParseObj", BuilderParseObj}, {"builderCommit", BuilderCommit}, {"builderNormalize", BuilderNormalize},
       {"builderBuild", BuilderBuild}, {"builderAutofocus", BuilderAutofocus}, {"envBins", EnvBins},

@@ -206,7 +206,7 @@ int ev_begin(fspt_target *t, int kind, hipStream_t stream) {
   // FSPT_STAGE_EVENTS=0 (environment, read once): no event pair around the launches - fspt_last_stage_ms then reports
   // zeros; a measurement hook for what the events themselves cost (profiles/r05/ab_stream_events.log)
   static const bool events_on = !(getenv("FSPT_STAGE_EVENTS") && getenv("FSPT_STAGE_EVENTS")[0] == '0');
-  if (!events_on) return -1;
+  if (!events_on || !t->stage_events) return -1;
   if (t->ev_used >= EV_PAIRS) { t->ev_overflow = true; return -1; }
   if (t->ev_pool.size() < (size_t)(t->ev_used + 1) * 2) {
     hipEvent_t a, b;

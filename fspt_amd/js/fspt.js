@@ -404,6 +404,14 @@ class MultiPathTracer {
   renderAsync(nTicks) { const p = addon.multiRenderAsync(this._multi, this._params(), this.pingpong, nTicks, this._rng[0]); this._advance(nTicks); return p; }
   clear() { addon.multiClear(this._multi); this.pingpong = 0; }
   sync() { addon.multiSync(this._multi); }
+  /** the read-out exchange (include/fspt_multi.h): 'peer' (hipMemcpyPeerAsync of the packed tiles, default), 'rccl_gather'
+   *  (ncclSend / ncclRecv of the same tiles), 'rccl_reduce' (ncclReduce(SUM) of own-tiles-only frames); RCCL needs distinct devices */
+  setExchange(mode) {
+    const codes = { peer: 0, rccl_gather: 1, rccl_reduce: 2 };
+    if (codes[mode] === undefined) throw new Error("unknown exchange '" + mode + "' (want " + Object.keys(codes).join(', ') + ')');
+    addon.multiSetExchange(this._multi, codes[mode]);
+  }
+  exchange() { return addon.multiGetExchange(this._multi); }
   readRadiance(out) {
     out = out || new Float32Array(this.resolution[0] * this.resolution[1] * 4);
     if (out.length !== this.resolution[0] * this.resolution[1] * 4) throw new RangeError('readRadiance: need W*H*4 floats');

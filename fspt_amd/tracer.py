@@ -184,6 +184,10 @@ class PathTracer:
         L.check(L.lib().fspt_target_path_state_bytes(self._t, C.byref(b), C.byref(n)))
         return b.value, n.value
 
+    def set_stage_timing(self, on=True):
+        """HIP event pairs around every launch (what last_stage_ms reads); off: ~1.3 % faster 20-tick regions, zeros there."""
+        L.check(L.lib().fspt_target_set_stage_timing(self._t, 1 if on else 0))
+
     def last_stage_ms(self):
         ms = (C.c_float * 5)(); n = (C.c_uint32 * 5)()
         L.check(L.lib().fspt_last_stage_ms(self._t, ms, n))

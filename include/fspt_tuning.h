@@ -96,6 +96,11 @@ int fspt_target_live_paths(fspt_target *target, double *frac, uint32_t n_rounds)
 int fspt_set_texture_interleave_budget(uint64_t bytes);
 
 /* ---- measurement ---------------------------------------------------------------------------------------------------- */
+/* Per-launch stage timing: a HIP event pair around every kernel launch of the wavefront pipeline, what fspt_last_stage_ms
+ * reads (default on).  The events are not free - two timestamp markers per launch, ~30 launches per 20-tick batch: 1.3 % of
+ * a 20-tick region (profiles/r05/ab_stage_events.log) - so a host that only wants frames switches them off; the events
+ * around the whole call (fspt_last_kernel_ms) stay.  With them off fspt_last_stage_ms reports zeros. */
+int fspt_target_set_stage_timing(fspt_target *target, int enable);
 /* HIP-event time of the most recent fspt_trace / fspt_render on this target (total ms, kernel launches).  Blocking. */
 int fspt_last_kernel_ms(fspt_target *target, float *ms, uint32_t *launches);
 /* ... per kernel class {primary, trace, logic, resolve, tail}: summed HIP-event durations and launch counts.  With

@@ -104,6 +104,24 @@ if (mode === 'scene_file') {
       fs.writeFileSync(process.argv[4], JSON.stringify(out));
     });
   }).catch((e) => { console.error(e); process.exit(1); });
+} else if (mode === 'render_multi_rccl') {
+  // the library's RCCL exchanges from the JS host (one device: a one-rank communicator), then an unknown mode
+  const s = F.buildScene(job.props, job.objs, env, 4);
+  const mp = new F.MultiPathTracer(s, job.W, job.H, job.devices);
+  mp.eye = job.cam.P; mp.dir = job.cam.I; mp.fovScale = job.cam.fov_scale; mp.envTheta = job.cam.env_theta;
+  mp.lensFeatures = job.cam.lens; mp.numBounces = job.bounces;
+  mp.seed(job.seed);
+  mp.render(job.ticks);
+  out.before = mp.exchange();
+  mp.setExchange('rccl_reduce');
+  out.reduce = mp.exchange();
+  out.radiance_reduce = b64(mp.readRadiance());
+  mp.setExchange('rccl_gather');
+  out.radiance_gather = b64(mp.readRadiance());
+  mp.setExchange('peer');
+  out.radiance_peer = b64(mp.readRadiance());
+  try { mp.setExchange('carrier-pigeon'); out.unknown = null; } catch (e) { out.unknown = String(e.message); }
+  mp.close();
 } else if (mode === 'bounces_range') {
   // NUM_BOUNCES outside [0, 64] or not an integer: RangeError at the N-API boundary, before any device call
   out.errors = {};
