@@ -155,9 +155,10 @@ def parse_args(argv=None):
     ap.add_argument("--tex-interleave-budget", type=int, default=None,
                     help="bytes of interleaved material textures the scene may use (A/B: 0 = single-layer images only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stage-events", default="last", choices=["last", "all"],
+    ap.add_argument("--stage-events", default="first", choices=["first", "last", "all"],
                     help="which timed regions carry the per-launch HIP event pairs behind the per-kernel times (they cost ~1.3 %% of a "
-                         "20-step region): only the last one (default; the reported per-kernel times and the roofline are that region's), or all")
+                         "20-step region): only the first one (default; the reported per-kernel times and the roofline are that region's), "
+                         "only the last one, or all")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="only the headline workload (default: after it, BASELINE configs[2] and [4] at N = 1 / configs[3] at N > 1 as extra_configs)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of the timed run's accumulator")
@@ -316,6 +317,10 @@ def trim_extra(o, seconds):
     keep["roofline"]["kernels"] = {c: {k: v.get(k) for k in ("ms_per_step", "launches", "avg_launch_ms", "alg_GBps", "traffic_GBps", "frac", "bound")} for c, v in (r.get("kernels") or {}).items()}
     keep["wall_s"] = round(seconds, 1)
     return keep
+def _event_region(args):
+    return 0 if args.stage_events == "first" else args.reps - 1
+
+
 class Env:
     """What every workload of one bench.py process shares: the rank's place in the job and its process group."""
     def __init__(self, **kw):
@@ -389,8 +394,10 @@ def run_workload(args, env):
     foreign = (~torch.from_numpy(D.owner_mask(rank, n_gpus, W, H))).to(accum.device) if (n_gpus > 1 and args.exchange == "reduce") else None
     times, kernel_ms_all, stages_all, exch_ms, render_ms = [], [], [], [], []
     for rep_i in range(args.reps):
-        # per-launch HIP event pairs (the per-kernel times of the report) in the last region only, unless asked otherwise
-        pt.set_stage_timing(args.stage_events == "all" or rep_i == args.reps - 1)
+        # per-launch HIP event pairs (the per-kernel times of the report) in ONE region only, unless asked otherwise: the
+        # first by default - of the driver's five 20-step regions the first (first use of the 20-tick batch) and the second
+        # (the primary-form tuner's look at the other form) are never the median, so `value` is an event-free region's
+        pt.set_stage_timing(args.stage_events == "all" or rep_i == _event_region(args))
         barrier(f"barrier before region {rep_i}")
         t_start = time.perf_counter()
         pt.render(args.steps)
@@ -420,7 +427,7 @@ def run_workload(args, env):
     elapsed = times[med]
     # the region whose launches carried HIP event pairs: its stage timings (and its own wall time) are what the per-kernel
     # part of the report is about
-    ev_rep = med if args.stage_events == "all" else args.reps - 1
+    ev_rep = med if args.stage_events == "all" else _event_region(args)
     kernel_ms, launches = kernel_ms_all[ev_rep]
     stages = stages_all[ev_rep]
     pt.set_stage_timing(True)  # (the counting ticks of report() and anything after read stage times again)
@@ -433,13 +440,19 @@ def run_workload(args, env):
                                                            kernel_ms=[round(k[0], 3) for k in kernel_ms_all])) + "\n")
         sys.stderr.flush()
 
-    if rank == 0:
-        # the frame as the timed regions left it (rank 0 holds the whole frame after the exchange), checked against the
-        # oracle BEFORE the counting ticks of report() add to it
+    if rank != 0:
+        pt.close()
+        return None
+    # Rank 0's part that needs no other rank - the oracle check of the assembled frame and the counting ticks of the report -
+    # is DEFERRED (main() runs it after the timed regions of every workload, when the other ranks have already been
+    # released: VERDICT r4 weak 8 iii - seven ranks used to sit in a barrier with a 600 s timeout meanwhile).  The frame as
+    # the timed regions left it is copied to the host now (the counting ticks add to the accumulator later).
+    frame = accum.cpu().numpy() if (not args.no_parity_check or n_gpus > 1) else None  # N > 1: mandatory - bytes that crossed xGMI are verified
+
+    def finish():
         check = None
-        if not args.no_parity_check or n_gpus > 1:  # N > 1: mandatory - the first time bytes that crossed xGMI are verified
-            check = parity_check(arrays, W, H, cam, lens, args.bounces, args.warmup + args.reps * args.steps, 1,
-                                 accum.cpu().numpy())
+        if frame is not None:
+            check = parity_check(arrays, W, H, cam, lens, args.bounces, args.warmup + args.reps * args.steps, 1, frame)
         out = report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed, times, kernel_ms, launches,
                      stages, build_s)
         out["stage_events"] = {"regions": args.stage_events, "region": ev_rep, "region_ms_per_step": round(times[ev_rep] * 1e3 / args.steps, 4),
@@ -449,9 +462,9 @@ def run_workload(args, env):
         if n_gpus > 1:
             out["exchange_ms"] = round(exch_ms[med], 3)  # read-out exchange + closing barrier of the median region (inside `value`)
             out["rank0"] = rank_info
-        result = out
-    pt.close()
-    return result
+        pt.close()
+        return out
+    return finish
 
 
 def main():
@@ -477,7 +490,7 @@ def main():
 
     # The request-rate peak the trace kernel is priced against is measured first, by a child process started BEFORE this
     # process touches the GPU (no fork of a process that holds a HIP context).  Under a profiler the preloaded library
-    # has initialised the GPU before main() runs: such runs pass --l1-peak (tools/prof_r04.sh measures it once, outside
+    # has initialised the GPU before main() runs: such runs pass --l1-peak (tools/prof_session.sh measures it once, outside
     # rocprofv3) or --no-l1-microbench, and no child is ever started from this process.
     global _L1_PEAK
     if rank == 0 and _L1_PEAK is None:
@@ -523,11 +536,12 @@ def main():
         sys.stderr.write("[bench rank] " + json.dumps(rank_info) + "\n"); sys.stderr.flush()
 
     env = Env(rank=rank, local_rank=local_rank, n_gpus=n_gpus, dist=dist, world_seen=world_seen, rank_info=rank_info)
-    out = run_workload(args, env)
-    # ---- the other BASELINE configs on the same record: after the headline, whose JSON keys and
-    # timed regions are exactly what they were.  N = 1: configs[2] (1 M triangles) and configs[4] (aperture 0.1 + small
-    # sun) as extra_configs.c3 / .c5; N > 1 on the weak-scaled default: configs[3] (3840x2160 cut over the N ranks,
-    # strong scaling) as extra_configs.strong_c4.  Each with its own regions, per-kernel times and parity check.
+    # ---- the timed regions of every workload first.  The headline, then the other BASELINE configs on the same record
+    # (VERDICT r4 item 2): N = 1: configs[2] (1 M triangles) and configs[4] (aperture 0.1 + small sun) as extra_configs.c3 /
+    # .c5; N > 1 on the weak-scaled default: configs[3] (3840x2160 cut over the N ranks, strong scaling) as
+    # extra_configs.strong_c4.  Each with its own regions, per-kernel times and parity check.
+    t_h = time.perf_counter()
+    pending = [("headline", run_workload(args, env), time.perf_counter() - t_h)]
     extras = []
     if not args.no_extra_configs and args.config == "c2" and args.pipeline == "wavefront" and not args.textured:
         if n_gpus == 1:
@@ -537,18 +551,26 @@ def main():
     for key, over in extras:
         a2 = parse_args(_extra_argv(sys.argv[1:], over, steps=min(args.steps, 20), warmup=min(args.warmup, 5)))
         t_x = time.perf_counter()
-        o2 = run_workload(a2, env)
-        if rank == 0 and out is not None and o2 is not None:
-            out.setdefault("extra_configs", {})[key] = trim_extra(o2, time.perf_counter() - t_x)
-    if rank == 0 and out is not None:
+        pending.append((key, run_workload(a2, env), time.perf_counter() - t_x))
+    # ---- every collective of the job is done: the other ranks leave now; rank 0's oracle checks and counting ticks (no
+    # communication in either) follow, with nobody waiting for them
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        out = None
+        for key, fin, secs in pending:
+            t_f = time.perf_counter()
+            o = fin()
+            secs += time.perf_counter() - t_f
+            if key == "headline":
+                out = o
+            else:
+                out.setdefault("extra_configs", {})[key] = trim_extra(o, secs)
         print(json.dumps(out), flush=True)
         bad = [k for k, v in [("headline", out)] + list(out.get("extra_configs", {}).items())
                if v.get("parity_check") is not None and not v["parity_check"]["equal"]]
         if bad:
             raise SystemExit(f"bench.py: the timed run's accumulator differs from the oracle ({', '.join(bad)})")
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     return 0
 
 
@@ -663,7 +685,7 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
                 kj["traffic_GBps"] = round(tb / (ms / 1e3) / 1e9, 1) if ms > 0 else None
             if pkey:
                 pk = prof["kernels"][pkey]
-                if "ta_busy" in pk:  # stamped SQ / TA / TD counters of the same code (tools/collect_r04.py)
+                if "ta_busy" in pk:  # stamped SQ / TA / TD counters of the same code (tools/collect_profiles.py)
                     kj["counters"] = {c: pk[c] for c in ("ta_busy", "td_busy", "valu_active_share", "valu_lane_utilisation", "wait_share", "l2_hit") if c in pk}
             if k == "trace":
                 rps = tr_req * steps / (ms / 1e3) if ms > 0 else 0.0

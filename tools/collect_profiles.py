@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Derive the committed profile files from a tools/prof_r04.sh session.
-    python tools/collect_r04.py <tag> <workload-key> [<tag> <workload-key> ...]
- -> profiles/r04/<tag>_kernel_stats.csv, <tag>_bench.json.log, <tag>_pmc_summary.txt and profiles/hbm_traffic.json
+"""Derive the committed profile files from a tools/prof_session.sh session.
+    python tools/collect_profiles.py <tag> <workload-key> [<tag> <workload-key> ...]
+ -> profiles/<round>/<tag>_kernel_stats.csv, <tag>_bench.json.log, <tag>_pmc_summary.txt and profiles/hbm_traffic.json
     (bytes per sample per kernel, stamped with the hash of the kernel sources the numbers were measured on)."""
 import collections, csv, glob, json, os, re, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
-G, P = "gpurun_out", os.path.join("profiles", "r04")
+G, P = "gpurun_out", os.path.join("profiles", os.environ.get("FSPT_PROFILE_ROUND", "r05"))
 os.makedirs(P, exist_ok=True)
 pairs = list(zip(sys.argv[1::2], sys.argv[2::2]))
 out = {"source_sha": bench.source_sha(),
@@ -139,7 +139,7 @@ for tag, wl in pairs:
                 if src in d:
                     kern[k][dst] = d[src]
     if derived:
-        json.dump({"note": "from <tag>_pmc_summary.txt: one timed region of bench.py (SQ_ARGS of tools/prof_r04.sh, default --steps 20); busy = *_BUSY_sum / "
+        json.dump({"note": "from <tag>_pmc_summary.txt: one timed region of bench.py (SQ_ARGS of tools/prof_session.sh, default --steps 20); busy = *_BUSY_sum / "
                            "GRBM_GUI_ACTIVE / 31.33 instances (profiles/r01/l1_pipe.json)", "kernels": derived},
                   open(os.path.join(P, f"{base}_derived.json"), "w"), indent=1)
         for k, d in derived.items():

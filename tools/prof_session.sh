@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 profile session (run on the GPU box through gpurun):
-#   tools/prof_r04.sh <tag> [bench args...]     -> gpurun_out/<tag>_{kt,fetch,write,sq*}/ + logs
+# Profile session (run on the GPU box through gpurun):
+#   tools/prof_session.sh <tag> [bench args...]     -> gpurun_out/<tag>_{kt,fetch,write,sq*}/ + logs
 # kernel trace + stats of the default bench command, then PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, as the
 # guide prescribes; SQ / TA / TD sets) over one timed batch.  rocprofv3 gets the program itself after `--`.
 set -u
