@@ -141,7 +141,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=128)
-    ap.add_argument("--reps", type=int, default=5, help="timed regions of exactly --steps steps; the median is reported")
+    ap.add_argument("--reps", type=int, default=7, help="timed regions of exactly --steps steps; the median is reported (7: of the "
+                    "driver's 20-step regions the first runs cold, the second is the primary-form tuner's look at the other form and "
+                    "the last carries the per-launch event pairs - the median is one of the other four)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json configs[1..4]")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -155,10 +157,10 @@ def parse_args(argv=None):
     ap.add_argument("--tex-interleave-budget", type=int, default=None,
                     help="bytes of interleaved material textures the scene may use (A/B: 0 = single-layer images only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stage-events", default="first", choices=["first", "last", "all"],
+    ap.add_argument("--stage-events", default="last", choices=["first", "last", "all"],
                     help="which timed regions carry the per-launch HIP event pairs behind the per-kernel times (they cost ~1.3 %% of a "
-                         "20-step region): only the first one (default; the reported per-kernel times and the roofline are that region's), "
-                         "only the last one, or all")
+                         "20-step region): only the last one (default: a warm, steady-state region; the reported per-kernel times and the "
+                         "roofline are that region's), only the first one, or all")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="only the headline workload (default: after it, BASELINE configs[2] and [4] at N = 1 / configs[3] at N > 1 as extra_configs)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of the timed run's accumulator")
@@ -395,8 +397,9 @@ def run_workload(args, env):
     times, kernel_ms_all, stages_all, exch_ms, render_ms = [], [], [], [], []
     for rep_i in range(args.reps):
         # per-launch HIP event pairs (the per-kernel times of the report) in ONE region only, unless asked otherwise: the
-        # first by default - of the driver's five 20-step regions the first (first use of the 20-tick batch) and the second
-        # (the primary-form tuner's look at the other form) are never the median, so `value` is an event-free region's
+        # last by default - warm and in the form the tuner settled on.  Of seven 20-step regions the first (first use of the
+        # 20-tick batch), the second (the primary-form tuner's look at the other form) and this one are the three slowest,
+        # so `value` - the median - is one of the four steady-state regions without the events' 1.3 %
         pt.set_stage_timing(args.stage_events == "all" or rep_i == _event_region(args))
         barrier(f"barrier before region {rep_i}")
         t_start = time.perf_counter()

@@ -499,6 +499,14 @@ static napi_value SetTail(napi_env env, napi_callback_info info) {
   FSPT_OK_OR_THROW(fspt_target_set_tail((fspt_target *)h, r));
   return undefined(env);
 }
+/* setStageTiming(target, on): the per-launch HIP event pairs behind fspt_last_stage_ms (fspt_tuning.h) */
+static napi_value SetStageTiming(napi_env env, napi_callback_info info) {
+  napi_value a[2]; void *h; bool on;
+  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  NAPI_OK(napi_get_value_bool(env, a[1], &on));
+  FSPT_OK_OR_THROW(fspt_target_set_stage_timing((fspt_target *)h, on ? 1 : 0));
+  return undefined(env);
+}
 static napi_value Clear(napi_env env, napi_callback_info info) {
   napi_value a[1]; void *h;
   if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
@@ -880,7 +888,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"sceneCreate", SceneCreate}, {"sceneDestroy", SceneDestroy}, {"targetCreate", TargetCreate},
       {"targetDestroy", TargetDestroy}, {"camera", Camera}, {"trace", Trace}, {"traceTest", TraceTest}, {"render", Render}, {"clear", Clear},
       {"sync", Sync}, {"readRadiance", ReadRadiance}, {"draw", Draw}, {"setShard", SetShard}, {"setViewport", SetViewport}, {"setPipeline", SetPipeline}, {"setPool", SetPool}, {"setTraceBudget", SetTraceBudget},
-      {"setMemoryLimit", SetMemoryLimit}, {"setTextureInterleaveBudget", SetTextureInterleaveBudget}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail}, {"setDeferred", SetDeferred},
+      {"setMemoryLimit", SetMemoryLimit}, {"setTextureInterleaveBudget", SetTextureInterleaveBudget}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail}, {"setDeferred", SetDeferred}, {"setStageTiming", SetStageTiming},
       {"renderAsync", RenderAsync}, {"multiCreate", MultiCreate}, {"multiDestroy", MultiDestroy}, {"multiTarget", MultiTarget},
       {"multiCamera", MultiCamera}, {"multiTrace", MultiTrace}, {"multiRender", MultiRender}, {"multiRenderAsync", MultiRenderAsync},
       {"multiClear", MultiClear}, {"multiSync", MultiSync}, {"multiSetExchange", MultiSetExchange}, {"multiGetExchange", MultiGetExchange}, {"multiReadRadiance", MultiReadRadiance}, {"multiDraw", MultiDraw},

@@ -7,7 +7,7 @@
  * exactly `steps` ticks + sync, `reps` regions, median.  Prints ONE JSON line with bench.py's keys.
  *
  *   node fspt_amd/js/bench.js --scene <web-root>/scene/bench.json [--width 1920 --height 1080 --bounces 8 --steps 20
- *        --warmup 5 --reps 5 --batch 128 --focal-depth 2 --aperture 0.02 --seed 1 --out-radiance frame.f32]
+ *        --warmup 5 --reps 7 --batch 128 --focal-depth 2 --aperture 0.02 --seed 1 --out-radiance frame.f32]
  * (tools/write_bench_scene.py writes bench.py's synthetic 'bunny' workload as such a web root.)                        */
 const fs = require('fs');
 const path = require('path');
@@ -15,7 +15,7 @@ const F = require('./fspt.js');
 const SF = require('./scene_file.js');
 
 function args(argv) {
-  const o = { width: 1920, height: 1080, bounces: 8, steps: 20, warmup: 5, reps: 5, batch: 128, seed: 1, device: 0 };
+  const o = { width: 1920, height: 1080, bounces: 8, steps: 20, warmup: 5, reps: 7, batch: 128, seed: 1, device: 0 };
   for (let i = 0; i < argv.length; i++) {
     const a = argv[i];
     if (!a.startsWith('--')) throw new Error('unexpected argument ' + a);
@@ -44,6 +44,7 @@ function main() {
     const batch = Math.max(1, Math.min(o.batch, Math.max(o.steps, o.warmup)));
     pt.setPipeline('wavefront', batch);
     pt.seed(o.seed);
+    pt.setStageTiming(false);           // this host reads no per-kernel times: no event pairs around the launches
     pt.prepare();                       // path state is allocated here, never inside a timed region
     if (o.warmup > 0) pt.render(o.warmup);
     pt.sync();

@@ -368,6 +368,8 @@ class PathTracer {
   /** drawCamera + drawTracer ticks are recorded and run as batches at the next read-out (default, include/fspt.h);
    *  false: every drawTracer executes at once */
   setDeferred(on) { addon.setDeferred(this._target, on !== false); }
+  /** HIP event pairs around every kernel launch (per-kernel timing for measurement hosts; ~1.3 % of a 20-tick batch): on by default */
+  setStageTiming(on) { addon.setStageTiming(this._target, on !== false); }
   /** cap / query the wavefront path state (include/fspt.h: fspt_target_set_memory_limit) and pre-allocate it */
   setMemoryLimit(bytes) { addon.setMemoryLimit(this._target, bytes || 0); }
   pathStateBytes() { return addon.pathStateBytes(this._target); }

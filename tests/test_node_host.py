@@ -44,7 +44,7 @@ def test_addon_exports():
                  "builderCreate", "builderParseObj", "builderCommit", "builderNormalize", "builderBuild",
                  "builderAutofocus", "builderDestroy", "envBins", "counters", "renderAsync", "multiCreate", "multiRender",
                  "multiRenderAsync", "multiReadRadiance", "multiDraw", "multiTarget", "multiDestroy", "setTail",
-                 "setMemoryLimit", "prepare", "setTextureInterleaveBudget", "setPool", "setTraceBudget", "multiSetExchange",
+                 "setMemoryLimit", "prepare", "setTextureInterleaveBudget", "setPool", "setTraceBudget", "setStageTiming", "multiSetExchange",
                  "multiGetExchange"):
         assert name in out["exports"]
 
@@ -457,7 +457,7 @@ def test_js_bench_matches_oracle_and_the_python_host_rate(tmp_path):
     full = WB.write(str(tmp_path / "full"), mesh_n=76)
     js, py = [], []
     for _ in range(2):
-        js.append(_node_bench(full, "--steps", 20, "--warmup", 5, "--reps", 5)["value"])
+        js.append(_node_bench(full, "--steps", 20, "--warmup", 5, "--reps", 7)["value"])
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
                             "--no-extra-configs", "--no-l1-microbench", "--no-parity-check"], capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
