@@ -29,7 +29,7 @@ g++ $SAN -std=c++17 -o $D/libfspt_san.so fspt_amd/csrc/scene_build.cpp $D/stubs.
 export ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
 FSPT_ORACLE_LIB=$D/liboracle_san.so python3 -m pytest tests/test_goldens.py -q -p no:cacheprovider \
-  -k "d2 or d3 or sample or bounce or camera or bvh_test or rnd_replay"
+  -k "d2 or d3 or d6 or sample or bounce or camera or bvh_test or rnd_replay"
 FSPT_LIB=$D/libfspt_san.so python3 -m pytest tests/test_goldens.py -q -p no:cacheprovider \
-  -k "d0_native or mtl_parser or 70k_scene or scene_file_loader_matches"
+  -k "d0_native or mtl_parser or 70k_scene or 1M_scene or scene_file_loader_matches"
 FSPT_LIB=$D/libfspt_san.so python3 tools/fuzz_builder.py
