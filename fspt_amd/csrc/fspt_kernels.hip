@@ -1837,6 +1837,12 @@ FM_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src, WAVE), __shfl(v.y, s
 #ifndef WF_TAIL_WAVES
 #define WF_TAIL_WAVES 4
 #endif
+#ifndef WF_TAIL_PAIRS
+#define WF_TAIL_PAIRS 32u // lane pairs of a wave that carry a path when WF_TAIL_PAIRS_AUTO is 0 (measurement hook: profiles/r05/ab_tail_pairs_*.log)
+#endif
+#ifndef WF_TAIL_PAIRS_AUTO
+#define WF_TAIL_PAIRS_AUTO 1 // the kernel spreads a small launch's paths over all its waves (see k_wf_tail)
+#endif
 #ifndef WF_TAIL_SLICE
 #define WF_TAIL_SLICE 32u // traversal steps of a lane per T phase.  No slicing / 64 / 32 / 16: tail 0.126 / 0.115 / 0.100 / 0.092 ms per
 // tick on the 1 M-triangle scene at 20-tick batches, 0.755 / 0.762 / 0.760 / 0.803 ms for a single tick of the 70 k scene,
@@ -1867,8 +1873,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
   WfCounts *cn = p.counts + p.cnt_out;
   const uint32_t total = cn->n_ext;
   Counters cnt = {0, 0, 0, 0, 0, 0};
-  const bool is_main = (lane & 1) == 0;
-  constexpr uint32_t PAIRS = WAVE / 2;
+  // Lane pairs of a wave that take paths.  A wave's traversal step lasts as long as the slowest of its lanes' fetches (and
+  // its shading phase as long as its paths' branches differ), so a launch with FEW paths spreads them over all its
+  // waves - as few pairs per wave as that takes - instead of filling some waves to the brim: 20 K paths 0.031 -> 0.026 ms
+  // per tick, 5 K paths 0.55 -> 0.36 ms (profiles/r05/ab_tail_pairs_*.log); with many paths (> 32 per wave) nothing changes.
+  const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
+  uint32_t PAIRS = WF_TAIL_PAIRS;
+  if (WF_TAIL_PAIRS_AUTO && !GEN) {
+    PAIRS = (total + n_waves - 1u) / n_waves;
+    PAIRS = PAIRS < 1u ? 1u : (PAIRS > WAVE / 2 ? WAVE / 2 : PAIRS);
+  }
+  const bool is_main = (lane & 1) == 0 && (uint32_t)(lane >> 1) < PAIRS;
   Path ps;
   ps.pix = -1;
   ps.hasShadow = false;
@@ -1882,7 +1897,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
   float r_t = MAX_T;
   // pool as in k_wf_trace: chunks of 32 paths; every wave's first chunk is its own, the rest is dealt out by the
   // wave's stripe head
-  const uint32_t n_waves = gridDim.x * WAVES_PER_BLOCK;
   const uint32_t wave_id = blockIdx.x * WAVES_PER_BLOCK + wave;
   const uint32_t stripe = wave_id % WF_HEADS;
   const uint32_t n_chunks = (total + PAIRS - 1u) / PAIRS;
@@ -2358,7 +2372,9 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
     else FSPT_LAUNCH_TRACE(false, true, false);
 #undef FSPT_LAUNCH_TRACE
   } else if (kernel == WF_K_TAIL) {
-    uint32_t grid = min((2u * total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * (WF_TAIL_WAVES > 4 ? WF_TAIL_WAVES : 4)); // two lanes per path
+    // paths a block holds at a time (two lanes per path; one pair per wave when the kernel spreads a small launch's paths)
+    const uint32_t per_block = WAVES_PER_BLOCK * (WF_TAIL_PAIRS_AUTO && !(p.ctl && p.finish) ? 1u : (uint32_t)WF_TAIL_PAIRS);
+    uint32_t grid = min((total + per_block - 1) / per_block, (uint32_t)num_cus * (WF_TAIL_WAVES > 4 ? WF_TAIL_WAVES : 4));
     size_t lds = stack_bytes(p.scene);
 #define FSPT_LAUNCH_TAIL(C, A, Wd)                                                                         \
     do {                                                                                                     \
