@@ -1004,6 +1004,23 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 #ifndef WF_LOGIC_U
 #define WF_LOGIC_U 8
 #endif
+// Block iterations of the primary and the logic launch by TICKET instead of a static stride (see k_wf_primary): 1 / 0
+// (measurement hooks: profiles/r05/ab_primary_tickets_*.log, ab_logic_tickets_*.log)
+#ifndef WF_PRIMARY_TICKETS
+#define WF_PRIMARY_TICKETS 1
+#endif
+#ifndef WF_LOGIC_TICKETS
+#define WF_LOGIC_TICKETS 1
+#endif
+// Grid sizes (measurement hooks, profiles/r05/ab_grid_sizes_*.log): 256-thread blocks per CU of a trace launch (8: 6 are
+// resident at 80 registers; 6 / 7: trace launch -2 % / +-0 on the 70 k scene, +-0 on the 1 M one, whole job +-0), and the
+// factor over what is resident for the primary / logic launches (2; 1: +-0 with tickets)
+#ifndef WF_TRACE_GRID_PER_CU
+#define WF_TRACE_GRID_PER_CU 8u
+#endif
+#ifndef WF_PL_OVERSUB
+#define WF_PL_OVERSUB 2u
+#endif
 // k_wf_primary takes ONE path per thread and block iteration: r01: 1 / 2 / 4 / 8 -> 0.327 / 0.320 / 0.331 / 0.357 ms per tick;
 // r02: 1 / 2 / 4 -> 15.0 / 15.4 / 16.9 ms per 128 ticks (one is the only count without register spills at 4 waves/SIMD;
 // profiles/r02/ab_primary_paths_per_thread.log).  (The top of the tree in LDS, as in k_wf_trace, makes this launch 10 %
@@ -1525,7 +1542,7 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
   constexpr int NW = WF_PRIMARY_THREADS / WAVE;
   constexpr uint32_t SPAN = (uint32_t)R * WF_PRIMARY_THREADS; // samples of a block iteration
   static_assert(R >= 1 && R <= WF_PRIMARY_R_MAX, "k_wf_primary: R");
-  __shared__ uint32_t s_off[2], s_base[2];
+  __shared__ uint32_t s_off[2], s_base[2], s_next[2];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
   DScene S = p.scene;
@@ -1560,7 +1577,18 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
   float4 *s_ray = reinterpret_cast<float4 *>(lds_tab + (LDSTAB ? wf_table_bytes(S.n_tex_sets, S.n_bins, p.n_batch) / 4u : 0u));
 
   uint32_t par = 0;
-  for (uint32_t base = blockIdx.x * SPAN; base < n_in; base += gridDim.x * SPAN, par ^= 1u) {
+  // Block iterations are handed out by TICKET (batch scheduler; the counter is pool head 0 of the unused round 0, cleared
+  // with the others behind every batch): a block's first iteration is its own index, every further one comes from the
+  // counter - blocks whose pixels were cheap take more of them, and the launch ends within one iteration's time of its
+  // last block instead of with the slowest block's whole static share (the grid is twice what is resident: with static
+  // shares the second half only started when blocks of the first had finished theirs).  70 k triangles: 0.126 -> 0.113
+  // ms per tick, 1 M: 0.180 -> 0.145 (profiles/r05/ab_primary_tickets_*.log).  (The first iteration by ticket as well:
+  // no different at 20 ticks, single-tick primary 0.23 -> 0.27, ab_first_ticket_*.log.)
+  const bool tickets = WF_PRIMARY_TICKETS && p.ctl == nullptr;
+  uint32_t it = blockIdx.x, it_next = 0;
+  for (uint32_t base; (unsigned long long)it * SPAN < (unsigned long long)n_in; it = it_next, par ^= 1u) {
+    base = it * SPAN;
+    it_next = it + gridDim.x;
     unsigned long long m_surv[R];
     // R == 1: this thread's one sample, in registers
     V3 o1 = v3(0.0f, 0.0f, 0.0f), d1 = v3(0.0f, 0.0f, 1.0f);
@@ -1672,8 +1700,10 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
       const uint32_t tot = s_off[par];
       s_base[par] = tot ? atomicAdd(&cn->n_ext, tot) : 0u;
       s_off[par ^ 1u] = 0u;
+      if (tickets) s_next[par] = gridDim.x + atomicAdd(p.heads, 1u);
     }
     __syncthreads();
+    if (tickets) it_next = __builtin_amdgcn_readfirstlane(s_next[par]);
 #pragma unroll
     for (int u = 0; u < R; ++u) {
       uint32_t i;
@@ -1730,7 +1760,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
   constexpr int U = WF_LOGIC_U;
   extern __shared__ int lds_dyn[]; // the staged tables
   __shared__ uint16_t s_list[U * WF_LOGIC_THREADS];
-  __shared__ uint32_t s_n, s_total, s_gbase;
+  __shared__ uint32_t s_n, s_total, s_gbase, s_next;
   // the launch's last carry_blocks blocks move the suspended traversals' paths on (k_wf_carry's work) and are done
   const uint32_t n_blocks = gridDim.x - p.carry_blocks;
   if (blockIdx.x >= n_blocks) {
@@ -1757,7 +1787,14 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
   uint32_t u_eff = (n_in + n_blocks * WF_LOGIC_THREADS - 1) / (n_blocks * WF_LOGIC_THREADS);
   u_eff = u_eff < 1u ? 1u : (u_eff > (uint32_t)U ? (uint32_t)U : u_eff);
   const uint32_t span = u_eff * WF_LOGIC_THREADS;
-  for (uint32_t base = blockIdx.x * span; base < n_in; base += n_blocks * span) {
+  // block iterations by ticket, as in k_wf_primary (batch scheduler): the counter is the second line of this round's
+  // first pool-head slot (the trace launch of the round uses the first word of each slot), cleared with the heads
+  const bool tickets = WF_LOGIC_TICKETS && p.ctl == nullptr;
+  uint32_t *ticket = p.heads + (size_t)p.cnt_out * WF_HEADS * WF_HEAD_STRIDE + WF_HEAD_STRIDE / 2;
+  uint32_t it_next = 0;
+  for (uint32_t it = blockIdx.x; (unsigned long long)it * span < (unsigned long long)n_in; it = it_next) {
+    const uint32_t base = it * span;
+    it_next = it + n_blocks;
     // ---- 1: classify ----
     uint32_t own_fin = 0; // bit u: own path u finishes in this round (handled in 2a)
     for (uint32_t u = 0; u < u_eff; ++u) {
@@ -1784,6 +1821,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
       s_total = tot;
       s_n = 0;
       my_gbase = tot ? atomicAdd(&cn->n_ext, tot) : 0u; // consumed after phase 2a, which covers its round trip
+      if (tickets) s_next = n_blocks + atomicAdd(ticket, 1u);
     }
     // ---- 2a (own finishing paths) then 2b (listed paths, dense) through ONE copy of the path code ----
     uint32_t n_shade = 0, gbase = 0;
@@ -1799,6 +1837,7 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
           __syncthreads();
           n_shade = s_total;
           gbase = s_gbase;
+          if (tickets) it_next = __builtin_amdgcn_readfirstlane(s_next);
         }
         const uint32_t tsh = (jt - u_eff) * WF_LOGIC_THREADS + threadIdx.x;
         if ((jt - u_eff) * WF_LOGIC_THREADS >= n_shade) break; // block-uniform
@@ -2063,6 +2102,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
       if (p.live_out) p.live_out[r] = p.counts[r].n_ext;
       p.counts[r].n_ext = 0u;
       p.counts[r].n_susp = 0u;
+      p.heads[(size_t)r * WF_HEADS * WF_HEAD_STRIDE + WF_HEAD_STRIDE / 2] = 0u; // the logic launch's ticket counter
     }
     for (uint32_t i = threadIdx.x; i < p.zero_rounds * WF_HEADS; i += BLOCK_THREADS) p.heads[(size_t)i * WF_HEAD_STRIDE] = 0u;
   }
@@ -2346,7 +2386,7 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
   const bool wide = count == 0 && p.scene.quads != nullptr && kernel < WF_K_KINDS && ((p.wide >> kernel) & 1u) != 0u;
   if (kernel == WF_K_TRACE) {
     // persistent: the grid only has to fill the machine; the pool heads balance the work
-    uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * 8u);
+    uint32_t grid = min((total + BLOCK_THREADS - 1) / BLOCK_THREADS, (uint32_t)num_cus * WF_TRACE_GRID_PER_CU);
     size_t lds = stack_bytes(p.scene) + (size_t)4 * WAVES_PER_BLOCK * WAVE * sizeof(int); // + four entries per lane (k_wf_trace: the kept shadow result, the extension ray's direction)
     // LDS left over per block at the occupancy the stacks (and the registers: 7 blocks) allow -> top-of-tree cache
     WfP q = p;
@@ -2395,7 +2435,7 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
   } else if (kernel == WF_K_LOGIC || kernel == WF_K_PRIMARY) {
     // resident blocks per CU at WF_LOGIC_WAVES waves per SIMD (4 SIMDs): 2 blocks of 512 threads at 4 waves; twice that many in flight
     const uint32_t threads = kernel == WF_K_PRIMARY ? (uint32_t)WF_PRIMARY_THREADS : (uint32_t)WF_LOGIC_THREADS;
-    const uint32_t blocks_per_cu = 2u * ((uint32_t)WF_LOGIC_WAVES * 4u * WAVE / threads);
+    const uint32_t blocks_per_cu = WF_PL_OVERSUB * ((uint32_t)WF_LOGIC_WAVES * 4u * WAVE / threads);
     const uint32_t prim_r = p.primary_r >= 2u ? 2u : 1u;
     const uint32_t per_block = kernel == WF_K_PRIMARY ? threads * prim_r : threads;
     uint32_t grid = min((total + per_block - 1) / per_block, (uint32_t)num_cus * blocks_per_cu);
