@@ -1577,14 +1577,16 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
   float4 *s_ray = reinterpret_cast<float4 *>(lds_tab + (LDSTAB ? wf_table_bytes(S.n_tex_sets, S.n_bins, p.n_batch) / 4u : 0u));
 
   uint32_t par = 0;
-  // Block iterations are handed out by TICKET (batch scheduler; the counter is pool head 0 of the unused round 0, cleared
-  // with the others behind every batch): a block's first iteration is its own index, every further one comes from the
+  // Block iterations are handed out by TICKET (the counter is the second line of pool-head slot 1 of this round /
+  // iteration - the trace launch uses the first word of each slot -, cleared with the heads: by the resolve launch behind
+  // every batch, by k_wf_plan one iteration ahead in a stream run): a block's first iteration is its own index, every further one comes from the
   // counter - blocks whose pixels were cheap take more of them, and the launch ends within one iteration's time of its
   // last block instead of with the slowest block's whole static share (the grid is twice what is resident: with static
   // shares the second half only started when blocks of the first had finished theirs).  70 k triangles: 0.126 -> 0.113
   // ms per tick, 1 M: 0.180 -> 0.145 (profiles/r05/ab_primary_tickets_*.log).  (The first iteration by ticket as well:
   // no different at 20 ticks, single-tick primary 0.23 -> 0.27, ab_first_ticket_*.log.)
-  const bool tickets = WF_PRIMARY_TICKETS && p.ctl == nullptr;
+  const bool tickets = WF_PRIMARY_TICKETS != 0;
+  uint32_t *ticket = p.heads + ((size_t)p.cnt_out * WF_HEADS + 1u) * WF_HEAD_STRIDE + WF_HEAD_STRIDE / 2;
   uint32_t it = blockIdx.x, it_next = 0;
   for (uint32_t base; (unsigned long long)it * SPAN < (unsigned long long)n_in; it = it_next, par ^= 1u) {
     base = it * SPAN;
@@ -1700,7 +1702,7 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
       const uint32_t tot = s_off[par];
       s_base[par] = tot ? atomicAdd(&cn->n_ext, tot) : 0u;
       s_off[par ^ 1u] = 0u;
-      if (tickets) s_next[par] = gridDim.x + atomicAdd(p.heads, 1u);
+      if (tickets) s_next[par] = gridDim.x + atomicAdd(ticket, 1u);
     }
     __syncthreads();
     if (tickets) it_next = __builtin_amdgcn_readfirstlane(s_next[par]);
@@ -1787,9 +1789,9 @@ __global__ __launch_bounds__(WF_LOGIC_THREADS, WF_LOGIC_WAVES) void k_wf_logic(c
   uint32_t u_eff = (n_in + n_blocks * WF_LOGIC_THREADS - 1) / (n_blocks * WF_LOGIC_THREADS);
   u_eff = u_eff < 1u ? 1u : (u_eff > (uint32_t)U ? (uint32_t)U : u_eff);
   const uint32_t span = u_eff * WF_LOGIC_THREADS;
-  // block iterations by ticket, as in k_wf_primary (batch scheduler): the counter is the second line of this round's
-  // first pool-head slot (the trace launch of the round uses the first word of each slot), cleared with the heads
-  const bool tickets = WF_LOGIC_TICKETS && p.ctl == nullptr;
+  // block iterations by ticket, as in k_wf_primary: the counter is the second line of this round's (iteration's) first
+  // pool-head slot, cleared with the heads
+  const bool tickets = WF_LOGIC_TICKETS != 0;
   uint32_t *ticket = p.heads + (size_t)p.cnt_out * WF_HEADS * WF_HEAD_STRIDE + WF_HEAD_STRIDE / 2;
   uint32_t it_next = 0;
   for (uint32_t it = blockIdx.x; (unsigned long long)it * span < (unsigned long long)n_in; it = it_next) {
@@ -2102,9 +2104,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
       if (p.live_out) p.live_out[r] = p.counts[r].n_ext;
       p.counts[r].n_ext = 0u;
       p.counts[r].n_susp = 0u;
-      p.heads[(size_t)r * WF_HEADS * WF_HEAD_STRIDE + WF_HEAD_STRIDE / 2] = 0u; // the logic launch's ticket counter
     }
-    for (uint32_t i = threadIdx.x; i < p.zero_rounds * WF_HEADS; i += BLOCK_THREADS) p.heads[(size_t)i * WF_HEAD_STRIDE] = 0u;
+    for (uint32_t i = threadIdx.x; i < p.zero_rounds * WF_HEADS; i += BLOCK_THREADS) {
+      p.heads[(size_t)i * WF_HEAD_STRIDE] = 0u;
+      p.heads[(size_t)i * WF_HEAD_STRIDE + WF_HEAD_STRIDE / 2] = 0u; // (slots 0 / 1 of a round: the logic / primary launch's ticket counters)
+    }
   }
   for (uint32_t ub = u0 + blockIdx.x * WAVES_PER_BLOCK; ub < u1; ub += gridDim.x * WAVES_PER_BLOCK) { // block-uniform trip count
     const uint32_t unit = ub + (uint32_t)wave;
@@ -2148,7 +2152,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_wf_resolve(const WfP p) {
 __global__ __launch_bounds__(WAVE) void k_wf_plan(const WfP p) {
   WfStreamCtl *c = p.ctl;
   const uint32_t nxt = (p.cnt_out + 1u) % WF_RING;
-  if (threadIdx.x < WF_HEADS) p.heads[((size_t)nxt * WF_HEADS + threadIdx.x) * WF_HEAD_STRIDE] = 0u;
+  if (threadIdx.x < WF_HEADS) {
+    p.heads[((size_t)nxt * WF_HEADS + threadIdx.x) * WF_HEAD_STRIDE] = 0u;
+    p.heads[((size_t)nxt * WF_HEADS + threadIdx.x) * WF_HEAD_STRIDE + WF_HEAD_STRIDE / 2] = 0u; // ticket counters of primary(i + 1), logic(i + 1)
+  }
   if (threadIdx.x != 0) return;
   p.counts[nxt].n_ext = 0u;
   p.counts[nxt].n_susp = 0u;
