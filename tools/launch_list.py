@@ -5,7 +5,12 @@ import csv, glob, re, sys
 d = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = []
-for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+import os
+files = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
+newest = max(os.path.getmtime(f) for f in files)  # (a directory merged over several sessions holds older runs' traces too)
+for f in files:
+    if newest - os.path.getmtime(f) > 60:
+        continue
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
