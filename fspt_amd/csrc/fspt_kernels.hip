@@ -1018,6 +1018,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 #ifndef WF_TRACE_GRID_PER_CU
 #define WF_TRACE_GRID_PER_CU 8u
 #endif
+// ... and the trace grid capped at what is resident (blocks per CU the registers allow; 0 = no cap): trace launches -2.5 %
+// on the 70 k scene (20 ticks), -0.7 % (128 ticks), +-0 on the 1 M one (profiles/r05/ab_trace_grid_resident_*.log)
+#ifndef WF_TRACE_GRID_RESIDENT
+#define WF_TRACE_GRID_RESIDENT 6
+#endif
 #ifndef WF_PL_OVERSUB
 #define WF_PL_OVERSUB 2u
 #endif
@@ -2407,6 +2412,12 @@ hipError_t launch_wf(int kernel, const WfP &p, int count, int num_cus, hipStream
       uint32_t fit = (uint32_t)(spare / rec);
       q.lds_top = WF_TRACE_LDS_TOP ? min(min(fit, p.scene.n_top), (uint32_t)WF_TRACE_LDS_TOP) : 0u;
       lds += (size_t)q.lds_top * rec;
+#if WF_TRACE_GRID_RESIDENT
+      // no more blocks than are resident at once (the registers allow WF_TRACE_GRID_RESIDENT per CU, the stacks `blocks`):
+      // every wave's first chunk of paths is its own, and a block that only starts when another has run out of work would
+      // keep its waves' first chunks back until the end of the launch
+      grid = min(grid, (uint32_t)num_cus * min((uint32_t)blocks, (uint32_t)WF_TRACE_GRID_RESIDENT));
+#endif
     }
 #define FSPT_LAUNCH_TRACE(C, A, Wd)                                                                        \
     do {                                                                                                     \
