@@ -788,6 +788,13 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
                                                 "lane) from an L2-resident table at this kernel's occupancy, measured in this run on this box",
                                           "peak_source": l1_src},
                         "requests_per_launch": round(tr_req * steps / max(1, d_n))}
+            nf = [int(x) for x in args.node_form.split(",")] if args.node_form else []
+            if len(nf) > 1 and (nf[1] == 1 or (len(nf) > 3 and nf[3] > 0)):
+                # two-level trace launches fetch 8 requests per round trip covering 1-2 steps: the count above (4 per
+                # interior step) does not describe them - no fraction rather than a wrong one (A/B runs only)
+                roofline.update({"frac": None, "frac_range": None, "frac_vs_l1_microbench": None,
+                                 "note": "--node-form selects two-level nodes for trace launches: lane-requests are not 4 per interior step there, no fraction is priced"})
+
         else:
             roofline = {"bound": "hbm", "achieved": dom["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(dom["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": dom["traffic_bytes_per_launch"],

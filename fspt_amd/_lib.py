@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FSPT_LIB") or os.path.join(_HERE, "libfspt.so")  # FSPT_LIB: A/B builds of the same ABI
+ABI_VERSION = 4  # include/fspt.h FSPT_ABI_VERSION this binding was written against (tests/test_abi.py pins the two)
 
 
 class FsptError(RuntimeError):
@@ -156,6 +157,8 @@ SIGNATURES = {
     "fspt_builder_autofocus": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fspt_builder_get": (C.c_int, [_VP, _F, _F, _F, _F, _F]),
     "fspt_env_bins": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, _U32, C.c_uint32, _U32]),
+    "fspt_multi_last_stage_ms": (C.c_int, [_VP, _F, C.c_uint32]),
+    "fspt_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fspt_last_error": (C.c_char_p, []),
     "fspt_abi_version": (C.c_int, []),
     "fspt_device_count": (C.c_int, []),
@@ -191,6 +194,14 @@ def lib():
             raise FsptError(-100, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         _share_hip_runtime_with_torch()
         l = C.CDLL(LIB_PATH)
+        try:
+            l.fspt_abi_version.restype = C.c_int
+            have = l.fspt_abi_version()
+        except AttributeError:
+            have = None
+        if have != ABI_VERSION:
+            raise FsptError(-101, f"{LIB_PATH} has ABI version {have}, this binding needs {ABI_VERSION}: stale build - "
+                                  "run `python -c 'import __graft_entry__ as g; g.build()'`")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = res

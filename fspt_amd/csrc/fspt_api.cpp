@@ -73,6 +73,16 @@ int fspt_device_count(void) {
   return n;
 }
 
+int fspt_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+  if (!free_bytes || !total_bytes) { fspt_set_error("fspt_device_memory: NULL argument"); return FSPT_E_INVALID; }
+  if (fspt_device_count() <= 0) { fspt_set_error("fspt_device_memory: no HIP device"); return FSPT_E_NO_DEVICE; }
+  size_t f = 0, t = 0;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  *free_bytes = f; *total_bytes = t;
+  return FSPT_OK;
+}
+
 float fspt_rand_base_next(uint64_t *state) {
   uint64_t x = *state;
   x ^= x >> 12;
@@ -767,8 +777,16 @@ int fspt_trace(fspt_target *t, uint32_t tick, float rand_base, float env_theta, 
     cp.env_theta = env_theta; cp.num_bounces = num_bounces;
     t->ev_used = 0; t->ev_overflow = false;
     HIP_TRY(hipEventRecord(t->ev0, t->stream));
-    int rc = t->sched == 1 ? render_stream(t, &cp, tick, 1, nullptr, &rand_base, true)
-                           : render_wavefront(t, &cp, tick, 1, nullptr, &rand_base, true);
+    int rc;
+    if (t->sched == 1 || t->stream_fallback) {
+      rc = render_stream(t, &cp, tick, 1, nullptr, &rand_base, true);
+    } else {
+      rc = render_wavefront(t, &cp, tick, 1, nullptr, &rand_base, true);
+      if (rc == FSPT_E_NOMEM) { // as in render_ticks: the bounded pool when the batch scheduler's path state does not fit
+        t->stream_fallback = true;
+        rc = render_stream(t, &cp, tick, 1, nullptr, &rand_base, true);
+      }
+    }
     if (rc) return rc;
     HIP_TRY(hipEventRecord(t->ev1, t->stream));
     t->timed = true; t->last_launches = 1;

@@ -2,6 +2,7 @@
 // device traces every n-th 32x32 tile, the read-out gathers the tiles on devices[0].
 #include "fspt_internal.hpp"
 
+#include <array>
 #include <dlfcn.h>
 
 // ---------------------------------------------------------------------------
@@ -52,6 +53,20 @@ int rccl_load() {
     ncclResult_t r_ = (expr);                                                                                 \
     if (r_ != 0) { fspt_set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); return FSPT_E_HIP; } \
   } while (0)
+// first error inside an ncclGroupStart / ncclGroupEnd section (nothing may return in between)
+struct GroupErr {
+  int code = 0; // 0 none, 1 HIP, 2 RCCL
+  int value = 0;
+  const char *what = "";
+  bool ok() const { return code == 0; }
+  void hip(hipError_t e, const char *w) { if (!code && e != hipSuccess) { code = 1; value = (int)e; what = w; } }
+  void nccl(ncclResult_t r, const char *w) { if (!code && r != 0) { code = 2; value = r; what = w; } }
+  int report() const {
+    if (code == 1) fspt_set_error("%s failed inside an RCCL group: %s", what, hipGetErrorString((hipError_t)value));
+    else fspt_set_error("%s failed: %s", what, g_rccl.GetErrorString(value));
+    return FSPT_E_HIP;
+  }
+};
 } // namespace
 
 extern "C" {
@@ -73,7 +88,20 @@ struct fspt_multi {
   int exchange = FSPT_EXCHANGE_PEER_COPY;
   std::vector<ncclComm_t> comms;  // RCCL modes: one rank per device (ncclCommInitAll)
   std::vector<float4 *> frame;    // RCCL_REDUCE: per device a full frame that is zero outside its own tiles
+  // fspt_multi_last_stage_ms: per device, events around the stages of the most recent read-out - on the device's own
+  // stream: [0] before its pack kernel(s), [1] behind them, [2] behind its copy / send / reduce; on devices[0]'s stream:
+  // [3] before, [4] behind the scatter of its tiles.  (Created with the handle; recording one costs about a microsecond.)
+  std::vector<std::array<hipEvent_t, 5>> stage_ev;
+  std::vector<std::array<bool, 5>> stage_set;
 };
+
+static int stage_mark(fspt_multi *m, size_t i, int k, hipStream_t s) {
+  if (i >= m->stage_ev.size() || !m->stage_ev[i][k]) return FSPT_OK;
+  HIP_TRY(hipEventRecord(m->stage_ev[i][k], s));
+  m->stage_set[i][k] = true;
+  return FSPT_OK;
+}
+#define STAGE_MARK(i, k, s) do { int rc_ = stage_mark(m, (i), (k), (s)); if (rc_) return rc_; } while (0)
 
 static void multi_pack_params(fspt_target *t, fspt::TilePackP &q) {
   fspt::TraceP tp{};
@@ -94,6 +122,9 @@ int fspt_multi_destroy(fspt_multi *m) {
     if (i < m->arrived.size() && m->arrived[i]) { hipSetDevice(m->devices[i]); hipEventDestroy(m->arrived[i]); }
   }
   for (size_t i = 0; i < m->frame.size(); ++i) if (m->frame[i]) { hipSetDevice(m->devices[i]); hipFree(m->frame[i]); }
+  for (size_t i = 0; i < m->stage_ev.size(); ++i)
+    for (int k = 0; k < 5; ++k)
+      if (m->stage_ev[i][k]) { hipSetDevice(m->devices[k < 3 ? i : 0]); hipEventDestroy(m->stage_ev[i][k]); }
   for (ncclComm_t c : m->comms) if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
   for (fspt_target *t : m->targets) fspt_target_destroy(t);
   for (fspt_scene *s : m->scenes) fspt_scene_destroy(s);
@@ -108,6 +139,8 @@ int fspt_multi_create(const fspt_scene_desc *desc, const int *devices, uint32_t 
   m->W = W; m->H = H;
   m->devices.assign(devices, devices + n_devices);
   m->packed.assign(n_devices, nullptr); m->staging.assign(n_devices, nullptr); m->arrived.assign(n_devices, nullptr); m->peer_direct.assign(n_devices, 3);
+  m->stage_ev.assign(n_devices, std::array<hipEvent_t, 5>{{nullptr, nullptr, nullptr, nullptr, nullptr}});
+  m->stage_set.assign(n_devices, std::array<bool, 5>{{false, false, false, false, false}});
   int rc = FSPT_OK;
   for (uint32_t i = 0; i < n_devices && rc == FSPT_OK; ++i) {
     // one scene copy per DISTINCT device (a device listed twice shares it)
@@ -117,6 +150,13 @@ int fspt_multi_create(const fspt_scene_desc *desc, const int *devices, uint32_t 
     fspt_target *t = nullptr;
     if (rc == FSPT_OK) rc = fspt_target_create(s, W, H, &t);
     if (rc == FSPT_OK) { m->targets.push_back(t); rc = fspt_target_set_shard(t, i, n_devices, 32); }
+    if (rc == FSPT_OK) {
+      for (int k = 0; k < 5 && rc == FSPT_OK; ++k) {
+        hipError_t e = hipSetDevice(devices[k < 3 ? i : 0]);
+        if (e == hipSuccess) e = hipEventCreate(&m->stage_ev[i][k]);
+        if (e != hipSuccess) { fspt_set_error("fspt_multi_create: %s", hipGetErrorString(e)); rc = FSPT_E_HIP; }
+      }
+    }
     if (rc == FSPT_OK && i > 0) {
       fspt::TilePackP q{};
       multi_pack_params(t, q);
@@ -184,7 +224,12 @@ int fspt_multi_set_exchange(fspt_multi *m, int mode) {
     if (rc) return rc;
     for (fspt_target *t : m->targets) { int rc_ = fspt_sync(t); if (rc_) return rc_; }
     std::vector<ncclComm_t> comms(m->devices.size(), nullptr);
-    NCCL_TRY(g_rccl.CommInitAll(comms.data(), (int)m->devices.size(), m->devices.data()));
+    const ncclResult_t r = g_rccl.CommInitAll(comms.data(), (int)m->devices.size(), m->devices.data());
+    if (r != 0) {
+      for (ncclComm_t c : comms) if (c) (void)g_rccl.CommDestroy(c); // whatever it had created before it failed
+      fspt_set_error("ncclCommInitAll failed: %s", g_rccl.GetErrorString(r));
+      return FSPT_E_HIP;
+    }
     m->comms = comms;
   }
   m->exchange = mode;
@@ -211,25 +256,38 @@ static int multi_gather_rccl(fspt_multi *m) {
     if (!count[i]) continue;
     HIP_TRY(hipSetDevice(m->devices[i]));
     q.accum = t->accum; q.packed = m->packed[i];
+    STAGE_MARK(i, 0, t->stream);
     HIP_TRY(fspt::launch_tile_pack(q, false, t->stream));
+    STAGE_MARK(i, 1, t->stream);
     m->gather_bytes += count[i] * 4u;
   }
+  // Inside the group nothing returns: the first error is kept, ncclGroupEnd is ALWAYS called (an open group would stall
+  // the host's own later collectives - the library prefers the librccl the process has already loaded), then reported.
   NCCL_TRY(g_rccl.GroupStart());
+  GroupErr ge;
+  for (size_t i = 1; i < m->targets.size() && ge.ok(); ++i) {
+    if (!count[i]) continue;
+    ge.hip(hipSetDevice(m->devices[i]), "hipSetDevice");
+    if (ge.ok()) ge.nccl(g_rccl.Send(m->packed[i], count[i], NCCL_FLOAT32, 0, m->comms[i], m->targets[i]->stream), "ncclSend");
+    if (ge.ok()) ge.hip(hipSetDevice(m->devices[0]), "hipSetDevice");
+    if (ge.ok()) ge.nccl(g_rccl.Recv(m->staging[i], count[i], NCCL_FLOAT32, (int)i, m->comms[0], t0->stream), "ncclRecv");
+  }
+  ge.nccl(g_rccl.GroupEnd(), "ncclGroupEnd");
+  if (!ge.ok()) return ge.report();
   for (size_t i = 1; i < m->targets.size(); ++i) {
     if (!count[i]) continue;
     HIP_TRY(hipSetDevice(m->devices[i]));
-    NCCL_TRY(g_rccl.Send(m->packed[i], count[i], NCCL_FLOAT32, 0, m->comms[i], m->targets[i]->stream));
-    HIP_TRY(hipSetDevice(m->devices[0]));
-    NCCL_TRY(g_rccl.Recv(m->staging[i], count[i], NCCL_FLOAT32, (int)i, m->comms[0], t0->stream));
+    STAGE_MARK(i, 2, m->targets[i]->stream);
   }
-  NCCL_TRY(g_rccl.GroupEnd());
   HIP_TRY(hipSetDevice(m->devices[0]));
   for (size_t i = 1; i < m->targets.size(); ++i) {
     if (!count[i]) continue;
     fspt::TilePackP q{};
     multi_pack_params(m->targets[i], q);
     q.accum = t0->accum; q.packed = m->staging[i];
+    STAGE_MARK(i, 3, t0->stream);
     HIP_TRY(fspt::launch_tile_pack(q, true, t0->stream));
+    STAGE_MARK(i, 4, t0->stream);
   }
   return FSPT_OK;
 }
@@ -249,6 +307,7 @@ static int multi_reduce_rccl(fspt_multi *m) {
     const size_t bytes = (size_t)q.n_owned_tiles * q.tile * q.tile * sizeof(float4);
     if (!m->frame[i]) HIP_TRY(hipMalloc((void **)&m->frame[i], px * sizeof(float4)));
     if (!m->packed[i]) HIP_TRY(hipMalloc((void **)&m->packed[i], bytes ? bytes : 16)); // (devices[0] has none from fspt_multi_create)
+    STAGE_MARK(i, 0, t->stream);
     HIP_TRY(hipMemsetAsync(m->frame[i], 0, px * sizeof(float4), t->stream));
     if (bytes) {
       q.accum = t->accum; q.packed = m->packed[i];
@@ -256,16 +315,25 @@ static int multi_reduce_rccl(fspt_multi *m) {
       q.accum = m->frame[i];
       HIP_TRY(fspt::launch_tile_pack(q, true, t->stream));
     }
+    STAGE_MARK(i, 1, t->stream);
     if (i) m->gather_bytes += px * sizeof(float4);
   }
   NCCL_TRY(g_rccl.GroupStart());
+  GroupErr ge; // (as in multi_gather_rccl: no return between GroupStart and GroupEnd)
+  for (size_t i = 0; i < m->targets.size() && ge.ok(); ++i) {
+    ge.hip(hipSetDevice(m->devices[i]), "hipSetDevice");
+    if (ge.ok()) ge.nccl(g_rccl.Reduce(m->frame[i], m->frame[i], px * 4u, NCCL_FLOAT32, NCCL_SUM, 0, m->comms[i], m->targets[i]->stream), "ncclReduce");
+  }
+  ge.nccl(g_rccl.GroupEnd(), "ncclGroupEnd");
+  if (!ge.ok()) return ge.report();
   for (size_t i = 0; i < m->targets.size(); ++i) {
     HIP_TRY(hipSetDevice(m->devices[i]));
-    NCCL_TRY(g_rccl.Reduce(m->frame[i], m->frame[i], px * 4u, NCCL_FLOAT32, NCCL_SUM, 0, m->comms[i], m->targets[i]->stream));
+    STAGE_MARK(i, 2, m->targets[i]->stream);
   }
-  NCCL_TRY(g_rccl.GroupEnd());
   HIP_TRY(hipSetDevice(m->devices[0]));
+  STAGE_MARK(0, 3, m->targets[0]->stream);
   HIP_TRY(hipMemcpyAsync(m->targets[0]->accum, m->frame[0], px * sizeof(float4), hipMemcpyDeviceToDevice, m->targets[0]->stream));
+  STAGE_MARK(0, 4, m->targets[0]->stream);
   return FSPT_OK;
 }
 
@@ -273,6 +341,7 @@ static int multi_reduce_rccl(fspt_multi *m) {
 static int multi_gather(fspt_multi *m) {
   fspt_target *t0 = m->targets[0];
   m->gather_bytes = 0;
+  for (auto &f : m->stage_set) f = {{false, false, false, false, false}};
   for (fspt_target *t : m->targets) FLUSH_OR_RETURN(t); // recorded two-call ticks of every device run before its tiles are packed
   if (m->exchange == FSPT_EXCHANGE_RCCL_GATHER) return multi_gather_rccl(m);
   if (m->exchange == FSPT_EXCHANGE_RCCL_REDUCE) return multi_reduce_rccl(m);
@@ -284,8 +353,11 @@ static int multi_gather(fspt_multi *m) {
     if (!bytes) continue;
     HIP_TRY(hipSetDevice(m->devices[i]));
     q.accum = t->accum; q.packed = m->packed[i];
+    STAGE_MARK(i, 0, t->stream);
     HIP_TRY(fspt::launch_tile_pack(q, false, t->stream));
+    STAGE_MARK(i, 1, t->stream);
     HIP_TRY(hipMemcpyPeerAsync(m->staging[i], m->devices[0], m->packed[i], m->devices[i], bytes, t->stream));
+    STAGE_MARK(i, 2, t->stream);
     HIP_TRY(hipEventRecord(m->arrived[i], t->stream));
     m->gather_bytes += bytes;
   }
@@ -296,7 +368,9 @@ static int multi_gather(fspt_multi *m) {
     if (!q.n_owned_tiles) continue;
     HIP_TRY(hipStreamWaitEvent(t0->stream, m->arrived[i], 0));
     q.accum = t0->accum; q.packed = m->staging[i];
+    STAGE_MARK(i, 3, t0->stream);
     HIP_TRY(fspt::launch_tile_pack(q, true, t0->stream));
+    STAGE_MARK(i, 4, t0->stream);
   }
   return FSPT_OK;
 }
@@ -368,6 +442,30 @@ int fspt_multi_size(fspt_multi *m, uint32_t *W, uint32_t *H) {
 int fspt_multi_peer_access(fspt_multi *m, uint32_t i, int *mask) {
   if (!m || !mask || i >= m->targets.size()) { fspt_set_error("fspt_multi_peer_access: bad argument"); return FSPT_E_INVALID; }
   *mask = m->peer_direct[i];
+  return FSPT_OK;
+}
+
+int fspt_multi_last_stage_ms(fspt_multi *m, float *ms, uint32_t n_devices) {
+  if (!m || !ms || n_devices != m->targets.size()) { fspt_set_error("fspt_multi_last_stage_ms: bad argument (ms[n_devices][4])"); return FSPT_E_INVALID; }
+  for (size_t i = 0; i < m->targets.size(); ++i) {
+    float *o = ms + 4 * i;
+    o[0] = o[1] = o[2] = o[3] = -1.0f;
+    fspt_target *t = m->targets[i];
+    HIP_TRY(hipSetDevice(m->devices[i]));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    uint32_t launches = 0;
+    float render = 0.0f;
+    if (fspt_last_kernel_ms(t, &render, &launches) == FSPT_OK) o[0] = render;
+    const auto &e = m->stage_ev[i];
+    const auto &f = m->stage_set[i];
+    if (f[0] && f[1]) HIP_TRY(hipEventElapsedTime(&o[1], e[0], e[1]));
+    if (f[1] && f[2]) HIP_TRY(hipEventElapsedTime(&o[2], e[1], e[2]));
+    if (f[3] && f[4]) {
+      HIP_TRY(hipSetDevice(m->devices[0]));
+      HIP_TRY(hipStreamSynchronize(m->targets[0]->stream));
+      HIP_TRY(hipEventElapsedTime(&o[3], e[3], e[4]));
+    }
+  }
   return FSPT_OK;
 }
 

@@ -23,6 +23,9 @@
  *   multiCreate(sceneDesc, [devices], W, H) -> multi handle; multiCamera / multiTrace / multiRender / multiRenderAsync /
  *   multiClear / multiSync / multiReadRadiance / multiDraw / multiTarget(multi, i) / multiDestroy   (fspt_multi_*: one frame
  *   over several GPUs from this one JS thread, tiles gathered onto the first device at read-out)
+ *   multiSetExchange / multiGetExchange / multiLastStageMs(multi, nDevices) -> Float32Array(nDevices * 4)
+ * Handles are napi externals with finalizers (a dropped tracer frees its device memory when it is collected), and while
+ * a renderAsync job runs every other call on its target / multi throws Error('render in flight') - see "handles" below.
  *   enableCounters(target, on) / counters(target) -> object
  *   builderCreate / builderParseObj / builderCommit / builderNormalize / builderBuild / builderAutofocus /
  *   builderDestroy                                                   (native obj_loader.js + bvh.js, 1:1 fspt_builder_*)
@@ -129,11 +132,94 @@ static int float_list(napi_env env, napi_value arr, float *out, uint32_t n) {
   }
   return 0;
 }
-static int unwrap(napi_env env, napi_value v, void **out) {
-  if (napi_get_value_external(env, v, out) != napi_ok || !*out) {
-    napi_throw_type_error(env, NULL, "fspt_napi: expected a handle");
+/* ---------------------------------------------------------------- handles
+ * A handle is an napi external around a small box, not the bare library pointer:
+ *   - the box knows what it holds, so a scene passed where a target is expected is a TypeError, not a crash;
+ *   - `busy` counts the renderAsync jobs in flight on it: while a libuv worker is inside fspt_render, every other addon
+ *     call on that target / multi (readRadiance, tick, clear, destroy, ...) throws Error('render in flight') instead
+ *     of racing the worker (the library's contract is one thread at a time per target, include/fspt.h; the reference's
+ *     tick() is single-threaded, main.js:838-857).  Set and cleared on the JS thread only;
+ *   - the external has a finalizer: a tracer that is dropped without close() gives its device memory back when the
+ *     JS object is collected (fspt_target_destroy waits for the target's stream first);
+ *   - a target keeps its scene alive (a strong reference to the scene's external), a multi's per-device target
+ *     (multiTarget) keeps the multi alive and dies with it; sceneDestroy refuses while targets of the scene exist. */
+enum { H_SCENE = 1, H_TARGET = 2, H_MULTI = 3, H_BUILDER = 4 };
+static const char *const kind_name[] = {"?", "scene", "target", "multi", "builder"};
+typedef struct fspt_handle {
+  int kind;
+  void *ptr;                   /* NULL once destroyed */
+  int owned;                   /* 0: a multi's per-device target: owned by the multi */
+  int busy;                    /* renderAsync jobs in flight on this handle (a target's job also counts on its scene) */
+  int children;                /* scene: live targets made from it */
+  struct fspt_handle *parent;  /* target -> scene box; multi's target -> multi box (valid while parent_ref is held) */
+  napi_ref parent_ref;
+} fspt_handle;
+
+static void handle_release(napi_env env, fspt_handle *b) {
+  if (b->ptr && b->owned) {
+    switch (b->kind) {
+      case H_SCENE: fspt_scene_destroy((fspt_scene *)b->ptr); break;
+      case H_TARGET: fspt_target_destroy((fspt_target *)b->ptr); break; /* waits for its stream, drops recorded ticks */
+      case H_MULTI: fspt_multi_destroy((fspt_multi *)b->ptr); break;
+      case H_BUILDER: fspt_builder_destroy((fspt_builder *)b->ptr); break;
+    }
+  }
+  b->ptr = NULL;
+  if (b->parent) {
+    if (b->kind == H_TARGET && b->owned && b->parent->children > 0) b->parent->children--;
+    b->parent = NULL;
+  }
+  if (b->parent_ref) { napi_delete_reference(env, b->parent_ref); b->parent_ref = NULL; }
+}
+static void handle_finalize(napi_env env, void *data, void *hint) {
+  (void)hint;
+  fspt_handle *b = (fspt_handle *)data;
+  handle_release(env, b); /* (never busy here: a job in flight holds a reference to the external) */
+  free(b);
+}
+/* parent_val / parent: the external and box this handle keeps alive (NULL: none) */
+static napi_value make_handle(napi_env env, int kind, void *ptr, int owned, napi_value parent_val, fspt_handle *parent) {
+  fspt_handle *b = (fspt_handle *)calloc(1, sizeof(fspt_handle));
+  napi_value ext;
+  if (!b) { napi_throw_error(env, NULL, "fspt_napi: out of memory"); return NULL; }
+  b->kind = kind; b->ptr = ptr; b->owned = owned; b->parent = parent;
+  if (parent && napi_create_reference(env, parent_val, 1, &b->parent_ref) != napi_ok) b->parent = NULL;
+  if (napi_create_external(env, b, handle_finalize, NULL, &ext) != napi_ok) {
+    handle_release(env, b); free(b);
+    napi_throw_error(env, NULL, "fspt_napi: napi_create_external failed");
+    return NULL;
+  }
+  if (b->parent && kind == H_TARGET && owned) b->parent->children++;
+  return ext;
+}
+static int handle_busy(const fspt_handle *b) { return b->busy || (!b->owned && b->parent && b->parent->busy); }
+static int unwrap_box(napi_env env, napi_value v, int kind, fspt_handle **out) {
+  void *d = NULL;
+  napi_valuetype vt;
+  if (napi_typeof(env, v, &vt) != napi_ok || vt != napi_external || napi_get_value_external(env, v, &d) != napi_ok || !d ||
+      ((fspt_handle *)d)->kind != kind) {
+    char msg[96];
+    snprintf(msg, sizeof msg, "fspt_napi: expected a %s handle", kind_name[kind]);
+    napi_throw_type_error(env, NULL, msg);
     return -1;
   }
+  fspt_handle *b = (fspt_handle *)d;
+  if (!b->ptr || (!b->owned && (!b->parent || !b->parent->ptr))) {
+    char msg[96];
+    snprintf(msg, sizeof msg, "fspt_napi: the %s handle was destroyed", kind_name[kind]);
+    napi_throw_error(env, NULL, msg);
+    return -1;
+  }
+  *out = b;
+  return 0;
+}
+/* the library pointer behind a handle; throws (and returns non-zero) on a wrong / destroyed handle and while a
+ * renderAsync job is in flight on it */
+static int unwrap_k(napi_env env, napi_value v, int kind, void **out) {
+  fspt_handle *b;
+  if (unwrap_box(env, v, kind, &b)) return -1;
+  if (handle_busy(b)) { napi_throw_error(env, NULL, "render in flight"); return -1; }
+  *out = b->ptr;
   return 0;
 }
 
@@ -185,38 +271,42 @@ static napi_value SceneCreate(napi_env env, napi_callback_info info) {
   napi_get_value_int32(env, a[1], &device);
   fspt_scene *s = NULL;
   FSPT_OK_OR_THROW(fspt_scene_create(&d, device, &s));
-  napi_value ext;
-  NAPI_OK(napi_create_external(env, s, NULL, NULL, &ext));
+  napi_value ext = make_handle(env, H_SCENE, s, 1, NULL, NULL);
+  if (!ext) fspt_scene_destroy(s);
   return ext;
 }
 static napi_value SceneDestroy(napi_env env, napi_callback_info info) {
-  napi_value a[1]; void *h;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
-  FSPT_OK_OR_THROW(fspt_scene_destroy((fspt_scene *)h));
+  napi_value a[1]; void *h; fspt_handle *hb;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_SCENE, &h) || unwrap_box(env, a[0], H_SCENE, &hb)) return NULL;
+  if (hb->children > 0) { napi_throw_error(env, NULL, "fspt_napi: the scene still has targets (destroy them first)"); return NULL; }
+  handle_release(env, hb);
   return undefined(env);
 }
 
 /* ----------------------------------------------------------------- target */
 static napi_value TargetCreate(napi_env env, napi_callback_info info) {
   napi_value a[3]; void *h; uint32_t W, H;
-  if (get_args(env, info, 3, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 3, a) || unwrap_k(env, a[0], H_SCENE, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &W));
   NAPI_OK(napi_get_value_uint32(env, a[2], &H));
   fspt_target *t = NULL;
+  fspt_handle *sb;
+  if (unwrap_box(env, a[0], H_SCENE, &sb)) return NULL;
   FSPT_OK_OR_THROW(fspt_target_create((fspt_scene *)h, W, H, &t));
-  napi_value ext;
-  NAPI_OK(napi_create_external(env, t, NULL, NULL, &ext));
+  napi_value ext = make_handle(env, H_TARGET, t, 1, a[0], sb);
+  if (!ext) fspt_target_destroy(t);
   return ext;
 }
 static napi_value TargetDestroy(napi_env env, napi_callback_info info) {
-  napi_value a[1]; void *h;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
-  FSPT_OK_OR_THROW(fspt_target_destroy((fspt_target *)h));
+  napi_value a[1]; void *h; fspt_handle *hb;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_TARGET, &h) || unwrap_box(env, a[0], H_TARGET, &hb)) return NULL;
+  if (!hb->owned) { napi_throw_error(env, NULL, "fspt_napi: a multi's per-device target is destroyed with the multi"); return NULL; }
+  handle_release(env, hb);
   return undefined(env);
 }
 static napi_value Camera(napi_env env, napi_callback_info info) {
   napi_value a[6]; void *h; float P[3], I[3], lens[2]; double fov, rb;
-  if (get_args(env, info, 6, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 6, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   if (float_list(env, a[1], P, 3) || float_list(env, a[2], I, 3) || get_f64(env, a[3], &fov) || float_list(env, a[4], lens, 2) ||
       get_f64(env, a[5], &rb)) return NULL;
   FSPT_OK_OR_THROW(fspt_camera((fspt_target *)h, P, I, (float)fov, lens, (float)rb));
@@ -225,7 +315,7 @@ static napi_value Camera(napi_env env, napi_callback_info info) {
 static napi_value TraceTest(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; uint32_t tick;
   if (get_args(env, info, 2, a)) return NULL;
-  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  if (unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &tick));
   FSPT_OK_OR_THROW(fspt_trace_test((fspt_target *)h, tick));
   return undefined(env);
@@ -235,7 +325,7 @@ static napi_value Trace(napi_env env, napi_callback_info info) {
   if (get_args(env, info, 5, a)) return NULL;
   /* scalars first: a bad numBounces is reported as such even when the handle is bad too */
   if (get_f64(env, a[2], &rb) || get_f64(env, a[3], &theta) || get_bounces(env, a[4], &nb)) return NULL;
-  if (unwrap(env, a[0], &h)) return NULL;
+  if (unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &tick));
   FSPT_OK_OR_THROW(fspt_trace((fspt_target *)h, tick, (float)rb, (float)theta, nb));
   return undefined(env);
@@ -275,7 +365,7 @@ static napi_value Render(napi_env env, napi_callback_info info) {
   if (get_args(env, info, 5, a)) return NULL;
   fspt_camera_params cp;
   if (parse_camera_params(env, a[1], &cp)) return NULL;
-  if (unwrap(env, a[0], &h)) return NULL;
+  if (unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[2], &first));
   NAPI_OK(napi_get_value_uint32(env, a[3], &n));
   if (parse_seed(env, a[4], &seed64)) return NULL;
@@ -290,6 +380,8 @@ static napi_value Render(napi_env env, napi_callback_info info) {
 typedef struct {
   napi_async_work work;
   napi_deferred deferred;
+  fspt_handle *box;      /* the handle the job runs on: busy until render_complete */
+  napi_ref box_ref;      /* keeps its external (and so the box and the target) alive while the worker runs */
   fspt_target *target;
   fspt_multi *multi;
   fspt_camera_params cp;
@@ -314,6 +406,8 @@ static void render_execute(napi_env env, void *data) {
 static void render_complete(napi_env env, napi_status status, void *data) {
   render_job *j = (render_job *)data;
   napi_value v;
+  /* the target is the JS thread's again BEFORE the promise settles (its reactions may call readRadiance at once) */
+  if (j->box) { j->box->busy--; if (j->box->kind == H_TARGET && j->box->owned && j->box->parent) j->box->parent->busy--; }
   if (status == napi_ok && j->rc == 0) {
     napi_get_undefined(env, &v);
     napi_resolve_deferred(env, j->deferred, v);
@@ -323,15 +417,16 @@ static void render_complete(napi_env env, napi_status status, void *data) {
     napi_create_error(env, NULL, msg, &v);
     napi_reject_deferred(env, j->deferred, v);
   }
+  if (j->box_ref) napi_delete_reference(env, j->box_ref);
   napi_delete_async_work(env, j->work);
   free(j);
 }
 static napi_value render_async(napi_env env, napi_callback_info info, int multi) {
-  napi_value a[5], promise, name; void *h; uint64_t seed64 = 0;
+  napi_value a[5], promise, name; fspt_handle *hb = NULL; uint64_t seed64 = 0;
   if (get_args(env, info, 5, a)) return NULL;
   render_job *j = (render_job *)calloc(1, sizeof(render_job));
   if (!j) { napi_throw_error(env, NULL, "fspt_napi: out of memory"); return NULL; }
-  if (parse_camera_params(env, a[1], &j->cp) || unwrap(env, a[0], &h) || parse_seed(env, a[4], &seed64) ||
+  if (parse_camera_params(env, a[1], &j->cp) || unwrap_box(env, a[0], multi ? H_MULTI : H_TARGET, &hb) || parse_seed(env, a[4], &seed64) ||
       napi_get_value_uint32(env, a[2], &j->first) != napi_ok || napi_get_value_uint32(env, a[3], &j->n) != napi_ok) {
     bool pending = false;
     napi_is_exception_pending(env, &pending);
@@ -339,16 +434,23 @@ static napi_value render_async(napi_env env, napi_callback_info info, int multi)
     free(j);
     return NULL;
   }
-  if (multi) j->multi = (fspt_multi *)h; else j->target = (fspt_target *)h;
+  if (handle_busy(hb)) { free(j); napi_throw_error(env, NULL, "render in flight"); return NULL; } /* one job at a time per target */
+  if (multi) j->multi = (fspt_multi *)hb->ptr; else j->target = (fspt_target *)hb->ptr;
   j->seed = seed64;
+  if (napi_create_reference(env, a[0], 1, &j->box_ref) != napi_ok) { free(j); napi_throw_error(env, NULL, "fspt_napi: napi_create_reference failed"); return NULL; }
   if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
       napi_create_string_utf8(env, "fspt_render", NAPI_AUTO_LENGTH, &name) != napi_ok ||
       napi_create_async_work(env, NULL, name, render_execute, render_complete, j, &j->work) != napi_ok ||
       napi_queue_async_work(env, j->work) != napi_ok) {
+    napi_delete_reference(env, j->box_ref);
     free(j);
     napi_throw_error(env, NULL, "fspt_napi: could not queue the async work");
     return NULL;
   }
+  /* from here until render_complete every other call on this handle throws 'render in flight' (unwrap_k) */
+  j->box = hb;
+  hb->busy++;
+  if (hb->kind == H_TARGET && hb->owned && hb->parent) hb->parent->busy++;
   return promise;
 }
 static napi_value RenderAsync(napi_env env, napi_callback_info info) { return render_async(env, info, 0); }
@@ -371,27 +473,26 @@ static napi_value MultiCreate(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_get_value_uint32(env, a[3], &H));
   fspt_multi *m = NULL;
   FSPT_OK_OR_THROW(fspt_multi_create(&d, devices, n, W, H, &m));
-  napi_value ext;
-  NAPI_OK(napi_create_external(env, m, NULL, NULL, &ext));
+  napi_value ext = make_handle(env, H_MULTI, m, 1, NULL, NULL);
+  if (!ext) fspt_multi_destroy(m);
   return ext;
 }
 static napi_value MultiDestroy(napi_env env, napi_callback_info info) {
-  napi_value a[1]; void *h;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
-  FSPT_OK_OR_THROW(fspt_multi_destroy((fspt_multi *)h));
+  napi_value a[1]; void *h; fspt_handle *hb;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_MULTI, &h) || unwrap_box(env, a[0], H_MULTI, &hb)) return NULL;
+  handle_release(env, hb); /* its per-device target handles (multiTarget) are dead from here on */
   return undefined(env);
 }
 static napi_value MultiTarget(napi_env env, napi_callback_info info) {
-  napi_value a[2], ext; void *h; uint32_t i; fspt_target *t = NULL;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  napi_value a[2]; void *h; uint32_t i; fspt_target *t = NULL; fspt_handle *mb;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_MULTI, &h) || unwrap_box(env, a[0], H_MULTI, &mb)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &i));
   FSPT_OK_OR_THROW(fspt_multi_target((fspt_multi *)h, i, &t));
-  NAPI_OK(napi_create_external(env, t, NULL, NULL, &ext));
-  return ext;
+  return make_handle(env, H_TARGET, t, 0, a[0], mb); /* borrowed: lives and dies with the multi */
 }
 static napi_value MultiCamera(napi_env env, napi_callback_info info) {
   napi_value a[6]; void *h; float P[3], I[3], lens[2]; double fov, rb;
-  if (get_args(env, info, 6, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 6, a) || unwrap_k(env, a[0], H_MULTI, &h)) return NULL;
   if (float_list(env, a[1], P, 3) || float_list(env, a[2], I, 3) || get_f64(env, a[3], &fov) || float_list(env, a[4], lens, 2) ||
       get_f64(env, a[5], &rb)) return NULL;
   FSPT_OK_OR_THROW(fspt_multi_camera((fspt_multi *)h, P, I, (float)fov, lens, (float)rb));
@@ -401,7 +502,7 @@ static napi_value MultiTrace(napi_env env, napi_callback_info info) {
   napi_value a[5]; void *h; uint32_t tick, nb; double rb, theta;
   if (get_args(env, info, 5, a)) return NULL;
   if (get_f64(env, a[2], &rb) || get_f64(env, a[3], &theta) || get_bounces(env, a[4], &nb)) return NULL;
-  if (unwrap(env, a[0], &h)) return NULL;
+  if (unwrap_k(env, a[0], H_MULTI, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &tick));
   FSPT_OK_OR_THROW(fspt_multi_trace((fspt_multi *)h, tick, (float)rb, (float)theta, nb));
   return undefined(env);
@@ -411,7 +512,7 @@ static napi_value MultiRender(napi_env env, napi_callback_info info) {
   if (get_args(env, info, 5, a)) return NULL;
   fspt_camera_params cp;
   if (parse_camera_params(env, a[1], &cp)) return NULL;
-  if (unwrap(env, a[0], &h)) return NULL;
+  if (unwrap_k(env, a[0], H_MULTI, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[2], &first));
   NAPI_OK(napi_get_value_uint32(env, a[3], &n));
   if (parse_seed(env, a[4], &seed64)) return NULL;
@@ -420,14 +521,14 @@ static napi_value MultiRender(napi_env env, napi_callback_info info) {
 }
 static napi_value MultiClear(napi_env env, napi_callback_info info) {
   napi_value a[1]; void *h;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_MULTI, &h)) return NULL;
   FSPT_OK_OR_THROW(fspt_multi_clear((fspt_multi *)h));
   return undefined(env);
 }
 /* multiSetExchange(multi, mode): 0 peer copies, 1 RCCL send / recv of the packed tiles, 2 RCCL sum-reduce (fspt_multi.h) */
 static napi_value MultiSetExchange(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; int32_t mode;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_MULTI, &h)) return NULL;
   NAPI_OK(napi_get_value_int32(env, a[1], &mode));
   FSPT_OK_OR_THROW(fspt_multi_set_exchange((fspt_multi *)h, mode));
   return undefined(env);
@@ -435,7 +536,7 @@ static napi_value MultiSetExchange(napi_env env, napi_callback_info info) {
 /* multiGetExchange(multi) -> {mode, rcclVersion} */
 static napi_value MultiGetExchange(napi_env env, napi_callback_info info) {
   napi_value a[1], o, v; void *h; int mode = 0, ver = 0;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_MULTI, &h)) return NULL;
   FSPT_OK_OR_THROW(fspt_multi_get_exchange((fspt_multi *)h, &mode, &ver));
   NAPI_OK(napi_create_object(env, &o));
   NAPI_OK(napi_create_int32(env, mode, &v));
@@ -444,9 +545,21 @@ static napi_value MultiGetExchange(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_set_named_property(env, o, "rcclVersion", v));
   return o;
 }
+/* multiLastStageMs(multi, nDevices) -> Float32Array(nDevices * 4): per device render / pack / transfer / scatter ms of the
+ * most recent render + read-out (fspt_multi_last_stage_ms, include/fspt_multi.h; -1 = the stage did not run) */
+static napi_value MultiLastStageMs(napi_env env, napi_callback_info info) {
+  napi_value a[2], ab, ta; void *h, *data; uint32_t n;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_MULTI, &h)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &n));
+  if (n == 0 || n > 64) { napi_throw_range_error(env, NULL, "fspt_napi: nDevices must be 1..64"); return NULL; }
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 16, &data, &ab));
+  NAPI_OK(napi_create_typedarray(env, napi_float32_array, (size_t)n * 4, ab, 0, &ta));
+  FSPT_OK_OR_THROW(fspt_multi_last_stage_ms((fspt_multi *)h, (float *)data, n));
+  return ta;
+}
 static napi_value MultiSync(napi_env env, napi_callback_info info) {
   napi_value a[1]; void *h;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_MULTI, &h)) return NULL;
   FSPT_OK_OR_THROW(fspt_multi_sync((fspt_multi *)h));
   return undefined(env);
 }
@@ -470,14 +583,14 @@ static int check_multi_len(napi_env env, void *h, size_t n) {
 }
 static napi_value MultiReadRadiance(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h, *p; size_t n;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h) || typed(env, a[1], napi_float32_array, 0, &p, &n)) return NULL;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_MULTI, &h) || typed(env, a[1], napi_float32_array, 0, &p, &n)) return NULL;
   if (check_multi_len(env, h, n)) return NULL;
   FSPT_OK_OR_THROW(fspt_multi_read_radiance((fspt_multi *)h, (float *)p));
   return a[1];
 }
 static napi_value MultiDraw(napi_env env, napi_callback_info info) {
   napi_value a[6]; void *h, *p; size_t n; double ex, sat, sig; bool den;
-  if (get_args(env, info, 6, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 6, a) || unwrap_k(env, a[0], H_MULTI, &h)) return NULL;
   if (get_f64(env, a[1], &ex) || get_f64(env, a[2], &sat)) return NULL;
   NAPI_OK(napi_get_value_bool(env, a[3], &den));
   if (get_f64(env, a[4], &sig) || typed(env, a[5], napi_uint8_array, 0, &p, &n)) return NULL;
@@ -487,14 +600,14 @@ static napi_value MultiDraw(napi_env env, napi_callback_info info) {
 }
 static napi_value SetDeferred(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; bool on;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_bool(env, a[1], &on));
   FSPT_OK_OR_THROW(fspt_target_set_deferred((fspt_target *)h, on ? 1 : 0));
   return undefined(env);
 }
 static napi_value SetTail(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; int32_t r;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_int32(env, a[1], &r));
   FSPT_OK_OR_THROW(fspt_target_set_tail((fspt_target *)h, r));
   return undefined(env);
@@ -502,26 +615,26 @@ static napi_value SetTail(napi_env env, napi_callback_info info) {
 /* setStageTiming(target, on): the per-launch HIP event pairs behind fspt_last_stage_ms (fspt_tuning.h) */
 static napi_value SetStageTiming(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; bool on;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_bool(env, a[1], &on));
   FSPT_OK_OR_THROW(fspt_target_set_stage_timing((fspt_target *)h, on ? 1 : 0));
   return undefined(env);
 }
 static napi_value Clear(napi_env env, napi_callback_info info) {
   napi_value a[1]; void *h;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   FSPT_OK_OR_THROW(fspt_clear((fspt_target *)h));
   return undefined(env);
 }
 static napi_value Sync(napi_env env, napi_callback_info info) {
   napi_value a[1]; void *h;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   FSPT_OK_OR_THROW(fspt_sync((fspt_target *)h));
   return undefined(env);
 }
 static napi_value ReadRadiance(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h, *p; size_t n;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h) || typed(env, a[1], napi_float32_array, 0, &p, &n)) return NULL;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_TARGET, &h) || typed(env, a[1], napi_float32_array, 0, &p, &n)) return NULL;
   if (check_target_len(env, h, n)) return NULL;
   FSPT_OK_OR_THROW(fspt_read_radiance((fspt_target *)h, (float *)p));
   return a[1];
@@ -533,7 +646,7 @@ static napi_value Draw(napi_env env, napi_callback_info info) {
     napi_throw_type_error(env, NULL, "fspt_napi: wrong number of arguments");
     return NULL;
   }
-  if (unwrap(env, a[0], &h)) return NULL;
+  if (unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   if (get_f64(env, a[1], &ex) || get_f64(env, a[2], &sat)) return NULL;
   NAPI_OK(napi_get_value_bool(env, a[3], &den));
   if (get_f64(env, a[4], &sig) || typed(env, a[5], napi_uint8_array, 0, &p, &n)) return NULL;
@@ -544,7 +657,7 @@ static napi_value Draw(napi_env env, napi_callback_info info) {
 }
 static napi_value SetViewport(napi_env env, napi_callback_info info) {
   napi_value a[3]; void *h; uint32_t w, hh;
-  if (get_args(env, info, 3, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 3, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &w));
   NAPI_OK(napi_get_value_uint32(env, a[2], &hh));
   FSPT_OK_OR_THROW(fspt_target_set_viewport((fspt_target *)h, w, hh));
@@ -552,7 +665,7 @@ static napi_value SetViewport(napi_env env, napi_callback_info info) {
 }
 static napi_value SetShard(napi_env env, napi_callback_info info) {
   napi_value a[4]; void *h; uint32_t s, n, tile;
-  if (get_args(env, info, 4, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 4, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &s));
   NAPI_OK(napi_get_value_uint32(env, a[2], &n));
   NAPI_OK(napi_get_value_uint32(env, a[3], &tile));
@@ -561,7 +674,7 @@ static napi_value SetShard(napi_env env, napi_callback_info info) {
 }
 static napi_value SetPipeline(napi_env env, napi_callback_info info) {
   napi_value a[3]; void *h; int32_t p; uint32_t b;
-  if (get_args(env, info, 3, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 3, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_int32(env, a[1], &p));
   NAPI_OK(napi_get_value_uint32(env, a[2], &b));
   FSPT_OK_OR_THROW(fspt_target_set_pipeline((fspt_target *)h, p, b));
@@ -570,7 +683,7 @@ static napi_value SetPipeline(napi_env env, napi_callback_info info) {
 static napi_value SetPool(napi_env env, napi_callback_info info) {
   /* setPool(target, paths, drainIterations, maxIterations, overlap): fspt_target_set_pool (stream scheduler) */
   napi_value a[5]; void *h; uint32_t paths, cap; int32_t drain, overlap;
-  if (get_args(env, info, 5, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 5, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &paths));
   NAPI_OK(napi_get_value_int32(env, a[2], &drain));
   NAPI_OK(napi_get_value_uint32(env, a[3], &cap));
@@ -580,14 +693,14 @@ static napi_value SetPool(napi_env env, napi_callback_info info) {
 }
 static napi_value SetTraceBudget(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; uint32_t steps;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &steps));
   FSPT_OK_OR_THROW(fspt_target_set_trace_budget((fspt_target *)h, steps));
   return undefined(env);
 }
 static napi_value SetMemoryLimit(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; double bytes;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h) || get_f64(env, a[1], &bytes)) return NULL;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_TARGET, &h) || get_f64(env, a[1], &bytes)) return NULL;
   if (!(bytes >= 0.0 && bytes < 1.8e19)) { napi_throw_range_error(env, NULL, "fspt_napi: memory limit must be >= 0 bytes"); return NULL; }
   FSPT_OK_OR_THROW(fspt_target_set_memory_limit((fspt_target *)h, (uint64_t)bytes));
   return undefined(env);
@@ -601,7 +714,7 @@ static napi_value SetTextureInterleaveBudget(napi_env env, napi_callback_info in
 }
 static napi_value PathStateBytes(napi_env env, napi_callback_info info) {
   napi_value a[1], o, v; void *h; uint64_t bytes = 0; uint32_t batch = 0;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   FSPT_OK_OR_THROW(fspt_target_path_state_bytes((fspt_target *)h, &bytes, &batch));
   NAPI_OK(napi_create_object(env, &o));
   NAPI_OK(napi_create_double(env, (double)bytes, &v));
@@ -612,20 +725,20 @@ static napi_value PathStateBytes(napi_env env, napi_callback_info info) {
 }
 static napi_value Prepare(napi_env env, napi_callback_info info) {
   napi_value a[1]; void *h;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   FSPT_OK_OR_THROW(fspt_target_prepare((fspt_target *)h));
   return undefined(env);
 }
 static napi_value EnableCounters(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; bool on;
-  if (get_args(env, info, 2, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 2, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   NAPI_OK(napi_get_value_bool(env, a[1], &on));
   FSPT_OK_OR_THROW(fspt_enable_counters((fspt_target *)h, on ? 1 : 0));
   return undefined(env);
 }
 static napi_value GetCounters(napi_env env, napi_callback_info info) {
   napi_value a[1]; void *h;
-  if (get_args(env, info, 1, a) || unwrap(env, a[0], &h)) return NULL;
+  if (get_args(env, info, 1, a) || unwrap_k(env, a[0], H_TARGET, &h)) return NULL;
   fspt_counters c;
   FSPT_OK_OR_THROW(fspt_get_counters((fspt_target *)h, &c));
   napi_value o, v;
@@ -687,15 +800,16 @@ static napi_value BuilderCreate(napi_env env, napi_callback_info info) {
   (void)info;
   fspt_builder *b = NULL;
   FSPT_OK_OR_THROW(fspt_builder_create(&b));
-  napi_value h;
-  NAPI_OK(napi_create_external(env, b, NULL, NULL, &h));
+  napi_value h = make_handle(env, H_BUILDER, b, 1, NULL, NULL);
+  if (!h) fspt_builder_destroy(b);
   return h;
 }
 static napi_value BuilderDestroy(napi_env env, napi_callback_info info) {
   napi_value a[1]; void *h;
   if (get_args(env, info, 1, a)) return NULL;
-  NAPI_OK(napi_get_value_external(env, a[0], &h));
-  fspt_builder_destroy((fspt_builder *)h);
+  fspt_handle *hb;
+  if (unwrap_k(env, a[0], H_BUILDER, &h) || unwrap_box(env, a[0], H_BUILDER, &hb)) return NULL;
+  handle_release(env, hb);
   return undefined(env);
 }
 /* builderParseObj(b, objText, {rotate, scale, translate, normals}, worldTransforms[] | null, skips[] | null)
@@ -704,7 +818,7 @@ static napi_value BuilderDestroy(napi_env env, napi_callback_info info) {
 static napi_value BuilderParseObj(napi_env env, napi_callback_info info) {
   napi_value a[5]; void *h;
   if (get_args(env, info, 5, a)) return NULL;
-  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  if (unwrap_k(env, a[0], H_BUILDER, &h)) return NULL;
   fspt_builder *b = (fspt_builder *)h;
   fspt_prop_desc pd;
   memset(&pd, 0, sizeof(pd));
@@ -787,7 +901,7 @@ static napi_value BuilderParseObj(napi_env env, napi_callback_info info) {
 static napi_value BuilderCommit(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h;
   if (get_args(env, info, 2, a)) return NULL;
-  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  if (unwrap_k(env, a[0], H_BUILDER, &h)) return NULL;
   uint32_t n = 0;
   NAPI_OK(napi_get_array_length(env, a[1], &n));
   fspt_group_material *gm = (fspt_group_material *)calloc(n ? n : 1, sizeof(*gm));
@@ -812,7 +926,7 @@ done:
 static napi_value BuilderNormalize(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; double size;
   if (get_args(env, info, 2, a)) return NULL;
-  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  if (unwrap_k(env, a[0], H_BUILDER, &h)) return NULL;
   if (get_f64(env, a[1], &size)) return NULL;
   FSPT_OK_OR_THROW(fspt_builder_normalize((fspt_builder *)h, size));
   return undefined(env);
@@ -821,7 +935,7 @@ static napi_value BuilderNormalize(napi_env env, napi_callback_info info) {
 static napi_value BuilderBuild(napi_env env, napi_callback_info info) {
   napi_value a[2]; void *h; uint32_t leaf = 4;
   if (get_args(env, info, 2, a)) return NULL;
-  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  if (unwrap_k(env, a[0], H_BUILDER, &h)) return NULL;
   NAPI_OK(napi_get_value_uint32(env, a[1], &leaf));
   fspt_builder *b = (fspt_builder *)h;
   FSPT_OK_OR_THROW(fspt_builder_build(b, leaf));
@@ -843,7 +957,7 @@ static napi_value BuilderBuild(napi_env env, napi_callback_info info) {
 static napi_value BuilderAutofocus(napi_env env, napi_callback_info info) {
   napi_value a[3]; void *h; double eye[3], dir[3], dist = 0;
   if (get_args(env, info, 3, a)) return NULL;
-  NAPI_OK(napi_get_value_external(env, a[0], &h));
+  if (unwrap_k(env, a[0], H_BUILDER, &h)) return NULL;
   for (uint32_t k = 0; k < 3; ++k) {
     napi_value e;
     napi_get_element(env, a[1], k, &e); if (get_f64(env, e, &eye[k])) return NULL;
@@ -879,6 +993,19 @@ static napi_value RandBaseNext(napi_env env, napi_callback_info info) {
 static napi_value DeviceCount(napi_env env, napi_callback_info info) {
   napi_value v; napi_create_int32(env, fspt_device_count(), &v); return v;
 }
+/* deviceMemory(device) -> {free, total} in bytes (fspt_device_memory) */
+static napi_value DeviceMemory(napi_env env, napi_callback_info info) {
+  napi_value a[1], o, v; int32_t dev; uint64_t f = 0, t = 0;
+  if (get_args(env, info, 1, a)) return NULL;
+  NAPI_OK(napi_get_value_int32(env, a[0], &dev));
+  FSPT_OK_OR_THROW(fspt_device_memory(dev, &f, &t));
+  NAPI_OK(napi_create_object(env, &o));
+  NAPI_OK(napi_create_double(env, (double)f, &v));
+  NAPI_OK(napi_set_named_property(env, o, "free", v));
+  NAPI_OK(napi_create_double(env, (double)t, &v));
+  NAPI_OK(napi_set_named_property(env, o, "total", v));
+  return o;
+}
 static napi_value AbiVersion(napi_env env, napi_callback_info info) {
   napi_value v; napi_create_int32(env, fspt_abi_version(), &v); return v;
 }
@@ -891,11 +1018,11 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"setMemoryLimit", SetMemoryLimit}, {"setTextureInterleaveBudget", SetTextureInterleaveBudget}, {"pathStateBytes", PathStateBytes}, {"prepare", Prepare}, {"setTail", SetTail}, {"setDeferred", SetDeferred}, {"setStageTiming", SetStageTiming},
       {"renderAsync", RenderAsync}, {"multiCreate", MultiCreate}, {"multiDestroy", MultiDestroy}, {"multiTarget", MultiTarget},
       {"multiCamera", MultiCamera}, {"multiTrace", MultiTrace}, {"multiRender", MultiRender}, {"multiRenderAsync", MultiRenderAsync},
-      {"multiClear", MultiClear}, {"multiSync", MultiSync}, {"multiSetExchange", MultiSetExchange}, {"multiGetExchange", MultiGetExchange}, {"multiReadRadiance", MultiReadRadiance}, {"multiDraw", MultiDraw},
+      {"multiClear", MultiClear}, {"multiSync", MultiSync}, {"multiSetExchange", MultiSetExchange}, {"multiGetExchange", MultiGetExchange}, {"multiLastStageMs", MultiLastStageMs}, {"multiReadRadiance", MultiReadRadiance}, {"multiDraw", MultiDraw},
       {"enableCounters", EnableCounters}, {"counters", GetCounters}, {"builderCreate", BuilderCreate}, {"builderDestroy", BuilderDestroy},
       {"builderParseObj", BuilderParseObj}, {"builderCommit", BuilderCommit}, {"builderNormalize", BuilderNormalize},
       {"builderBuild", BuilderBuild}, {"builderAutofocus", BuilderAutofocus}, {"envBins", EnvBins},
-      {"randBaseNext", RandBaseNext}, {"deviceCount", DeviceCount}, {"abiVersion", AbiVersion}};
+      {"randBaseNext", RandBaseNext}, {"deviceCount", DeviceCount}, {"deviceMemory", DeviceMemory}, {"abiVersion", AbiVersion}};
   for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
     napi_value f;
     if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;

@@ -132,6 +132,10 @@ class TileGather:
                 self.big = torch.zeros((world * max(1, self.n_max), channels), dtype=torch.float32, device=device)
                 self.recv = list(self.big.split(max(1, self.n_max)))
                 self.slots = slots
+            # the zero fills above ran on torch's current stream, the pack / unpack kernels run on the library's own: order
+            # them once, here (the holes of ragged tiles rely on the fill having happened before the first pack)
+            if self.send.is_cuda:
+                torch.cuda.current_stream(self.send.device).synchronize()
             return
         self.idx = owned_pixel_index(rank, world, width, height, tile, device)
         counts = [int(owner_mask(r, world, width, height, tile).sum()) for r in range(world)]
@@ -161,7 +165,11 @@ class TileGather:
         """Own pixels of accum ([H, W, 4]) -> self.send ([n_max, channels])."""
         import torch
         if self.tracer is not None:
-            self.tracer.pack_tiles(self.send.data_ptr(), self.C)  # (accum is the tracer's bound accumulator; blocking)
+            bound = getattr(self.tracer, "bound_ptr", None)
+            if bound is not None and accum is not None and accum.data_ptr() != bound:
+                raise ValueError("TileGather.pack: `accum` is not the accumulator the tracer is bound to "
+                                 "(the library's pack kernel reads the bound one)")
+            self.tracer.pack_tiles(self.send.data_ptr(), self.C)  # blocking
             return self.send
         flat = accum.view(-1, 4)
         n = self.idx.numel()

@@ -15,6 +15,10 @@
  * All compute happens in the HIP kernels behind fspt_napi.node; errors surface as JS Errors.
  */
 const addon = require('./fspt_napi.node');
+const ABI_VERSION = 4;   // include/fspt.h FSPT_ABI_VERSION this module was written against
+if (addon.abiVersion() !== ABI_VERSION) {
+  throw new Error('libfspt.so has ABI version ' + addon.abiVersion() + ', fspt.js needs ' + ABI_VERSION + ': stale build (python -c "import __graft_entry__ as g; g.build()")');
+}
 
 function jsNum(v) { return String(Number(v)); }
 
@@ -331,12 +335,17 @@ class PathTracer {
     this.pingpong += nTicks;
   }
   /** render(nTicks) on a worker thread (napi_async_work): resolves when the ticks are on the device's accumulator.
-   *  Do not call anything else on this tracer until it settles. */
+   *  Until it settles every other call on this tracer throws Error('render in flight') (enforced by the addon: the
+   *  library's contract is one thread at a time per target, like the reference's single-threaded tick(),
+   *  main.js:838-857); close() waits for it. */
   renderAsync(nTicks) {
     const p = addon.renderAsync(this._target, { P: this.eye, I: this.dir, fovScale: this.fovScale, lens: this.lensFeatures,
       envTheta: this.envTheta, numBounces: this.numBounces }, this.pingpong, nTicks, this._rng[0]);
     for (let k = 0; k < 2 * nTicks; k++) this._randBase();
     this.pingpong += nTicks;
+    const settled = p.then(() => {}, () => {});
+    this._inflight = settled;
+    settled.then(() => { if (this._inflight === settled) this._inflight = null; });
     return p;
   }
   clear() { addon.clear(this._target); this.pingpong = 0; }                                  // main.js:826-836
@@ -377,8 +386,13 @@ class PathTracer {
   enableCounters(on) { addon.enableCounters(this._target, !!on); }
   counters() { return addon.counters(this._target); }
   /** Recorded (deferred) ticks are executed first: fspt_target_destroy itself drops them (it never writes to a
-   *  caller-owned accumulator, include/fspt.h). */
-  close() { if (this._target) { try { addon.sync(this._target); } finally { addon.targetDestroy(this._target); addon.sceneDestroy(this._scene); this._target = null; } } }
+   *  caller-owned accumulator, include/fspt.h).  With a renderAsync in flight close() waits for it and returns a
+   *  Promise; otherwise it is synchronous.  (A tracer that is simply dropped is cleaned up by the handles' finalizers.) */
+  close() {
+    if (this._inflight) return this._inflight.then(() => this.close());
+    if (this._target) { try { addon.sync(this._target); } finally { addon.targetDestroy(this._target); addon.sceneDestroy(this._scene); this._target = null; this._scene = null; } }
+    return undefined;
+  }
 }
 
 /** The same frame driver over several GPUs of the node from this one JS thread (include/fspt.h: fspt_multi_*):
@@ -403,7 +417,21 @@ class MultiPathTracer {
   tick() { this.drawCamera(); this.drawTracer(this.pingpong); this.pingpong++; }
   _advance(nTicks) { for (let k = 0; k < 2 * nTicks; k++) this._randBase(); this.pingpong += nTicks; }
   render(nTicks) { addon.multiRender(this._multi, this._params(), this.pingpong, nTicks, this._rng[0]); this._advance(nTicks); }
-  renderAsync(nTicks) { const p = addon.multiRenderAsync(this._multi, this._params(), this.pingpong, nTicks, this._rng[0]); this._advance(nTicks); return p; }
+  /** as PathTracer.renderAsync: other calls throw Error('render in flight') until it settles; close() waits */
+  renderAsync(nTicks) {
+    const p = addon.multiRenderAsync(this._multi, this._params(), this.pingpong, nTicks, this._rng[0]);
+    this._advance(nTicks);
+    const settled = p.then(() => {}, () => {});
+    this._inflight = settled;
+    settled.then(() => { if (this._inflight === settled) this._inflight = null; });
+    return p;
+  }
+  /** per device [render, pack, transfer, scatter] ms of the most recent render + read-out (fspt_multi_last_stage_ms; -1 = did not run) */
+  stageMs() {
+    const flat = addon.multiLastStageMs(this._multi, this.devices.length), out = [];
+    for (let i = 0; i < this.devices.length; i++) out.push(Array.from(flat.subarray(4 * i, 4 * i + 4)));
+    return out;
+  }
   clear() { addon.multiClear(this._multi); this.pingpong = 0; }
   sync() { addon.multiSync(this._multi); }
   /** the read-out exchange (include/fspt_multi.h): 'peer' (hipMemcpyPeerAsync of the packed tiles, default), 'rccl_gather'
@@ -429,7 +457,11 @@ class MultiPathTracer {
     const code = pipelineCode(name);
     for (let i = 0; i < this.devices.length; i++) addon.setPipeline(addon.multiTarget(this._multi, i), code, batch || 0);
   }
-  close() { if (this._multi) { addon.multiDestroy(this._multi); this._multi = null; } }
+  close() {
+    if (this._inflight) return this._inflight.then(() => this.close());
+    if (this._multi) { addon.multiDestroy(this._multi); this._multi = null; }
+    return undefined;
+  }
 }
 
 // memory later scenes may spend on interleaved material textures (fspt_set_texture_interleave_budget; results do not depend on it)

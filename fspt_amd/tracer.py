@@ -120,6 +120,7 @@ class PathTracer:
         collective can run on it in place; `keep` is held to keep it alive."""
         self._keep = keep
         L.check(L.lib().fspt_target_bind_accumulator(self._t, C.c_void_p(device_ptr)))
+        self.bound_ptr = int(device_ptr)  # what pack_tiles / unpack_tiles read and write (distributed.TileGather checks it)
 
     # ---- the two ends of a one-process-per-GPU read-out exchange (include/fspt.h) -----------------------------
     def shard_slots(self, shard, n_shards):

@@ -32,7 +32,13 @@
 extern "C" {
 #endif
 
-#define FSPT_ABI_VERSION 3
+/* 4 (round 6): the entry points rounds 5-6 added (fspt_intersect_form, fspt_scene_two_level_nodes, fspt_target_set_node_form,
+ * fspt_target_set_stage_timing, fspt_target_shard_slots / _pack_tiles / _unpack_tiles, fspt_multi_set_exchange /
+ * _get_exchange, fspt_multi_last_stage_ms) and two changes of behaviour: fspt_target_destroy DROPS recorded ticks (a host
+ * that wants them executed calls fspt_sync first - PathTracer.close() does), and under fspt_target_set_memory_limit a frame
+ * that cannot hold 8 ticks of path state runs on the stream scheduler's bounded pool.  The bindings compare
+ * fspt_abi_version() with this value when they load the library. */
+#define FSPT_ABI_VERSION 4
 
 enum {
   FSPT_OK = 0,

@@ -43,6 +43,13 @@ int fspt_multi_read_radiance(fspt_multi *m, float *out);
 int fspt_multi_draw(fspt_multi *m, float exposure, float saturation, int denoise, float max_sigma, uint8_t *out_rgba8);
 /* Bytes that crossed between devices in the most recent gather (the exchange's payload: 16 bytes per foreign pixel). */
 int fspt_multi_last_gather_bytes(fspt_multi *m, uint64_t *bytes);
+/* Where the time of the most recent render + read-out went, per device: ms[i][0] = GPU time of device i's last render call
+ * (fspt_last_kernel_ms of its target), [1] = its pack kernel(s), [2] = its copy / send / reduce to devices[0], [3] = the
+ * scatter of its tiles on devices[0]; -1 where a stage did not run (devices[0] packs nothing in the copy / gather modes; in
+ * the reduce mode only entry 0 has a [3]: the copy of the reduced frame into the accumulator).  n_devices must be the
+ * count the handle was made with.  Waits for the devices.  (Round 6: so that the first run on more than one physical GPU
+ * shows imbalance and exchange cost in one pass - none has happened yet) */
+int fspt_multi_last_stage_ms(fspt_multi *m, float *ms /* [n_devices][4] */, uint32_t n_devices);
 int fspt_multi_size(fspt_multi *m, uint32_t *width, uint32_t *height);  /* the frame fspt_multi_create was given */
 /* How target i's tiles reach devices[0]: bit 0 = its device can write devices[0]'s memory (the direction the gather
  * copy runs), bit 1 = the reverse mapping; 0 = staged through the host; a target on devices[0] itself reports 3. */

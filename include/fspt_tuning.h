@@ -110,6 +110,10 @@ int fspt_last_stage_ms(fspt_target *target, float ms[5], uint32_t launches[5]);
  * the tree instead of the vector-memory pipeline (bench.py's request-rate roofline). */
 int fspt_get_trace_lds_steps(fspt_target *target, uint64_t *steps);
 
+/* Free and total memory of a device as the HIP runtime reports it (hipMemGetInfo): what a host sizes its batches against,
+ * and how the tests check that dropped tracers give their memory back. */
+int fspt_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
+
 /* ---- test hook ------------------------------------------------------------------------------------------------------ */
 /* Device-side evaluation of the deterministic math primitives (DESIGN.md
  * "fspt-math"), for bitwise comparison against the oracle's C versions.

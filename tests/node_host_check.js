@@ -122,6 +122,46 @@ if (mode === 'scene_file') {
   out.radiance_peer = b64(mp.readRadiance());
   try { mp.setExchange('carrier-pigeon'); out.unknown = null; } catch (e) { out.unknown = String(e.message); }
   mp.close();
+} else if (mode === 'async_guard') {
+  // while renderAsync is in flight every other call on the tracer throws; close() waits for it (real library, real device)
+  const s = F.buildScene(job.props, job.objs, env, 4);
+  const pt = new F.PathTracer(s, job.W, job.H, 0);
+  pt.eye = job.cam.P; pt.dir = job.cam.I; pt.fovScale = job.cam.fov_scale; pt.envTheta = job.cam.env_theta;
+  pt.lensFeatures = job.cam.lens; pt.numBounces = job.bounces;
+  pt.seed(job.seed);
+  const thrown = (f) => { try { f(); return null; } catch (e) { return String(e.message); } };
+  const p = pt.renderAsync(job.ticks);
+  out.during = { readRadiance: thrown(() => pt.readRadiance()), tick: thrown(() => pt.tick()), clear: thrown(() => pt.clear()),
+    sync: thrown(() => pt.sync()), render: thrown(() => pt.render(1)), renderAsync: thrown(() => pt.renderAsync(1)) };
+  p.then(() => {
+    out.radiance = b64(pt.readRadiance());
+    const q = pt.renderAsync(job.ticks);   // ... and close() right behind a second job waits for it
+    const c = pt.close();
+    out.close_returned_promise = !!(c && typeof c.then === 'function');
+    return Promise.all([q, c]).then(() => {
+      out.after_close = thrown(() => pt.readRadiance());
+      fs.writeFileSync(process.argv[4], JSON.stringify(out));
+    });
+  }).catch((e) => { console.error(e); process.exit(1); });
+} else if (mode === 'drop_tracers') {
+  // tracers that are dropped without close(): the handles' finalizers give the device memory back
+  const s = F.buildScene(job.props, job.objs, env, 4);
+  const sleep = (ms) => new Promise((r) => setTimeout(r, ms));
+  const free = () => F.addon.deviceMemory(0).free;
+  (async () => {
+    { const warm = new F.PathTracer(s, job.W, job.H, 0); warm.render(2); warm.readRadiance(); warm.close(); }   // runtime pools, code objects
+    for (let i = 0; i < 4; i++) { global.gc(); await sleep(5); }
+    out.free_start = free();
+    let kept = new F.PathTracer(s, job.W, job.H, 0);
+    kept.render(2); kept.readRadiance();
+    out.free_with_one = free();
+    kept = null;
+    for (let k = 0; k < job.n; k++) { const pt = new F.PathTracer(s, job.W, job.H, 0); pt.render(2); pt.readRadiance(); }   // never closed
+    out.free_before_gc = free();
+    for (let i = 0; i < 8; i++) { global.gc(); await sleep(10); }
+    out.free_end = free();
+    fs.writeFileSync(process.argv[4], JSON.stringify(out));
+  })().catch((e) => { console.error(e); process.exit(1); });
 } else if (mode === 'bounces_range') {
   // NUM_BOUNCES outside [0, 64] or not an integer: RangeError at the N-API boundary, before any device call
   out.errors = {};

@@ -45,7 +45,12 @@ def test_binding_covers_header():
 
 
 def test_abi_version():
-    assert L.lib().fspt_abi_version() == 3
+    """header, library and both bindings agree (a stale libfspt.so is refused with a clear message at load, not with an
+    AttributeError on the first new entry point)"""
+    import re
+    hdr = int(re.search(r"#define FSPT_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "fspt.h")).read()).group(1))
+    js = int(re.search(r"const ABI_VERSION = (\d+)", open(os.path.join(ROOT, "fspt_amd", "js", "fspt.js")).read()).group(1))
+    assert L.lib().fspt_abi_version() == hdr == L.ABI_VERSION == js == 4
 
 
 def test_rand_base_stream_range():

@@ -23,7 +23,7 @@ def run_node(mode, job):
     with tempfile.TemporaryDirectory() as td:
         jp, op = os.path.join(td, "job.json"), os.path.join(td, "out.json")
         json.dump(job, open(jp, "w"))
-        subprocess.check_call(["node", os.path.join(ROOT, "tests", "node_host_check.js"), mode, jp, op], timeout=300)
+        subprocess.check_call(["node", "--expose-gc", os.path.join(ROOT, "tests", "node_host_check.js"), mode, jp, op], timeout=300)
         return json.load(open(op))
 
 
@@ -39,13 +39,13 @@ def dec(b, dt):
 
 def test_addon_exports():
     out = run_node("exports", {})
-    assert out["abi"] == 3
+    assert out["abi"] == 4
     for name in ("sceneCreate", "targetCreate", "camera", "trace", "render", "clear", "readRadiance", "setShard",
                  "builderCreate", "builderParseObj", "builderCommit", "builderNormalize", "builderBuild",
                  "builderAutofocus", "builderDestroy", "envBins", "counters", "renderAsync", "multiCreate", "multiRender",
                  "multiRenderAsync", "multiReadRadiance", "multiDraw", "multiTarget", "multiDestroy", "setTail",
                  "setMemoryLimit", "prepare", "setTextureInterleaveBudget", "setPool", "setTraceBudget", "setStageTiming", "multiSetExchange",
-                 "multiGetExchange"):
+                 "multiGetExchange", "multiLastStageMs", "deviceMemory"):
         assert name in out["exports"]
 
 
@@ -143,6 +143,38 @@ def test_js_multi_device_and_async_render(small_scene, camera):
              0, 6, 33, want)
     assert np.array_equal(dec(out["radiance"], np.float32).reshape(H, W, 4), want)
     assert np.array_equal(dec(out["radiance_single"], np.float32).reshape(H, W, 4), want)
+
+
+@pytest.mark.gpu
+def test_js_render_async_is_guarded(small_scene, camera):
+    """while a renderAsync job is inside fspt_render on the libuv worker, readRadiance() / tick() /
+    clear() / sync() / render() / a second renderAsync() on the same tracer throw Error('render in flight') instead of
+    racing it; the frame it resolves with is the oracle's; close() behind a job in flight returns a Promise and waits.
+    (The addon's logic alone, without a device: tests/test_napi_handles.py.)"""
+    W, H = 160, 96
+    job = small_job()
+    job.update(W=W, H=H, bounces=4, seed=51, ticks=6,
+               cam=dict(P=camera["P"], I=camera["I"], fov_scale=camera["fov_scale"], env_theta=camera["env_theta"], lens=camera["lens"]))
+    out = run_node("async_guard", job)
+    for name, msg in out["during"].items():
+        assert msg == "render in flight", (name, msg)
+    want = np.zeros((H, W, 4), np.float32)
+    O.render(small_scene, W, H, camera["P"], camera["I"], camera["fov_scale"], camera["lens"], camera["env_theta"], 4, 0, 6, 51, want)
+    assert np.array_equal(dec(out["radiance"], np.float32).reshape(H, W, 4), want)  # the refused calls left no trace
+    assert out["close_returned_promise"] is True
+    assert out["after_close"] is not None  # the tracer is closed: its handle is gone
+
+
+@pytest.mark.gpu
+def test_js_dropped_tracers_return_their_device_memory():
+    """50 PathTracers rendered and dropped without close(): the externals' finalizers destroy target and scene (the scene
+    after its target) when the objects are collected, and the device's free memory is back where it started."""
+    job = small_job()
+    job.update(W=256, H=192, n=50)
+    out = run_node("drop_tracers", job)
+    per_tracer = out["free_start"] - out["free_with_one"]
+    assert per_tracer > 1 << 20, out  # a tracer does hold device memory (accumulator, ray buffers, path state)
+    assert out["free_end"] >= out["free_start"] - (2 << 20), out  # all of it came back (HIP allocates in 2 MiB granules)
 
 
 @pytest.mark.gpu
