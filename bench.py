@@ -78,7 +78,7 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=15.0):
+def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=11.0):
     """The oracle (kind 'port': plain-C restatement, OpenMP over rows) timed on this host's cores on a bounded,
     uniformly tile-sampled part of the SAME frame: shard 0 of S round-robin 32x32-tile shards, S chosen from a probe."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -110,6 +110,22 @@ def cpu_baseline(arrays, W, H, cam, lens, bounces, budget_s=15.0):
     return {"value": round(s / t / 1e6, 5), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"oracle/liboracle.so (C restatement, OpenMP x{cores}), {n_ticks} tick(s) over every "
                       f"{n_shards}-th 32x32 tile of the same {W}x{H} depth-{bounces} frame: {s} samples in {t:.2f} s"}
+
+
+def reference_glsl_baseline():
+    """The reference's own tracer.fs timed beside the number (north_star) - a RECORDED figure: the GLSL cannot travel to
+    the GPU box (nothing of /root/reference may), so it was run once in the build container (tools/glsl_baseline.py:
+    unmodified camera.fs + tracer.fs on SwiftShader, BASELINE configs[0] on the scene this bench renders) and the committed
+    result is quoted here, never re-measured in this run."""
+    path = os.path.join(ROOT, "profiles", "r03", "glsl_baseline_config1.json")
+    if not os.path.exists(path):
+        return None
+    j = json.load(open(path))
+    return {"value": j["Msamples_per_s_total"], "unit": "Msamples/s", "after_first_tick": j["Msamples_per_s_after_first_tick"],
+            "renderer": j["renderer"], "cores": j["cores"], "where": "build container (8 vCPU, no GPU), NOT this box",
+            "config": "BASELINE configs[0]: " + j["config"], "kind": "reference (recorded)", "measured_in_this_run": False,
+            "source": "profiles/r03/glsl_baseline_config1.json (tools/glsl_baseline.py; BASELINE.md 3.2)",
+            "oracle_same_frame_same_container": j["oracle_same_frame"]["Msamples_per_s"]}
 
 
 def parity_check(arrays, W, H, cam, lens, bounces, n_ticks, seed, got, budget_samples=3.0e7):
@@ -156,6 +172,9 @@ def parse_args(argv=None):
     ap.add_argument("--textured", action="store_true", help="2048^2 image maps on the floor quads (scene/bunny.json:18-41)")
     ap.add_argument("--tex-interleave-budget", type=int, default=None,
                     help="bytes of interleaved material textures the scene may use (A/B: 0 = single-layer images only)")
+    ap.add_argument("--tick-mode", action="store_true",
+                    help="a step is ONE tick() call (drawCamera + drawTracer, main.js:838-857) followed by a sync - the interactive "
+                         "form, where every sample is observed before the next is issued - instead of one tick of a fused render(steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-events", default="last", choices=["first", "last", "all"],
                     help="which timed regions carry the per-launch HIP event pairs behind the per-kernel times (they cost ~1.3 %% of a "
@@ -295,6 +314,8 @@ def dry_run(args, rank, local_rank, world):
 def _extra_argv(argv, over, steps, warmup):
     """The command line of an extra config: this run's own arguments with the workload-selecting ones replaced."""
     drop_val = {"--config", "--steps", "--warmup", "--width", "--height", "--scaling", "--mesh-n", "--aperture", "--sun-deg", "--sun-gain", "--batch"}
+    if "reps" in over:
+        drop_val.add("--reps")
     out, skip = [], False
     for a in argv:
         if skip:
@@ -307,7 +328,9 @@ def _extra_argv(argv, over, steps, warmup):
             continue
         out.append(a)
     out += ["--config", over["config"], "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extra-configs"]
-    return out
+    if "reps" in over:
+        out += ["--reps", str(over["reps"])]
+    return out + list(over.get("flags", ()))
 
 
 def trim_extra(o, seconds):
@@ -359,7 +382,7 @@ def run_workload(args, env):
     pt.set_shard(rank, n_gpus, D.TILE)
     # a batch never holds more ticks than the longest call of this run: path state is allocated (and page-touched) for
     # that, not for the 128-tick maximum (216 bytes per pixel and tick: 57 GB at 1920x1080 x 128, 9 GB x 20)
-    args.batch = max(1, min(args.batch, max(args.steps, args.warmup)))
+    args.batch = 1 if args.tick_mode else max(1, min(args.batch, max(args.steps, args.warmup)))
     pt.set_pipeline(args.pipeline, args.batch)
     if args.primary_form:
         pt.set_primary_form(args.primary_form)
@@ -388,9 +411,18 @@ def run_workload(args, env):
                 dist.barrier()
         torch.cuda.synchronize()
 
+    def advance(n):
+        """n steps: one fused render call, or (--tick-mode) n x [tick(); sync()] - every tick observed before the next"""
+        if not args.tick_mode:
+            pt.render(n)
+            return
+        for _ in range(n):
+            pt.tick()
+            pt.sync()
+
     # ---- warmup (untimed) ----
     if args.warmup > 0:
-        pt.render(args.warmup)
+        advance(args.warmup)
     barrier()
     # ---- timed: --reps regions of exactly K steps each, every one closed by the path's one exchange step ----
     foreign = (~torch.from_numpy(D.owner_mask(rank, n_gpus, W, H))).to(accum.device) if (n_gpus > 1 and args.exchange == "reduce") else None
@@ -403,7 +435,7 @@ def run_workload(args, env):
         pt.set_stage_timing(args.stage_events == "all" or rep_i == _event_region(args))
         barrier(f"barrier before region {rep_i}")
         t_start = time.perf_counter()
-        pt.render(args.steps)
+        advance(args.steps)
         pt.sync()
         t_render = time.perf_counter()
         with D.Watchdog(args.rendezvous_timeout if n_gpus > 1 else 0, f"read-out exchange ({args.exchange}) of region {rep_i}", rank):
@@ -548,11 +580,15 @@ def main():
     extras = []
     if not args.no_extra_configs and args.config == "c2" and args.pipeline == "wavefront" and not args.textured:
         if n_gpus == 1:
-            extras = [("c3", dict(config="c3")), ("c5", dict(config="c5"))]
+            # configs[2] and [4]; the workload shaped like the reference's real scene (scene/bunny.json:18-41 image-maps both
+            # quads: 2048^2 atlas layers); and the interactive form - 128 single tick() calls, each observed before the next
+            # (main.js:838-857 displays every sample), ms_per_step = ms per tick
+            extras = [("c3", dict(config="c3")), ("c5", dict(config="c5")), ("textured", dict(config="c2", flags=["--textured"])),
+                      ("tick1", dict(config="c2", flags=["--tick-mode"], steps=128, warmup=8, reps=3))]
         elif args.scaling == "weak":
             extras = [("strong_c4", dict(config="c4"))]
     for key, over in extras:
-        a2 = parse_args(_extra_argv(sys.argv[1:], over, steps=min(args.steps, 20), warmup=min(args.warmup, 5)))
+        a2 = parse_args(_extra_argv(sys.argv[1:], over, steps=over.get("steps", min(args.steps, 20)), warmup=over.get("warmup", min(args.warmup, 5))))
         t_x = time.perf_counter()
         pending.append((key, run_workload(a2, env), time.perf_counter() - t_x))
     # ---- every collective of the job is done: the other ranks leave now; rank 0's oracle checks and counting ticks (no
@@ -838,7 +874,8 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "reps": args.reps, "rep_ms_per_step": [round(t * 1e3 / args.steps, 4) for t in times],
         "config": {"workload": f"{args.config}: bunny-synthetic {arrays.n_tris} tri{' + 2048^2 image maps' if args.textured else ''}, "
-                               f"{W}x{H}, depth {args.bounces}, 1 spp/step, aperture {cam['aperture']}, sun {args.sun_deg} deg x{args.sun_gain:g}",
+                               f"{W}x{H}, depth {args.bounces}, 1 spp/step, aperture {cam['aperture']}, sun {args.sun_deg} deg x{args.sun_gain:g}"
+                               + (", every step = one tick() call + sync (the interactive form, main.js:838-857)" if args.tick_mode else ""),
                    "scene_bytes": arrays.nbytes(), "bvh_nodes": arrays.n_nodes, "bvh_depth": arrays.depth,
                    "env_bins": int(arrays.bins.size // 4), "atlas": f"{arrays.atlas_res}^2 x {arrays.atlas_layers}",
                    "sharding": f"32x32 tiles round-robin over {n_gpus}", "world_size_seen": world_seen,
@@ -851,6 +888,7 @@ def report(args, pt, arrays, cam, lens, W, H, n_gpus, world_seen, value, elapsed
     }
     if n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(arrays, W, H, cam, lens, args.bounces)
+        out["reference_glsl_baseline"] = reference_glsl_baseline()
     return out
 
 

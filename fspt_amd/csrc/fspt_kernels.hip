@@ -1050,6 +1050,13 @@ FM_DEV V3 ld3(const float *p) {
 FM_DEV int ldi(const int *p) { return *p; }
 FM_DEV void sti(int *p, int v) { *p = v; }
 
+// The wave's index in its block as a SCALAR (round 6): threadIdx.x / 64 is the same for the 64 lanes of a wave, but the
+// compiler does not know that, so everything derived from it - the wave's pool-head address, its LDS stack base - lived in
+// vector registers.  In k_wf_trace the 64-bit head address was spilled to scratch and RELOADED AFTER EVERY LEAF VISIT (the
+// leaf code needs the registers): one more vector-memory instruction per leaf visit in the kernel that is bound by exactly
+// those; k_wf_tail spilled three such values.  With the readfirstlane both kernels use no scratch at all: trace launches
+// -5 % (70 k triangles), -4 % (1 M), whole job +1.7 ... +2.2 % (profiles/r06/ab_small3_*.log, isa_trace_spill.txt).
+FM_DEV int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)); }
 FM_DEV uint32_t lane_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -1179,7 +1186,7 @@ template <bool COUNT, bool ANYHIT, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK_THREADS, WF_TRACE_WAVES) void k_wf_trace(const WfP p) {
   extern __shared__ int lds_stack[];
   const int lane = threadIdx.x & (WAVE - 1);
-  const int wave = threadIdx.x / WAVE;
+  const int wave = wave_index();
   const DScene &S = p.scene;
   // one more LDS entry per lane than the tree needs: the lane's finished shadow result while its extension ray is traced
   // (a suspended traversal's record carries it along)
@@ -1549,7 +1556,7 @@ __global__ __launch_bounds__(WF_PRIMARY_THREADS, WF_LOGIC_WAVES) void k_wf_prima
   static_assert(R >= 1 && R <= WF_PRIMARY_R_MAX, "k_wf_primary: R");
   __shared__ uint32_t s_off[2], s_base[2], s_next[2];
   const int lane = threadIdx.x & (WAVE - 1);
-  const int wave = threadIdx.x / WAVE;
+  const int wave = wave_index();
   DScene S = p.scene;
   const float *s_rb = p.rb_trace;
   const WfSet out = p.set[p.set_out];
@@ -1912,7 +1919,7 @@ template <bool COUNT, bool ANYHIT, bool GEN, int WIDE = 0>
 __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const WfP p) {
   extern __shared__ int lds_stack[];
   const int lane = threadIdx.x & (WAVE - 1);
-  const int wave = threadIdx.x / WAVE;
+  const int wave = wave_index();
   const DScene &S = p.scene;
   int *stack = lds_stack + (size_t)wave * S.stack_n * WAVE + lane;
   const WfSet in = p.set[p.set_out];
