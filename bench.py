@@ -426,7 +426,7 @@ def run_workload(args, env):
     barrier()
     # ---- timed: --reps regions of exactly K steps each, every one closed by the path's one exchange step ----
     foreign = (~torch.from_numpy(D.owner_mask(rank, n_gpus, W, H))).to(accum.device) if (n_gpus > 1 and args.exchange == "reduce") else None
-    times, kernel_ms_all, stages_all, exch_ms, render_ms = [], [], [], [], []
+    times, kernel_ms_all, stages_all, exch_ms, render_ms, exch_stage_ms = [], [], [], [], [], []
     for rep_i in range(args.reps):
         # per-launch HIP event pairs (the per-kernel times of the report) in ONE region only, unless asked otherwise: the
         # last by default - warm and in the form the tuner settled on.  Of seven 20-step regions the first (first use of the
@@ -450,6 +450,7 @@ def run_workload(args, env):
         elapsed = time.perf_counter() - t_start
         exch_ms.append((time.perf_counter() - t_render) * 1e3)
         render_ms.append((t_render - t_start) * 1e3)
+        exch_stage_ms.append({k: round(v, 3) for k, v in exch.last_stage_ms.items()} if (exch is not None and exch.last_stage_ms) else None)
         if dist is not None:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else f"cuda:{local_rank}")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -472,6 +473,7 @@ def run_workload(args, env):
     if n_gpus > 1:
         sys.stderr.write("[bench rank] " + json.dumps(dict(rank_info, frame=[W, H], render_ms=[round(x, 3) for x in render_ms],
                                                            exchange_and_barrier_ms=[round(x, 3) for x in exch_ms],
+                                                           exchange_stage_ms=exch_stage_ms,  # per region: this rank's pack / collective / unpack (gather exchange)
                                                            kernel_ms=[round(k[0], 3) for k in kernel_ms_all])) + "\n")
         sys.stderr.flush()
 

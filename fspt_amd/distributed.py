@@ -119,6 +119,7 @@ class TileGather:
         assert channels in (3, 4)
         self.rank, self.world, self.dst, self.C = rank, world, dst, channels
         self.tracer = tracer
+        self.last_stage_ms = None
         if tracer is not None:
             # The library's own pack / unpack kernels (include/fspt_multi.h: fspt_target_pack_tiles / _unpack_tiles - the
             # k_tile_pack the single-process fspt_multi_* host uses): a shard's pixels in work-index order, one launch per
@@ -211,9 +212,18 @@ class TileGather:
         """accum: float32 [H, W, 4] on every rank (only own pixels non-zero); complete on `dst` afterwards.
         stage_host: the packed pieces travel through host memory (a backend without device-tensor gather: gloo with the
         ranks sharing one GPU, bench.py --share-gpu); packing and unpacking stay on the device."""
+        import time
         import torch
         import torch.distributed as dist
+
+        def done():  # the stage's work is finished on the device (host clock: the stages below are blocking by nature)
+            if accum.is_cuda:
+                torch.cuda.synchronize(accum.device)
+            return time.perf_counter()
+        t0 = time.perf_counter()
         self.pack(accum)
+        t1 = done()
+        t2 = t1
         if self.world > 1:
             if stage_host:
                 send = self.send.cpu()
@@ -223,8 +233,12 @@ class TileGather:
                     self.big.copy_(torch.cat(recv))
             else:
                 dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst)
+            t2 = done()
             if self.rank == self.dst:
                 self.unpack(accum)
+        # where this rank's share of the exchange went (bench.py prints it per rank: the first run on several physical
+        # GPUs shows pack / collective / scatter cost and imbalance in one pass)
+        self.last_stage_ms = {"pack": (t1 - t0) * 1e3, "collective": (t2 - t1) * 1e3, "unpack": (done() - t2) * 1e3}
         return accum
 
 

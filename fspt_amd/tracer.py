@@ -416,6 +416,15 @@ class MultiPathTracer:
         L.check(L.lib().fspt_multi_get_exchange(self._m, C.byref(m), C.byref(v)))
         return m.value, v.value
 
+    def stage_ms(self):
+        """Per device [render, pack, transfer, scatter] milliseconds of the most recent render + read-out
+        (fspt_multi_last_stage_ms; -1 = the stage did not run on that device).  Blocking."""
+        import numpy as np
+        n = len(self.devices)
+        out = np.zeros((n, 4), np.float32)
+        L.check(L.lib().fspt_multi_last_stage_ms(self._m, L.fptr(out), n))
+        return out
+
     def last_gather_bytes(self):
         b = C.c_uint64()
         L.check(L.lib().fspt_multi_last_gather_bytes(self._m, C.byref(b)))

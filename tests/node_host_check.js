@@ -151,6 +151,11 @@ if (mode === 'scene_file') {
   (async () => {
     { const warm = new F.PathTracer(s, job.W, job.H, 0); warm.render(2); warm.readRadiance(); warm.close(); }   // runtime pools, code objects
     for (let i = 0; i < 4; i++) { global.gc(); await sleep(5); }
+    // the yardstick: the same number of tracers alive at once and then CLOSED by hand (what the HIP runtime keeps of 50
+    // streams' worth of queues and signals after their destruction is its own pool, not a leak of this library's)
+    (() => { const held = []; for (let k = 0; k < job.n; k++) { const pt = new F.PathTracer(s, job.W, job.H, 0); pt.render(2); pt.readRadiance(); held.push(pt); }
+      for (const pt of held) pt.close(); })();
+    for (let i = 0; i < 4; i++) { global.gc(); await sleep(5); }
     out.free_start = free();
     // (allocations inside functions of their own: nothing of them stays reachable from this frame's registers)
     (() => { const kept = new F.PathTracer(s, job.W, job.H, 0); kept.render(2); kept.readRadiance(); out.free_with_one = free(); })();

@@ -1205,6 +1205,12 @@ def test_multi_device_target_bitwise(medium_scene, camera, n_dev):
     n_tiles = 7 * 4
     foreign = sum(len(range(s, n_tiles, n_dev)) for s in range(1, n_dev))
     assert mp.last_gather_bytes() == foreign * 32 * 32 * 16
+    # where the time went, per device (fspt_multi_last_stage_ms): every device rendered; devices[0] packs / sends nothing,
+    # every other one packed, sent and had its tiles scattered on devices[0]
+    ms = mp.stage_ms()
+    assert ms.shape == (n_dev, 4) and (ms[:, 0] > 0).all(), ms
+    assert (ms[0, 1:] == -1).all(), ms
+    assert (ms[1:, 1:] >= 0).all(), ms
     assert np.array_equal(mp.draw(1.3, 0.9, True, 2.0), O.draw(want, 1.3, 0.9, True, 2.0))
     mp.clear()
     mp.seed(77)
@@ -1325,6 +1331,8 @@ def test_multi_rccl_exchange_on_one_device(medium_scene, camera):
     assert part[..., 3].min() == 1.0
     mp.render(1)                       # the accumulation goes on behind a read-out that replaced the accumulator's contents
     assert np.array_equal(mp.readRadiance(), want)
+    ms = mp.stage_ms()  # reduce mode: the one device built its own-tiles frame, reduced it and took the result
+    assert ms.shape == (1, 4) and (ms[0] >= 0).all(), ms
     mp.set_exchange("rccl_gather")
     assert np.array_equal(mp.readRadiance(), want) and mp.last_gather_bytes() == 0
     assert np.array_equal(mp.draw(1.0, 1.0, False, 3.0), O.draw(want, 1.0, 1.0, False, 3.0))
