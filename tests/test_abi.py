@@ -77,6 +77,12 @@ def test_no_cpu_fallback(small_scene):
     devs = (C.c_int * 2)(0, 1)
     assert lib.fspt_multi_create(C.byref(d), devs, 2, 64, 48, C.byref(m)) == -2 and not m.value
     assert lib.fspt_multi_create(C.byref(d), devs, 0, 64, 48, C.byref(m)) == -1  # no devices listed
+    # round 6's entry points: the memory query needs a device too; the stage-time query refuses a NULL handle
+    f, t = C.c_uint64(), C.c_uint64()
+    assert lib.fspt_device_memory(0, C.byref(f), C.byref(t)) == -2
+    assert lib.fspt_device_memory(0, None, C.byref(t)) == -1
+    ms = np.zeros(8, np.float32)
+    assert lib.fspt_multi_last_stage_ms(None, L.fptr(ms), 2) == -1
 
 
 def test_scene_validation_errors(small_scene):
