@@ -442,6 +442,7 @@ static napi_value render_async(napi_env env, napi_callback_info info, int multi)
       napi_create_string_utf8(env, "fspt_render", NAPI_AUTO_LENGTH, &name) != napi_ok ||
       napi_create_async_work(env, NULL, name, render_execute, render_complete, j, &j->work) != napi_ok ||
       napi_queue_async_work(env, j->work) != napi_ok) {
+    if (j->work) napi_delete_async_work(env, j->work); /* created but not queued */
     napi_delete_reference(env, j->box_ref);
     free(j);
     napi_throw_error(env, NULL, "fspt_napi: could not queue the async work");
