@@ -258,6 +258,7 @@ struct WfP {
   uint32_t *live_out;
   uint32_t zero_rounds;
   uint32_t carry_blocks; // logic launch: this many trailing blocks do k_wf_carry's work instead (one launch less per round)
+  uint32_t tail_slice;    // tail kernel: traversal steps of a lane per T phase (0: WF_TAIL_SLICE); the host picks it by scene size
   uint32_t tail_adaptive; // tail kernel with its `wide` bit set: two-level nodes only once the wave's list is used up (k_wf_tail WIDE = 2)
   uint32_t wide;        // bit k: kernel class k (WF_K_PRIMARY / WF_K_TRACE / WF_K_TAIL) walks the two-level nodes (scene.quads; same results)
   uint32_t primary_r;   // k_wf_primary: 1 = one traversal per lane, 2 = per-lane refill over 2 x 64 samples per wave (same results)

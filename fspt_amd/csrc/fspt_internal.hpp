@@ -44,6 +44,12 @@ struct fspt_scene {
 };
 
 static const int WF_ARRAYS = 15;
+#ifndef FSPT_TAIL_SLICE_LARGE
+#define FSPT_TAIL_SLICE_LARGE 16u // scenes of >= 2^18 triangles (fspt_sched_batch.cpp wf_tail_slice)
+#endif
+#ifndef FSPT_TAIL_SLICE_SMALL
+#define FSPT_TAIL_SLICE_SMALL 32u
+#endif
 #ifndef FSPT_SUSP_BUDGET
 #define FSPT_SUSP_BUDGET 24 // profiles/r03/ab_trace_suspend_budget.log: 0 / 16 / 24 / 32 / 48 -> 3 883 / 3 938 / 3 940 / 3 935 / 3 921 Msamples/s in 20-step regions (same box, twice)
 #endif
@@ -221,6 +227,7 @@ int ev_begin(fspt_target *t, int kind, hipStream_t stream);
 void ev_end(fspt_target *t, int i, hipStream_t stream);
 void wf_collect_counts(fspt_target *t, fspt_target::WfLane &ln);
 uint32_t wide_bit(const fspt_target *t, int kind, double paths);
+uint32_t wf_tail_slice(const fspt_target *t); // fspt_sched_batch.cpp: the tail kernel's slice length for this target's scene
 int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint32_t first_tick, uint32_t n_ticks,
                      const float *rb_cam, const float *rb_trace, bool rays_from_buffers);
 // ---- fspt_sched_stream.cpp

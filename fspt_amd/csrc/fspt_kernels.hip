@@ -994,7 +994,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(const TraceP p) {
 #endif
 // measured on C2 (profiles/r01): 1 -> 0.462, 8 -> 0.348, 16 -> 0.338, 24 -> 0.336, 32 -> 0.343 ms per tick
 #ifndef WF_INTERIOR_MIN
-#define WF_INTERIOR_MIN 16
+#define WF_INTERIOR_MIN 24 // (round 6, on the trace kernel without its scratch reload: 16 -> 24: +0.9 % on the 70 k scene at 20 ticks, +3 % on the 1 M one; 8 / 20 / 32 lose or tie - profiles/r06/scan_constants*.log)
 #endif
 #ifndef WF_LOGIC_THREADS
 #define WF_LOGIC_THREADS 512
@@ -2061,7 +2061,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, WF_TAIL_WAVES) void k_wf_tail(const 
     }
     if (r_state != RAY_GOING) r_cur = REF_SENTINEL;
     uint32_t used = 0;
-    trace_slice<COUNT, WIDE>(S, stack, o, d, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), ANYHIT && !is_main, r_cur, r_sp, r_t, r_hit, WF_TAIL_SLICE,
+    trace_slice<COUNT, WIDE>(S, stack, o, d, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), ANYHIT && !is_main, r_cur, r_sp, r_t, r_hit, p.tail_slice ? p.tail_slice : WF_TAIL_SLICE,
                              used, cnt, exhausted && pool_next == pool_end && gen_done);
     if (r_state == RAY_GOING && r_cur == REF_SENTINEL) r_state = RAY_DONE;
     // a pair is ready when its extension ray is done and its shadow ray is done or was never cast

@@ -254,6 +254,13 @@ static uint32_t wf_tail_round(const fspt_target *t, uint64_t slots, uint32_t las
   return last + 1;
 }
 
+// Traversal steps per T phase of the tail kernel (k_wf_tail slices its rays so that finished pairs are shaded while long
+// rays go on).  Short slices pay where rays are long and scatter - the 1 M-triangle scene: tail launch 0.112-0.129 ->
+// 0.096-0.098 ms per tick at 16 steps (0.090 at 8), whole job +3.9 ... +5 % - and cost a single tick of the 70 k scene a few
+// per cent (round 4: +7 %; round 6: inside the launch's +-0.1 ms): chosen by scene size, like the primary launch's first
+// form (profiles/r06/scan_constants2_*.log).
+uint32_t wf_tail_slice(const fspt_target *t) { return t->scene->n_tris >= (1u << 18) ? FSPT_TAIL_SLICE_LARGE : FSPT_TAIL_SLICE_SMALL; }
+
 // Which node form a launch of kernel class `kind` over (an expected) `paths` paths walks: WfP::wide's bit for it.
 uint32_t wide_bit(const fspt_target *t, int kind, double paths) {
   if (!t->scene->quads || t->count) return 0u;
@@ -356,6 +363,7 @@ int render_wavefront(fspt_target *t, const fspt_camera_params *cam, uint32_t fir
     p.primary_r = form;
     p.wide = wide_bit(t, fspt::WF_K_PRIMARY, -1.0) | wide_bit(t, fspt::WF_K_TAIL, -1.0);
     p.tail_adaptive = (t->node_form[2] < 0 ? FSPT_WIDE_TAIL : t->node_form[2]) == 2 ? 1u : 0u;
+    p.tail_slice = wf_tail_slice(t);
     const bool time_primary = t->count == 0 && !t->prim_pending;
     bool prev_trace_suspends = false; // (no carry launch behind a trace launch that cannot have suspended anything)
     for (uint32_t r = 1; r <= last && r <= tail; ++r) {

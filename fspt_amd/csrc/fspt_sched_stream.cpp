@@ -124,6 +124,7 @@ int render_stream(fspt_target *t, const fspt_camera_params *cam, uint32_t first_
   base.primary_r = 1u; // (iterations of varying size: the plain form)
   base.wide = wide_bit(t, fspt::WF_K_PRIMARY, -1.0) | wide_bit(t, fspt::WF_K_TAIL, -1.0);
   base.tail_adaptive = (t->node_form[2] < 0 ? FSPT_WIDE_TAIL : t->node_form[2]) == 2 ? 1u : 0u;
+  base.tail_slice = wf_tail_slice(t);
 
   // everything already queued on the target's stream (clear, ray upload, earlier renders) comes first
   HIP_TRY(hipEventRecord(t->ev_start, t->stream));
