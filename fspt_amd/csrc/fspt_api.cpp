@@ -8,9 +8,6 @@
 #include "fspt_internal.hpp"
 
 #ifndef FSPT_NODE_TREELET
-#ifndef FSPT_STACK_SPARE
-#define FSPT_STACK_SPARE 1
-#endif
 #define FSPT_NODE_TREELET 0 // nodes per treelet below the breadth-first top of the tree; 0 = pre-order (profiles/r02: A/B on the 1 M-triangle scene)
 #endif
 
@@ -484,11 +481,11 @@ int fspt_scene_create(const fspt_scene_desc *desc, int device, fspt_scene **out)
   s->d.n_bins = desc->n_bins;
   s->d.leaf_size = desc->leaf_size;
   s->d.root_ref = ref[0];
-  // Entries of a lane's traversal stack.  The walk pushes a far child only at an INTERIOR node that has as many entries
-  // below it as it has ancestors, and the deepest interior node sits at depth max_depth - 1: the stack never holds more
-  // than max_depth entries.  (FSPT_STACK_SPARE: rounds 1-5 kept one entry more; it costs the 1 M-triangle scene - depth
-  // 22 - its sixth resident trace block per CU.)
-  s->d.stack_n = max_depth + FSPT_STACK_SPARE;
+  // Entries of a lane's traversal stack: one more than the walk can use (it pushes a far child only at an interior node,
+  // the deepest of which sits at depth max_depth - 1).  Dropping the spare entry gives the 1 M-triangle scene - depth 22 -
+  // its sixth resident trace block per CU at the price of the LDS copy of the top of the tree (8 nodes instead of 31):
+  // measured +-0 (profiles/r06/ab_final_constants_c3.log, f_spare0), so the spare stays.
+  s->d.stack_n = max_depth + 1;
   s->d.n_top = n_interior < 256u ? n_interior : 256u; // interior nodes numbered breadth-first
   s->depth = max_depth;
   s->n_nodes = N;
