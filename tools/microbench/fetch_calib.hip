@@ -61,6 +61,26 @@ __global__ __launch_bounds__(256) void k_gather(const char *__restrict__ t, uint
   }
   if (acc == 123.456f) out[0] = acc;
 }
+// Round 6: the same 16-byte random read with the load's cache-policy bits set (gfx940+ sc0 / sc1 / nt): does any policy
+// make the L2 ask the fabric for LESS than a 128-byte line (TCC_EA0_RDREQ_32B / _64B)?  The environment lookups of the
+// logic kernel use 16 bytes of every line they fetch.
+template <int POLICY> // 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 sc1 nt, 6 sc0 sc1 nt
+__global__ __launch_bounds__(256) void k_gather16_pol(const char *__restrict__ t, uint32_t bits, uint32_t reads, float *out) {
+  float acc = 0.f;
+  for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < reads; r += gridDim.x * 256u) {
+    const size_t line = perm(r, bits);
+    const char *p = t + line * 128u + (size_t)((mix(r) % 8u) * 16u);
+    f4 v;
+    if (POLICY == 1) asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (POLICY == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (POLICY == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (POLICY == 5) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    acc += v.x + v.w;
+  }
+  if (acc == 123.456f) out[0] = acc;
+}
 __global__ __launch_bounds__(256) void k_gather_pair8(const char *__restrict__ t, uint32_t bits, uint32_t reads, float *out) {
   float acc = 0.f;
   for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < reads; r += gridDim.x * 256u) {
@@ -122,6 +142,12 @@ int main(int argc, char **argv) {
   timed("k_gather<4>", 4.0 * rd, [&] { k_gather<4><<<grid, 256>>>(t, line_bits, rd, out); });
   timed("k_gather<8>", 8.0 * rd, [&] { k_gather<8><<<grid, 256>>>(t, line_bits, rd, out); });
   timed("k_gather<16>", 16.0 * rd, [&] { k_gather<16><<<grid, 256>>>(t, line_bits, rd, out); });
+  timed("k_gather16_pol<1>", 16.0 * rd, [&] { k_gather16_pol<1><<<grid, 256>>>(t, line_bits, rd, out); });
+  timed("k_gather16_pol<2>", 16.0 * rd, [&] { k_gather16_pol<2><<<grid, 256>>>(t, line_bits, rd, out); });
+  timed("k_gather16_pol<3>", 16.0 * rd, [&] { k_gather16_pol<3><<<grid, 256>>>(t, line_bits, rd, out); });
+  timed("k_gather16_pol<4>", 16.0 * rd, [&] { k_gather16_pol<4><<<grid, 256>>>(t, line_bits, rd, out); });
+  timed("k_gather16_pol<5>", 16.0 * rd, [&] { k_gather16_pol<5><<<grid, 256>>>(t, line_bits, rd, out); });
+  timed("k_gather16_pol<6>", 16.0 * rd, [&] { k_gather16_pol<6><<<grid, 256>>>(t, line_bits, rd, out); });
   timed("k_gather<64>", 64.0 * rd, [&] { k_gather<64><<<grid, 256>>>(t, line_bits, rd, out); });
   timed("k_gather_pair8", 16.0 * rd, [&] { k_gather_pair8<<<grid, 256>>>(t, line_bits, rd, out); });
   timed("k_hitrec192", 192.0 * rd192, [&] { k_hitrec192<<<grid, 256>>>(t, rec_bits, rd192, out); });
