@@ -75,6 +75,8 @@ def source_sha():
     h = hashlib.sha256()
     for f in ("fspt_kernels.hip", "fspt_device.hpp", "fspt_math.hpp", "fspt_internal.hpp", "fspt_api.cpp", "fspt_sched_batch.cpp", "fspt_sched_stream.cpp", "fspt_multi.cpp"):
         h.update(open(os.path.join(ROOT, "fspt_amd", "csrc", f), "rb").read())
+    import __graft_entry__ as G  # ... and of the flags they are compiled with
+    h.update(" ".join(G.LIB_FLAGS).encode())
     return h.hexdigest()[:16]
 
 

@@ -2,7 +2,7 @@
 # Per-kernel register / scratch / occupancy table of fspt_kernels.hip (hipcc -Rpass-analysis=kernel-resource-usage), demangled.
 # usage: tools/kernel_resources.sh [extra -D flags]
 cd "$(dirname "$0")/.." || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -Wno-unused-value -c --cuda-device-only \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off ${AB_SLP:--fno-slp-vectorize} -std=c++17 -Wno-unused-value -c --cuda-device-only \
   -Rpass-analysis=kernel-resource-usage "$@" fspt_amd/csrc/fspt_kernels.hip -o /tmp/fspt_kernels_res.o 2>&1 |
 python3 -c '
 import re, sys, subprocess
