@@ -22,6 +22,7 @@ with open("/tmp/fspt_san/stubs.cpp", "w") as f:
         if n in defined:
             continue
         f.write('const char *fspt_last_error(void) { return g_err; }\n' if n == "fspt_last_error"
+                else f'int fspt_abi_version(void) {{ return {L.ABI_VERSION}; }}\n' if n == "fspt_abi_version"  # (the binding checks it at load)
                 else f'int {n}(...) {{ fspt_set_error("{n}: not in the sanitizer build"); return -100; }}\n')
     f.write("}\n")
 PY
