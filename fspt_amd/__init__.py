@@ -6,4 +6,4 @@ the scene assembly helpers (scene).  Nothing here imports oracle/.
 """
 from ._lib import FsptError, lib  # noqa: F401
 from .scene import SceneArrays, build_scene, bunny_scene, BUNNY_CAMERA  # noqa: F401
-from .tracer import MultiPathTracer, PathTracer, Scene, bytes_per_sample, set_texture_interleave_budget  # noqa: F401
+from .tracer import MultiPathTracer, PathTracer, Scene, bytes_per_sample, device_memory, set_texture_interleave_budget  # noqa: F401

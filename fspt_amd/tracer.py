@@ -22,6 +22,14 @@ def set_texture_interleave_budget(nbytes):
     """Memory later Scene()s may spend on interleaved material textures (fspt_set_texture_interleave_budget)."""
     L.check(L.lib().fspt_set_texture_interleave_budget(int(nbytes)))
 
+def device_memory(device=0):
+    """(free, total) bytes of a device as the HIP runtime reports them (fspt_device_memory): what a host sizes its batches
+    against, and how the tests check that dropped tracers give their memory back."""
+    f, t = C.c_uint64(), C.c_uint64()
+    L.check(L.lib().fspt_device_memory(int(device), C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
+
+
 PIPELINES = {"megakernel": 0, "wavefront": 1, "stream": 2}  # fspt_target_set_pipeline codes
 
 

@@ -1343,6 +1343,29 @@ def test_multi_rccl_exchange_on_one_device(medium_scene, camera):
     mp2.close()
 
 
+def test_closed_tracers_return_their_device_memory(small_scene, camera):
+    """fspt_device_memory (hipMemGetInfo through the C ABI): a tracer holds device memory while it lives - accumulator, ray
+    buffers, path state - and close() gives it back.  (The JS host's dropped, never closed tracers:
+    tests/test_node_host.py::test_js_dropped_tracers_return_their_device_memory.)"""
+    import fspt_amd
+    free0, total = fspt_amd.device_memory(0)
+    assert 0 < free0 <= total
+    def eight():
+        pts = [make_pt(small_scene, 256, 192, camera, 4, "wavefront", 0) for _ in range(8)]
+        for pt in pts:
+            pt.render(2)
+            pt.readRadiance()
+        low = fspt_amd.device_memory(0)[0]
+        for pt in pts:
+            pt.close()
+        return low
+    eight()  # the yardstick: what the HIP runtime keeps of eight streams' queues after their destruction is its own pool
+    free1 = fspt_amd.device_memory(0)[0]
+    low = eight()
+    assert free1 - low > 8 << 20, (free1, low)  # eight live tracers do hold memory ...
+    assert fspt_amd.device_memory(0)[0] >= free1 - (4 << 20)  # ... and closing them gives all of it back
+
+
 def test_close_executes_recorded_ticks_into_a_bound_accumulator(small_scene, camera):
     """tick() only RECORDS (deferred execution, include/fspt.h) and fspt_target_destroy drops what is recorded -
     it never writes to a caller-owned buffer, which may be gone.  PathTracer.close() therefore executes the recorded
